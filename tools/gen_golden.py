@@ -1,0 +1,564 @@
+#!/usr/bin/env python3
+"""tools/gen_golden.py -- regenerate tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing here is
+needed on the GPU box: the fixtures it writes are plain data (inputs + the reference's
+outputs) and are committed.
+
+How the reference is executed:
+  * her.py, replay_buffer.py, models.py import as they are;
+  * normalizer.py, utils.py, ddpg_agent.py import mpi4py (absent here) -> an in-memory
+    stub module is installed first.  The stub supports W "ranks" as W threads of this
+    process with a barrier-based summing Allreduce, which is how multi-rank fixtures
+    (normalizer mean-of-ranks) are produced;
+  * bmirobot_env/* cannot be imported (gym + pybullet absent).  The two functions of it
+    that are on the hot path -- goal_distance (bmirobot_env_push_F.py:20-23) and
+    compute_reward (:84-90) -- are pulled out of the reference source with `ast` and
+    executed unmodified against a dummy object carrying reward_type/distance_threshold
+    (bmirobot_push_F.py:9,20).
+Every fixture is cross-checked against oracle/ before it is written, so a passing run
+of this script is itself the "oracle == reference" proof on this container.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import threading
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------- mpi stub
+class _World:
+    def __init__(self, size):
+        self.size = size
+        self.barrier = threading.Barrier(size)
+        self.slots = [None] * size
+        self.local = threading.local()
+
+    def rank(self):
+        return getattr(self.local, "rank", 0)
+
+
+_WORLD = _World(1)
+
+
+class _Comm:
+    def Get_rank(self):
+        return _WORLD.rank()
+
+    def Get_size(self):
+        return _WORLD.size
+
+    def _gather(self, x):
+        w = _WORLD
+        if w.size == 1:
+            return [x]
+        w.slots[w.rank()] = np.array(x, copy=True)
+        w.barrier.wait()
+        vals = [np.array(v, copy=True) for v in w.slots]
+        w.barrier.wait()
+        return vals
+
+    def Allreduce(self, x, buf, op=None):
+        vals = self._gather(x)
+        acc = np.zeros_like(buf)
+        for v in vals:                      # rank order 0..W-1, like a linear MPI_SUM
+            acc = acc + v
+        buf[...] = acc
+
+    def allreduce(self, x, op=None):
+        return sum(float(v) for v in self._gather(np.asarray(x)))
+
+    def Bcast(self, x, root=0):
+        vals = self._gather(x)
+        x[...] = vals[root]
+
+
+def install_mpi_stub():
+    m = types.ModuleType("mpi4py")
+    mpi = types.SimpleNamespace(COMM_WORLD=_Comm(), SUM="SUM")
+    m.MPI = mpi
+    sys.modules["mpi4py"] = m
+
+
+def set_world(size):
+    global _WORLD
+    _WORLD = _World(size)
+
+
+def run_ranks(fn, size):
+    """Run fn(rank) on `size` stub ranks (threads); returns the list of results."""
+    set_world(size)
+    out, err = [None] * size, []
+
+    def body(r):
+        _WORLD.local.rank = r
+        try:
+            out[r] = fn(r)
+        except BaseException as e:  # pragma: no cover
+            err.append(e)
+            _WORLD.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(size)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    set_world(1)
+    if err:
+        raise err[0]
+    return out
+
+
+# ----------------------------------------------------------------- reference extraction
+def load_reference():
+    install_mpi_stub()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import her, replay_buffer, normalizer, models, utils, ddpg_agent, arguments  # noqa: E401
+
+    return types.SimpleNamespace(her=her, replay_buffer=replay_buffer, normalizer=normalizer,
+                                 models=models, utils=utils, ddpg_agent=ddpg_agent, arguments=arguments)
+
+
+def reference_env():
+    """Dummy env whose compute_reward is the reference's own function body."""
+    path = os.path.join(REF, "bmirobot_env", "bmirobot_env_push_F.py")
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    ns = {"np": np}
+    wanted = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "goal_distance":
+            wanted["goal_distance"] = node
+        if isinstance(node, ast.ClassDef):
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == "compute_reward":
+                    wanted["compute_reward"] = sub
+    mod = ast.Module(body=[wanted["goal_distance"], wanted["compute_reward"]], type_ignores=[])
+    exec(compile(mod, path, "exec"), ns)
+
+    class _Env:
+        reward_type = "sparse"            # bmirobot_push_F.py:9
+        distance_threshold = 0.05         # bmirobot_push_F.py:20
+        compute_reward = ns["compute_reward"]
+
+    return _Env()
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+ENV_PARAMS = {"obs": 27, "goal": 3, "action": 4, "action_max": 0.5, "max_timesteps": 100}
+
+
+# ---------------------------------------------------------------------------- fixtures
+def gen_rng_kat(ref, out):
+    """F1: indices the reference's her.py derives from the legacy RNG stream."""
+    from oracle.her_replay import draw_her_indices, future_probability
+
+    env = reference_env()
+    cases, payload = [], {}
+    T = 100
+    for seed in (125, 126):
+        for n in (1, 2, 7, 64, 100, 5000):
+            for B in (100, 256, 1024):
+                for k in ((4, 8) if (n, B) == (100, 256) else (4,)):
+                    # tagged episodes: outputs reveal (e, t, her, future_t)
+                    ee, tt = np.meshgrid(np.arange(n), np.arange(T + 1), indexing="ij")
+                    obs = np.stack([ee, tt], -1).astype(np.float64)
+                    ag = np.stack([ee, tt, np.full_like(ee, 7)], -1).astype(np.float64)
+                    g = -np.ones((n, T, 3))
+                    act = np.zeros((n, T, 1))
+                    batch = {"obs": obs, "ag": ag, "g": g, "actions": act,
+                             "obs_next": obs[:, 1:], "ag_next": ag[:, 1:]}
+                    sampler = ref.her.her_sampler("future", k, env.compute_reward.__get__(env))
+                    np.random.seed(seed)
+                    tr = sampler.sample_her_transitions(batch, B)
+                    key, pos = np.random.get_state()[1:3]
+                    e = tr["obs"][:, 0].astype(np.int64)
+                    t = tr["obs"][:, 1].astype(np.int64)
+                    her = tr["g"][:, 2] == 7
+                    fut = np.where(her, tr["g"][:, 1], -1).astype(np.int64)
+                    assert np.all(tr["g"][her, 0] == e[her])
+                    # oracle cross-check
+                    rs = np.random.RandomState(seed)
+                    oe, ot, oh, of = draw_her_indices(rs, n, T, B, future_probability("future", k))
+                    assert np.array_equal(oe, e) and np.array_equal(ot, t) and np.array_equal(oh, her)
+                    assert np.array_equal(of[her], fut[her])
+                    assert np.array_equal(rs.get_state()[1], key) and rs.get_state()[2] == pos
+                    tag = f"s{seed}_n{n}_b{B}_k{k}"
+                    cases.append(tag)
+                    payload[tag + "_e"] = e.astype(np.int32)
+                    payload[tag + "_t"] = t.astype(np.int16)
+                    payload[tag + "_her"] = her
+                    payload[tag + "_future_t"] = fut.astype(np.int16)
+                    payload[tag + "_key"] = key.astype(np.uint32)
+                    payload[tag + "_pos"] = np.int32(pos)
+    payload["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "rng_kat.npz"), **payload)
+    print(f"rng_kat.npz: {len(cases)} cases")
+
+
+def gen_her_samples(ref, out):
+    """F2: full sample() outputs of the reference replay_buffer + her_sampler."""
+    from oracle.her_replay import EpisodeStore, future_probability
+    from rl_arm_under_sparse_reward_amd.synthetic import episode_checksum, make_episodes
+
+    env = reference_env()
+    payload, cases = {}, []
+    for (n, B, k, mode, seed, dseed) in [(7, 256, 4, "walk", 125, 11), (64, 256, 8, "walk", 126, 12),
+                                         (100, 1024, 4, "iid", 125, 1), (5, 100, 4, "walk", 3, 13),
+                                         (1, 64, 4, "walk", 9, 14)]:
+        eps = make_episodes(n, seed=dseed, mode=mode)
+        sampler = ref.her.her_sampler("future", k, env.compute_reward.__get__(env))
+        with quiet():
+            buf = ref.replay_buffer.replay_buffer(ENV_PARAMS, n * 100, sampler.sample_her_transitions)
+        buf.store_episode(eps)
+        np.random.seed(seed)
+        tr = buf.sample(B)
+        key, pos = np.random.get_state()[1:3]
+        # oracle cross-check (bitwise)
+        st = EpisodeStore(100, 27, 3, 4, n * 100)
+        rs = np.random.RandomState(seed)
+        st.store_episode(eps, rs)
+        otr, _ = st.sample(B, future_probability("future", k), rs)
+        for kk in tr:
+            assert tr[kk].dtype == otr[kk].dtype and np.array_equal(
+                tr[kk].view(np.uint8), otr[kk].view(np.uint8)), kk
+        tag = f"n{n}_b{B}_k{k}_{mode}"
+        cases.append(tag)
+        payload[tag + "_meta"] = np.array([n, B, k, seed, dseed], dtype=np.int64)
+        payload[tag + "_mode"] = np.array(mode)
+        payload[tag + "_checksum"] = np.float64(episode_checksum(eps))
+        for kk, v in tr.items():
+            payload[tag + "_" + kk] = v
+        payload[tag + "_key"] = key.astype(np.uint32)
+        payload[tag + "_pos"] = np.int32(pos)
+        payload[tag + "_success_frac"] = np.float64(np.mean(tr["r"] == 0))
+    payload["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "her_sample.npz"), **payload)
+    print("her_sample.npz:", cases, [float(payload[c + "_success_frac"]) for c in cases])
+
+
+def gen_reward_adversarial(out):
+    """F3: (ag, g) pairs around the 0.05 radius; rewards from the reference function."""
+    import math
+
+    from oracle.her_replay import compute_reward, squared_distance_threshold
+
+    env = reference_env()
+    rs = np.random.RandomState(5)
+    M = 4096
+    g = rs.uniform(-1, 1, (M, 3))
+    u = rs.normal(size=(M, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    radius = np.full(M, 0.05)
+    # nudge the radius by -6..+6 ulps of 0.05, plus exact zeros, tiny and huge offsets
+    ulps = rs.randint(-6, 7, M)
+    for i in range(M):
+        r = 0.05
+        for _ in range(abs(int(ulps[i]))):
+            r = math.nextafter(r, math.inf if ulps[i] > 0 else -math.inf)
+        radius[i] = r
+    ag = g + u * radius[:, None]
+    ag[:64] = g[:64]                                    # identical rows -> d = 0 -> -0.0
+    ag[64:128] = g[64:128] + 1e-300                      # denormal-scale differences
+    ag[128:192] = g[128:192] + rs.uniform(-3, 3, (64, 3))  # far
+    # single-axis exact-threshold cases: |dx| = 0.05 exactly representable offset
+    ag[192:256] = g[192:256]
+    ag[192:256, 0] = g[192:256, 0] + 0.05
+    # refine a block so that the *computed* squared distance sits within a few ulps of s*
+    s_star = squared_distance_threshold(0.05)
+    for i in range(256, 1280):
+        d = ag[i] - g[i]
+        s = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+        for _ in range(60):
+            if abs(s - s_star) <= 4 * math.ulp(s_star):
+                break
+            scale = math.sqrt(s_star / s)
+            ag[i] = g[i] + (ag[i] - g[i]) * scale
+            d = ag[i] - g[i]
+            s = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+    r = env.compute_reward(ag, g, None)
+    assert r.dtype == np.float32
+    ro = compute_reward(ag, g)
+    assert np.array_equal(r.view(np.uint32), ro.view(np.uint32))
+    d = ag - g
+    s = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    assert np.array_equal((s >= s_star), (r != 0)), "squared-threshold rule disagrees with the reference"
+    bits = r.view(np.uint32)
+    assert set(np.unique(bits)) <= {0x80000000, 0xBF800000}
+    near = np.sum(np.abs(s - s_star) <= 8 * math.ulp(s_star))
+    np.savez_compressed(os.path.join(out, "reward_adversarial.npz"), ag=ag, g=g, r_bits=bits,
+                        s_star=np.float64(s_star))
+    print(f"reward_adversarial.npz: {M} pairs, {int(np.sum(bits == 0x80000000))} successes, {int(near)} within 8 ulp of s*")
+
+
+def gen_storage_idx(ref, out):
+    """F4: slot sequences of replay_buffer._get_storage_idx across its three branches."""
+    from oracle.her_replay import EpisodeStore
+
+    payload, cases = {}, []
+    small = {"obs": 2, "goal": 1, "action": 1, "action_max": 1.0, "max_timesteps": 3}
+    for (size_eps, incs, seed) in [(5, [2, 2, 2, 2, 1, 3, 1, 5, 7], 0), (5, [2, 2, 2, 2], 1), (5, [2, 2, 2, 2], 2),
+                                   (5, [2, 2, 2, 2], 3), (16, [5, 5, 5, 5, 1, 1, 16, 20], 42), (3, [1, 1, 1, 1, 1], 7),
+                                   (100, [64, 64, 2, 2, 2], 125)]:
+        with quiet():
+            buf = ref.replay_buffer.replay_buffer(small, size_eps * 3, None)
+        st = EpisodeStore(3, 2, 1, 1, size_eps * 3)
+        np.random.seed(seed)
+        rs = np.random.RandomState(seed)
+        seq, sizes = [], []
+        for inc in incs:
+            idx = np.atleast_1d(buf._get_storage_idx(inc)).astype(np.int64)
+            oidx = np.atleast_1d(st.storage_slots(inc, rs)).astype(np.int64)
+            assert np.array_equal(idx, oidx) and buf.current_size == st.current_size
+            seq.append(idx)
+            sizes.append(buf.current_size)
+        key, pos = np.random.get_state()[1:3]
+        tag = f"size{size_eps}_seed{seed}_n{len(incs)}"
+        cases.append(tag)
+        payload[tag + "_size"] = np.int64(size_eps)
+        payload[tag + "_seed"] = np.int64(seed)
+        payload[tag + "_incs"] = np.array(incs, dtype=np.int64)
+        payload[tag + "_slots"] = np.concatenate(seq)
+        payload[tag + "_current_size"] = np.array(sizes, dtype=np.int64)
+        payload[tag + "_key"] = key.astype(np.uint32)
+        payload[tag + "_pos"] = np.int32(pos)
+    payload["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(out, "storage_idx.npz"), **payload)
+    print("storage_idx.npz:", cases)
+
+
+def _norm_inputs(rank, step, size):
+    rs = np.random.RandomState(1000 + 17 * rank + step)
+    n = [100, 100, 37, 250, 1, 100][step % 6]
+    scale = [1.0, 30.0, 1e-3, 250.0, 1.0, 5.0][step % 6]     # 250 exceeds clip_obs=200 on purpose
+    return rs.normal(0.3 * (rank + 1), scale, size=(n, size))
+
+
+def gen_normalizer(ref, out):
+    """F5: float32 bit patterns of the running normalizer, world size 1 and 2."""
+    from oracle.running_norm import RunningNorm
+
+    payload = {}
+    for world in (1, 2):
+        for size in (27, 3):
+            def body(rank, size=size):
+                nz = ref.normalizer.normalizer(size=size, default_clip_range=5)
+                hist = []
+                for step in range(6):
+                    v = np.clip(_norm_inputs(rank, step, size), -200, 200)
+                    nz.update(v)
+                    if step % 2 == 1 or step == 4:          # sometimes two updates per recompute
+                        nz.recompute_stats()
+                        hist.append([np.array(a, copy=True) for a in
+                                     (nz.mean, nz.std, nz.total_sum, nz.total_sumsq, nz.total_count)])
+                probe = np.random.RandomState(5).normal(0, 40, size=(16, size))
+                return hist, nz.normalize(probe), probe
+
+            res = run_ranks(body, world)
+            for r in range(world):
+                assert all(np.array_equal(a, b) for h0, h1 in zip(res[0][0], res[r][0]) for a, b in zip(h0, h1))
+            hist, normed, probe = res[0]
+            # oracle cross-check: world ranks in lockstep with an explicit mean hook
+            locals_ = [RunningNorm(size, default_clip_range=5) for _ in range(world)]
+            ohist = []
+            for step in range(6):
+                for r, nz in enumerate(locals_):
+                    nz.update(np.clip(_norm_inputs(r, step, size), -200, 200))
+                if step % 2 == 1 or step == 4:
+                    acc = {}
+                    for name in ("local_sum", "local_sumsq", "local_count"):
+                        tot = np.zeros_like(getattr(locals_[0], name))
+                        for nz in locals_:
+                            tot = tot + getattr(nz, name)
+                        tot /= world
+                        acc[name] = tot
+                    for nz in locals_:
+                        it = iter([acc["local_sum"], acc["local_sumsq"], acc["local_count"]])
+                        nz._mean_over_ranks = lambda x, it=it: next(it).copy()
+                        nz.recompute_stats()
+                    nz0 = locals_[0]
+                    ohist.append([np.array(a, copy=True) for a in (nz0.mean, nz0.std, nz0.total_sum, nz0.total_sumsq, nz0.total_count)])
+            for h, oh in zip(hist, ohist):
+                for a, b in zip(h, oh):
+                    assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (world, size)
+            assert np.array_equal(locals_[0].normalize(probe), normed)
+            tag = f"w{world}_d{size}"
+            names = ("mean", "std", "total_sum", "total_sumsq", "total_count")
+            for i, h in enumerate(hist):
+                for nm, a in zip(names, h):
+                    payload[f"{tag}_r{i}_{nm}"] = a
+            payload[tag + "_n_recompute"] = np.int64(len(hist))
+            payload[tag + "_probe"] = probe
+            payload[tag + "_normalized"] = normed
+    payload["numpy_version"] = np.array(np.__version__)
+    payload["std_dtype"] = np.array(str(payload["w1_d27_r0_std"].dtype))
+    np.savez_compressed(os.path.join(out, "normalizer.npz"), **payload)
+    print("normalizer.npz: std dtype", payload["std_dtype"], "numpy", np.__version__)
+
+
+def gen_ddpg_update(ref, out):
+    """F6: three consecutive _update_network() calls + a polyak update on a seeded agent."""
+    import torch
+
+    from oracle import ddpg_update as oupd
+    from oracle.her_replay import EpisodeStore, future_probability
+    from oracle.running_norm import RunningNorm, update_normalizers
+    from rl_arm_under_sparse_reward_amd.synthetic import episode_checksum, make_episodes
+
+    torch.set_num_threads(1)
+    env = reference_env()
+    env.compute_reward = env.compute_reward.__get__(env)
+    args = ref.arguments.Args()
+    args.add_demo = False
+    args.cuda = False
+    args.buffer_size = 64 * 100
+    n_eps, dseed, np_seed = 64, 21, 125
+    eps = make_episodes(n_eps, seed=dseed, mode="walk")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(0)
+            with quiet():
+                agent = ref.ddpg_agent.ddpg_agent(args, env, dict(ENV_PARAMS))
+        finally:
+            os.chdir(cwd)
+    init_actor = {k: v.detach().clone() for k, v in agent.actor_network.state_dict().items()}
+    init_critic = {k: v.detach().clone() for k, v in agent.critic_network.state_dict().items()}
+    np.random.seed(np_seed)
+    agent.buffer.store_episode(eps)
+    first_two = [a[:2] for a in eps]
+    agent._update_normalizer(first_two)
+
+    grads, losses, batches = [], [], []
+    orig_sync = ref.ddpg_agent.sync_grads
+
+    def spy_sync(net):
+        grads.append(np.concatenate([p.grad.detach().numpy().ravel() for p in net.parameters()]).astype(np.float32))
+        return orig_sync(net)
+
+    ref.ddpg_agent.sync_grads = spy_sync
+    orig_backward = torch.Tensor.backward
+
+    def spy_backward(self, *a, **kw):
+        losses.append(float(self.detach()))
+        return orig_backward(self, *a, **kw)
+
+    torch.Tensor.backward = spy_backward
+    orig_sample = agent.buffer.sample
+
+    def spy_sample(bs):
+        tr = orig_sample(bs)
+        batches.append({k: v.copy() for k, v in tr.items()})
+        return tr
+
+    agent.buffer.sample = spy_sample
+    try:
+        snaps = []
+        for _ in range(3):
+            agent._update_network()
+            snaps.append((ref.utils._get_flat_params(agent.actor_network)[0].copy(),
+                          ref.utils._get_flat_params(agent.critic_network)[0].copy()))
+        agent._soft_update_target_network(agent.actor_target_network, agent.actor_network)
+        agent._soft_update_target_network(agent.critic_target_network, agent.critic_network)
+    finally:
+        ref.ddpg_agent.sync_grads = orig_sync
+        torch.Tensor.backward = orig_backward
+    key, pos = np.random.get_state()[1:3]
+    tgt_actor = ref.utils._get_flat_params(agent.actor_target_network)[0]
+    tgt_critic = ref.utils._get_flat_params(agent.critic_target_network)[0]
+
+    # ---- oracle cross-check of the whole pipeline (store -> norm -> 3x sample+update -> polyak)
+    rs = np.random.RandomState(np_seed)
+    st = EpisodeStore(100, 27, 3, 4, 64 * 100)
+    st.store_episode(eps, rs)
+    fp = future_probability("future", args.replay_k)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    update_normalizers(on, gn, first_two, fp, rs)
+    assert np.array_equal(on.mean, agent.o_norm.mean) and np.array_equal(on.std, agent.o_norm.std)
+    assert np.array_equal(gn.mean, agent.g_norm.mean) and np.array_equal(gn.std, agent.g_norm.std)
+    learner = oupd.DDPGLearner(init_actor, init_critic)
+    mb = []
+    for i in range(3):
+        tr, _ = st.sample(256, fp, rs)
+        for kk in tr:
+            assert np.array_equal(tr[kk], batches[i][kk]), kk
+        x, xn, a, r = oupd.minibatch_tensors(tr, on, gn)
+        mb.append((x.numpy(), xn.numpy(), a.numpy(), r.numpy()))
+        res = learner.update(x, xn, a, r)
+        assert res["actor_loss"] == losses[2 * i] and res["critic_loss"] == losses[2 * i + 1], (res, losses)
+        assert np.array_equal(res["actor_grads"], grads[2 * i]) and np.array_equal(res["critic_grads"], grads[2 * i + 1])
+        assert np.array_equal(learner.flat("actor"), snaps[i][0]) and np.array_equal(learner.flat("critic"), snaps[i][1])
+    learner.soft_update()
+    assert np.array_equal(learner.flat("actor_target"), tgt_actor)
+    assert np.array_equal(learner.flat("critic_target"), tgt_critic)
+    assert np.array_equal(rs.get_state()[1], key) and rs.get_state()[2] == pos
+
+    payload = dict(
+        meta=np.array([n_eps, dseed, np_seed, 256, args.replay_k], dtype=np.int64),
+        checksum=np.float64(episode_checksum(eps)),
+        init_actor=oupd.flatten(list(init_actor.values())), init_critic=oupd.flatten(list(init_critic.values())),
+        o_mean=agent.o_norm.mean, o_std=agent.o_norm.std, g_mean=agent.g_norm.mean, g_std=agent.g_norm.std,
+        actor_loss=np.array(losses[0::2], dtype=np.float64), critic_loss=np.array(losses[1::2], dtype=np.float64),
+        actor_grads_step1=grads[0], critic_grads_step1=grads[1],
+        actor_after_step1=snaps[0][0], critic_after_step1=snaps[0][1],
+        actor_after_step3=snaps[2][0], critic_after_step3=snaps[2][1],
+        actor_target_after_polyak=tgt_actor, critic_target_after_polyak=tgt_critic,
+        x_step1=mb[0][0], x_next_step1=mb[0][1], a_step1=mb[0][2], r_step1=mb[0][3],
+        key=key.astype(np.uint32), pos=np.int32(pos),
+        torch_version=np.array(torch.__version__), numpy_version=np.array(np.__version__),
+    )
+    np.savez_compressed(os.path.join(out, "ddpg_update.npz"), **payload)
+    print("ddpg_update.npz: losses", losses)
+
+
+def gen_demo(out):
+    from rl_arm_under_sparse_reward_amd.synthetic import write_demo_npz
+
+    write_demo_npz(os.path.join(out, "bmirobot_8_push_demo.npz"), n_episodes=8, seed=7)
+    print("bmirobot_8_push_demo.npz written (synthetic; the real 1000-episode files are absent from the mount)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    ref = load_reference()
+    todo = a.only.split(",") if a.only else ["rng", "her", "reward", "storage", "norm", "ddpg", "demo"]
+    if "rng" in todo:
+        gen_rng_kat(ref, a.out)
+    if "her" in todo:
+        gen_her_samples(ref, a.out)
+    if "reward" in todo:
+        gen_reward_adversarial(a.out)
+    if "storage" in todo:
+        gen_storage_idx(ref, a.out)
+    if "norm" in todo:
+        gen_normalizer(ref, a.out)
+    if "ddpg" in todo:
+        gen_ddpg_update(ref, a.out)
+    if "demo" in todo:
+        gen_demo(a.out)
+
+
+if __name__ == "__main__":
+    main()
