@@ -1,0 +1,210 @@
+/*
+ * rlarm_hip.h -- C ABI of librlarm_hip.so: the MI355X (gfx950) implementation of the
+ * HER-replay + DDPG-update hot path of PiggyCh/RL_arm_under_sparse_reward.
+ *
+ * The reference has no FFI of its own (pure Python); its seam is the
+ * set of duck-typed Python objects wired in ddpg_agent.py:24-53.  Each entry point below
+ * names the reference interface it stands in for (file:line relative to the reference
+ * root).  The Python mirror of those objects lives in rl_arm_under_sparse_reward_amd/ and
+ * binds this header with ctypes; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative hp_status otherwise;
+ *     hp_last_error() returns a thread-local message for the last failure;
+ *   - "host" pointers are caller-owned and only read/written during the call (the
+ *     reference's copy-in / copy-out semantics, replay_buffer.py:39-42, her.py:26);
+ *   - "dev" pointers are HIP device addresses (e.g. torch.Tensor.data_ptr());
+ *   - all kernels are enqueued on the context's stream (hp_ctx_set_stream), so work
+ *     is ordered with whatever else the caller enqueues on that stream;
+ *   - one calling thread per handle (the reference's locks are never contended).
+ *   - there is NO CPU fallback: without a gfx950 device hp_ctx_create fails.
+ */
+#ifndef RLARM_HIP_H
+#define RLARM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HP_ABI_VERSION 1
+
+typedef enum {
+    HP_OK = 0,
+    HP_ERR_INVALID = -1,   /* bad argument (maps to ValueError in the Python mirror) */
+    HP_ERR_EMPTY = -2,     /* sampling an empty buffer (numpy: "ValueError: high <= 0") */
+    HP_ERR_HIP = -3,       /* a HIP runtime call failed */
+    HP_ERR_NODEVICE = -4,  /* no gfx950 device visible */
+    HP_ERR_STATE = -5      /* call sequence error */
+} hp_status;
+
+typedef struct hp_ctx hp_ctx;
+typedef struct hp_rng hp_rng;
+typedef struct hp_buffer hp_buffer;
+typedef struct hp_norm hp_norm;
+typedef struct hp_agent hp_agent;
+
+int hp_abi_version(void);
+const char *hp_last_error(void);
+
+/* ---- context ---------------------------------------------------------------------- */
+int hp_ctx_create(int device_id, hp_ctx **out);
+/* stream == NULL selects a stream owned by the context */
+int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
+int hp_ctx_synchronize(hp_ctx *ctx);
+int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
+void hp_ctx_destroy(hp_ctx *ctx);
+
+/* ---- random stream ------------------------------------------------------------------
+ * Device-resident twin of numpy's legacy global RandomState, which the reference draws
+ * from at her.py:24,25,29,31 and replay_buffer.py:64,67 (seeded at train.py:36).
+ * State is interoperable with np.random.get_state()/set_state(): (key[624], pos). */
+int hp_rng_create(hp_ctx *ctx, hp_rng **out);
+int hp_rng_seed(hp_rng *rng, uint32_t seed);                              /* np.random.seed(int) */
+int hp_rng_set_state(hp_rng *rng, const uint32_t *key624, int32_t pos);   /* np.random.set_state */
+int hp_rng_get_state(hp_rng *rng, uint32_t *key624, int32_t *pos);        /* synchronises */
+/* test hooks: the primitive draws, results copied to host (synchronises) */
+int hp_rng_randint(hp_rng *rng, int64_t low, int64_t high, int64_t count, int64_t *host_out);
+int hp_rng_uniform(hp_rng *rng, int64_t count, double *host_out);
+void hp_rng_destroy(hp_rng *rng);
+
+/* ---- episodic replay buffer ------------------------------------------------------------
+ * replay_buffer.py:11-71.  Storage is float64 [size, T+1, obs], [size, T+1, goal],
+ * [size, T, goal], [size, T, action] in HBM (same layout as the reference's numpy arrays). */
+int hp_buffer_create(hp_ctx *ctx, int64_t size_episodes, int32_t T, int32_t obs_dim, int32_t goal_dim,
+                     int32_t act_dim, hp_buffer **out);
+/* replay_buffer.store_episode (:32-43) + _get_storage_idx (:57-71).  Host arrays, float64,
+ * C-contiguous [n_new, T+1, obs] / [n_new, T+1, goal] / [n_new, T, goal] / [n_new, T, action].
+ * Slot selection runs on the device and draws from `rng` exactly when the reference does. */
+int hp_buffer_store(hp_buffer *buf, hp_rng *rng, const double *obs, const double *ag, const double *g,
+                    const double *actions, int64_t n_new);
+int hp_buffer_info(hp_buffer *buf, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored,
+                   int32_t *T);
+/* slots chosen by the most recent hp_buffer_store (parity tests); synchronises */
+int hp_buffer_last_slots(hp_buffer *buf, int64_t *host_out, int64_t n);
+/* copy episodes [first, first+n) of one array back to the host: which = 0 obs, 1 ag, 2 g, 3 actions */
+int hp_buffer_read(hp_buffer *buf, int32_t which, int64_t first, int64_t n, double *host_out);
+
+/* replay_buffer.sample (:46-55) -> her_sampler.sample_her_transitions (her.py:13-41) with the
+ * sparse goal-distance reward of bmirobot_env_push_F.py:20-23,84-90 inlined.
+ *   future_p      her.py:8  (1 - 1/(1+replay_k));  0 disables relabelling
+ *   sq_threshold  smallest double s with sqrt(s) > distance_threshold (reward = -(s >= sq_threshold))
+ * Any host output pointer may be NULL.  r is float32 [B] with bit patterns 0x80000000 / 0xBF800000.
+ * e/t/future_t/her expose the drawn indices for parity tests (future_t is defined for every
+ * sample; the reference uses it only where her != 0). */
+typedef struct {
+    double *obs, *ag, *g, *actions, *obs_next, *ag_next; /* [B, dim] float64 */
+    float *r;                                            /* [B] */
+    int64_t *e, *t, *future_t;                           /* [B] */
+    uint8_t *her;                                        /* [B] */
+} hp_sample_out;
+int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
+                     const hp_sample_out *host_out);
+
+/* ---- running normalizer ----------------------------------------------------------------
+ * normalizer.py:5-70.  float32 accumulators/totals/mean; std is float64 when std_f32 == 0
+ * (what numpy >= 2 computes for the reference's expression) or float32 when std_f32 != 0
+ * (numpy 1.19.2, the version the reference pins). */
+int hp_norm_create(hp_ctx *ctx, int32_t size, double eps, double default_clip_range, int32_t std_f32,
+                   hp_norm **out);
+int hp_norm_update(hp_norm *nz, const double *v_host, int64_t rows);          /* normalizer.update :25-31 */
+/* normalizer.recompute_stats :40-57 split around the cross-rank mean (:34-38, :60-64):
+ *   begin: snapshot + zero the local accumulators; *dev_sync -> float32[2*size+1] = sum|sumsq|count
+ *   (caller all-reduces that vector and divides by world size -- RCCL -- or leaves it alone)
+ *   end:   totals += sync; mean/std recomputed. */
+int hp_norm_recompute_begin(hp_norm *nz, void **dev_sync, int64_t *n_floats);
+int hp_norm_recompute_end(hp_norm *nz);
+int hp_norm_recompute(hp_norm *nz);                                            /* single-rank: begin+end */
+/* host copies of the state (any pointer may be NULL); synchronises */
+int hp_norm_get(hp_norm *nz, float *mean, double *std, float *total_sum, float *total_sumsq, float *total_count,
+                float *local_sum, float *local_sumsq, float *local_count);
+int hp_norm_set_stats(hp_norm *nz, const float *mean, const double *std);    /* checkpoint load */
+/* normalizer.normalize :67-70 on host data (rollout / test path).  clip_range < 0 -> default */
+int hp_norm_normalize(hp_norm *nz, const double *v_host, int64_t rows, double clip_range, double *out_host);
+
+/* ddpg_agent._update_normalizer (:187-212): HER-sample T transitions out of the n_new
+ * episodes most recently passed to hp_buffer_store (still staged on the device), clip to
+ * +-clip_obs (:214-217), update both normalizers.  Does NOT recompute (call hp_norm_recompute*). */
+int hp_norm_update_from_staged(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, double future_p,
+                               double clip_obs);
+
+/* ---- DDPG learner -----------------------------------------------------------------------
+ * models.py:11-44 (actor 30-256-256-256-4, critic 34-256-256-256-1), ddpg_agent.py:220-277,
+ * torch.optim.Adam defaults (ddpg_agent.py:42-43), utils.py:6-69 flat parameter order. */
+typedef struct {
+    int32_t obs_dim, goal_dim, act_dim, hidden;
+    int32_t batch;           /* transitions per update (arguments.py:88) */
+    int32_t grad_world_size; /* informational (grads are SUMmed across ranks, utils.py:47) */
+    /* Python floats in the reference -> doubles here; they are narrowed to float32 exactly where
+     * torch narrows them (tensor-scalar ops) so the arithmetic matches. */
+    double max_action;       /* env action_max (bmirobot_env_push_F.py:75-78) */
+    double gamma;            /* arguments.py:89 */
+    double action_l2;        /* arguments.py:90 */
+    double lr_actor, lr_critic; /* arguments.py:91-92 */
+    double polyak;           /* arguments.py:93 */
+    double clip_obs;         /* arguments.py:87 */
+    double clip_range;       /* arguments.py:95 (normalizer default_clip_range) */
+    double adam_beta1, adam_beta2, adam_eps; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+} hp_agent_cfg;
+
+enum { HP_NET_ACTOR = 0, HP_NET_CRITIC = 1, HP_NET_ACTOR_TARGET = 2, HP_NET_CRITIC_TARGET = 3 };
+
+int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out);
+int64_t hp_agent_param_count(hp_agent *ag, int32_t net);   /* 140548 / 140801 for the reference sizes */
+/* flat float32 vectors in named_parameters() order (utils.py:18-40): fc1.weight, fc1.bias, ... */
+int hp_agent_set_params(hp_agent *ag, int32_t net, const float *flat_host, int64_t n);
+int hp_agent_get_params(hp_agent *ag, int32_t net, float *flat_host, int64_t n);
+int hp_agent_get_grads(hp_agent *ag, int32_t net, float *flat_host, int64_t n);  /* net = actor|critic */
+int hp_agent_get_adam(hp_agent *ag, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step);
+
+/* One ddpg_agent._update_network (:250-277) on a caller-provided, already normalised minibatch
+ * (host float32: x [B,obs+goal], x_next [B,obs+goal], actions [B,act], r [B]).
+ * losses_host[0] = actor_loss, [1] = critic_loss.  Synchronises. */
+int hp_agent_update_minibatch(hp_agent *ag, const float *x, const float *x_next, const float *actions,
+                              const float *r, float *losses_host);
+
+/* The hot loop (ddpg_agent.py:145-147): n_updates x { sample B transitions, relabel, reward, clip,
+ * normalise, 5 forwards, 3 backwards, Adam x2 } entirely on the device.  Asynchronous. */
+int hp_agent_sample_and_update(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng,
+                               double future_p, double sq_threshold, int32_t n_updates);
+/* losses of the most recent updates, newest last: out[2*i] actor, out[2*i+1] critic.  Synchronises. */
+int hp_agent_get_losses(hp_agent *ag, float *out_host, int32_t n_last);
+/* ddpg_agent._soft_update_target_network (:220-222) for both nets.  Asynchronous. */
+int hp_agent_soft_update(hp_agent *ag);
+/* actor forward on host inputs (rollout side, ddpg_agent.py:114-116): x [rows, obs+goal] -> actions [rows, act] */
+int hp_agent_actor_forward(hp_agent *ag, int32_t net, const float *x_host, int64_t rows, float *actions_host);
+
+/* Split-phase update for data-parallel ranks (utils.sync_grads, utils.py:43-48):
+ *   forward_backward: sample + forwards + backwards, leaves SUM-able gradients in one flat device
+ *   vector (*dev_grads, both nets, padded layout -- every rank has the same layout);
+ *   apply: Adam on whatever that vector holds after the caller's all-reduce. */
+int hp_agent_forward_backward(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng,
+                              double future_p, double sq_threshold);
+int hp_agent_grad_buffer(hp_agent *ag, void **dev_grads, int64_t *n_floats);
+int hp_agent_param_buffer(hp_agent *ag, void **dev_params, int64_t *n_floats); /* actor|critic, for Bcast (utils.py:6-15) */
+int hp_agent_apply(hp_agent *ag);
+int hp_agent_sync_targets(hp_agent *ag); /* ddpg_agent.py:33-34: targets := online nets */
+
+/* One training cycle's learner half (ddpg_agent.py:143-150) as one cached hipGraph:
+ *   store n_new episodes -> update normalizers (+recompute) -> n_batches updates -> soft update.
+ * Requires single-rank operation (no cross-rank exchange inside the graph). Asynchronous. */
+int hp_agent_train_cycle(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng,
+                         const double *obs, const double *ag_host, const double *g, const double *actions,
+                         int64_t n_new, double future_p, double sq_threshold, int32_t n_batches);
+
+/* timing hook for bench.py: average device time (ms) of the kernels tagged `which` over the
+ * last recorded region; see DESIGN.md "Measurement". */
+int hp_agent_profile(hp_agent *ag, int32_t enable);
+int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
+
+void hp_agent_destroy(hp_agent *ag);
+void hp_norm_destroy(hp_norm *nz);
+void hp_buffer_destroy(hp_buffer *buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLARM_HIP_H */

@@ -1,0 +1,199 @@
+"""ctypes binding of include/rlarm_hip.h (librlarm_hip.so, gfx950 HIP kernels).
+
+There is deliberately no fallback: if the shared library is missing or no MI355X is
+visible, every entry point of this package raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librlarm_hip.so")
+
+c_void_pp = C.POINTER(C.c_void_p)
+f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
+i64p = C.POINTER(C.c_int64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class HpError(RuntimeError):
+    pass
+
+
+class SampleOut(C.Structure):
+    _fields_ = [("obs", f64p), ("ag", f64p), ("g", f64p), ("actions", f64p), ("obs_next", f64p), ("ag_next", f64p),
+                ("r", f32p), ("e", i64p), ("t", i64p), ("future_t", i64p), ("her", u8p)]
+
+
+class AgentCfg(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("goal_dim", C.c_int32), ("act_dim", C.c_int32), ("hidden", C.c_int32),
+                ("batch", C.c_int32), ("grad_world_size", C.c_int32),
+                ("max_action", C.c_double), ("gamma", C.c_double), ("action_l2", C.c_double),
+                ("lr_actor", C.c_double), ("lr_critic", C.c_double), ("polyak", C.c_double),
+                ("clip_obs", C.c_double), ("clip_range", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h
+PROTOTYPES = {
+    "hp_abi_version": (C.c_int, []),
+    "hp_last_error": (C.c_char_p, []),
+    "hp_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
+    "hp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "hp_ctx_destroy": (None, [C.c_void_p]),
+    "hp_rng_create": (C.c_int, [C.c_void_p, c_void_pp]),
+    "hp_rng_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "hp_rng_set_state": (C.c_int, [C.c_void_p, u32p, C.c_int32]),
+    "hp_rng_get_state": (C.c_int, [C.c_void_p, u32p, C.POINTER(C.c_int32)]),
+    "hp_rng_randint": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, i64p]),
+    "hp_rng_uniform": (C.c_int, [C.c_void_p, C.c_int64, f64p]),
+    "hp_rng_destroy": (None, [C.c_void_p]),
+    "hp_buffer_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_void_pp]),
+    "hp_buffer_store": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p, C.c_int64]),
+    "hp_buffer_info": (C.c_int, [C.c_void_p, i64p, i64p, i64p, C.POINTER(C.c_int32)]),
+    "hp_buffer_last_slots": (C.c_int, [C.c_void_p, i64p, C.c_int64]),
+    "hp_buffer_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, f64p]),
+    "hp_buffer_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.POINTER(SampleOut)]),
+    "hp_buffer_destroy": (None, [C.c_void_p]),
+    "hp_norm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, c_void_pp]),
+    "hp_norm_update": (C.c_int, [C.c_void_p, f64p, C.c_int64]),
+    "hp_norm_recompute_begin": (C.c_int, [C.c_void_p, c_void_pp, i64p]),
+    "hp_norm_recompute_end": (C.c_int, [C.c_void_p]),
+    "hp_norm_recompute": (C.c_int, [C.c_void_p]),
+    "hp_norm_get": (C.c_int, [C.c_void_p, f32p, f64p, f32p, f32p, f32p, f32p, f32p, f32p]),
+    "hp_norm_set_stats": (C.c_int, [C.c_void_p, f32p, f64p]),
+    "hp_norm_normalize": (C.c_int, [C.c_void_p, f64p, C.c_int64, C.c_double, f64p]),
+    "hp_norm_update_from_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
+    "hp_norm_destroy": (None, [C.c_void_p]),
+    "hp_agent_create": (C.c_int, [C.c_void_p, C.POINTER(AgentCfg), c_void_pp]),
+    "hp_agent_param_count": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "hp_agent_set_params": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
+    "hp_agent_get_params": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
+    "hp_agent_get_grads": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
+    "hp_agent_get_adam": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int64, i64p]),
+    "hp_agent_update_minibatch": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, f32p]),
+    "hp_agent_sample_and_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                             C.c_double, C.c_int32]),
+    "hp_agent_get_losses": (C.c_int, [C.c_void_p, f32p, C.c_int32]),
+    "hp_agent_soft_update": (C.c_int, [C.c_void_p]),
+    "hp_agent_actor_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64, f32p]),
+    "hp_agent_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_double]),
+    "hp_agent_grad_buffer": (C.c_int, [C.c_void_p, c_void_pp, i64p]),
+    "hp_agent_param_buffer": (C.c_int, [C.c_void_p, c_void_pp, i64p]),
+    "hp_agent_apply": (C.c_int, [C.c_void_p]),
+    "hp_agent_sync_targets": (C.c_int, [C.c_void_p]),
+    "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
+                                       f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
+    "hp_agent_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "hp_agent_profile_read": (C.c_int, [C.c_void_p, f64p, C.c_int32]),
+    "hp_agent_destroy": (None, [C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load(path: str | None = None):
+    """dlopen the in-tree HIP library and attach prototypes.  Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise HpError(
+                f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        lib = C.CDLL(p)
+        missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        if missing:    # header/library mismatch (tests/test_abi.py asserts this list is empty)
+            raise HpError("librlarm_hip.so does not export: " + ", ".join(missing) + " -- rebuild it")
+        if lib.hp_abi_version() != 1:
+            raise HpError("librlarm_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(status: int):
+    """Translate an hp_status into the exception the reference would raise at the same spot."""
+    if status == 0:
+        return
+    msg = (load().hp_last_error() or b"").decode("utf-8", "replace")
+    if status in (-1, -2):          # HP_ERR_INVALID / HP_ERR_EMPTY -> numpy raises ValueError there
+        raise ValueError(msg)
+    raise HpError(f"[hp_status {status}] {msg}")
+
+
+def ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """Process-wide device context (one process per GPU, like one process per MPI rank)."""
+
+    _default = None
+
+    def __init__(self, device_id: int | None = None):
+        lib = load()
+        if device_id is None:
+            device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        check(lib.hp_ctx_create(int(device_id), C.byref(h)))
+        self.lib, self.h, self.device_id = lib, h, int(device_id)
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            cls._default = cls()
+        return cls._default
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.hp_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        import torch
+
+        torch.cuda.set_device(self.device_id)
+        self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream)
+
+    def synchronize(self):
+        check(self.lib.hp_ctx_synchronize(self.h))
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(160)
+        check(self.lib.hp_ctx_device_name(self.h, buf, 160))
+        return buf.value.decode()
+
+
+class DevicePointer:
+    """Zero-copy view of a library-owned device vector for torch (`torch.as_tensor(obj, device=...)`)."""
+
+    def __init__(self, address: int, n: int, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(address), False),
+                                         "version": 2}

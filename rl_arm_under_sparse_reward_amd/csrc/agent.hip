@@ -1,0 +1,1072 @@
+// agent.hip -- the DDPG learner on gfx950: fused HER-sample/normalise kernel, grouped FP32-MFMA
+// GEMMs for the five forward and three backward passes, loss kernel, fused Adam and polyak.
+// Reference: models.py:11-44, ddpg_agent.py:214-277, torch.optim.Adam (ddpg_agent.py:42-43).
+//
+// ---- why it is shaped like this --------------------------------------------------------
+// One update at batch 256 is 0.7 GFLOP over ~20 strictly dependent small matrix products:
+// microseconds of FP32-MFMA time, so the cost is the number of dependent launches, not math.
+//   * independent products of one dependency level go into ONE grouped launch
+//     (actor_target | critic | actor forward layer k together; dX and dW of a backward layer
+//     together), 19 launches per update;
+//   * every product uses v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain; there is no
+//     TF32 on gfx950 and 1e-5 loss parity needs fp32).  A 256-thread workgroup owns one
+//     32x32 output tile; its 4 wavefronts split the reduction dimension 4 ways (short
+//     dependent MFMA chains = low latency), partial tiles are combined through LDS in a fixed
+//     order (deterministic), and bias / ReLU / tanh / ReLU-mask run in the epilogue;
+//   * all state (weights, targets, Adam moments, step counter, normalizer statistics,
+//     RNG, buffer counters) is device resident and every kernel argument is constant across
+//     updates, so a whole training cycle (store -> normalizer -> 40 updates -> polyak) is one
+//     cached hipGraph launch.
+//
+// ---- HBM layout ------------------------------------------------------------------------
+// Parameter "arena" (float32): [actor | critic], each  W1[H][K1] b1[H] W2[H][H] b2[H] W3[H][H]
+// b3[H] W4[16][H] b4[16];  K1 = 32 for the actor, 48 for the critic, rows/cols beyond the real
+// sizes are zero and stay zero (their gradients are exactly zero).  Gradients, Adam m, Adam v
+// and the target networks use the same layout, so Adam and polyak are one elementwise pass.
+// Network inputs are rows of 48 floats: [ x (obs+goal = 30) | 0 0 | a/max_action (4) | 0.. ]:
+// the actor reads columns 0..31, the critic 0..47 (its W1 columns are permuted to match).
+#include "internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------- structures
+struct NetLayout {     // offsets in floats inside one net's arena segment
+    int K1;            // padded input width (multiple of 16)
+    int w1, b1, w2, b2, w3, b3, w4, b4, total;
+};
+
+enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_BIAS = 2, EPI_BIAS_TANH = 3, EPI_MASK = 4 };
+
+struct GemmProb {
+    const float *A, *B;
+    float *C;
+    const float *bias;   // EPI_BIAS*
+    const float *mask;   // EPI_MASK: gate on mask[m][n] > 0
+    float *bias_grad;    // non-null: also emit column sums of the A operand (db) from tile column 0
+    float *C2;           // EPI_BIAS_TANH: raw tanh output (needed by the backward pass)
+    int a_si, a_sk;      // A element strides: output-row index / reduction index
+    int b_sj, b_sk;      // B element strides: output-col index / reduction index
+    int ldc, ldmask, ldc2;
+    int M, N, K;         // output rows, output cols (multiples of 16), reduction length (multiple of 16)
+    int n_store;         // only columns < n_store are written
+    int epi;
+    int tile0, tiles_n;  // first workgroup of this problem, tiles along N
+    float max_action;    // EPI_BIAS_TANH
+};
+
+#define MAX_PROBS 6
+struct GemmGroup {
+    int n;
+    GemmProb p[MAX_PROBS];
+};
+
+struct Pass {  // hidden activations of one forward pass
+    float *h1, *h2, *h3;
+};
+
+struct AgentDevState {      // small device-resident scalars
+    long long step;         // Adam step counter (both optimizers step together)
+    long long n_logged;     // number of loss pairs written
+};
+
+#define LOSS_LOG 4096
+
+enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_N = 6 };
+
+struct hp_agent {
+    hp_ctx *ctx = nullptr;
+    hp_agent_cfg cfg;
+    int H = 256, B = 0, Mp = 0;
+    int xdim = 0, act_off = 0, ldx = 0;  // obs+goal, column of the action block, row stride of X buffers
+    NetLayout la, lc;                    // actor / critic layouts; critic segment starts at la.total
+    int n_arena = 0;
+    float *params = nullptr, *targets = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float *XA = nullptr, *XP = nullptr, *XT = nullptr, *R = nullptr, *TP = nullptr;
+    Pass AT, CT, CA, AP, CP;
+    float *QT = nullptr, *QA = nullptr, *QP = nullptr, *dQA = nullptr, *dQP = nullptr;
+    float *dA3 = nullptr, *dA2 = nullptr, *dA1 = nullptr;  // critic-loss path
+    float *dP3 = nullptr, *dP2 = nullptr, *dP1 = nullptr, *dXP = nullptr;  // actor-loss path through the critic
+    float *dZ = nullptr, *dK3 = nullptr, *dK2 = nullptr, *dK1 = nullptr;   // actor
+    float *loss_log = nullptr;
+    AgentDevState *d_state = nullptr;
+    DevBuf plan, norm_plan;
+    int plan_batches = 0;
+    DevBuf fwd_ws;          // actor_forward scratch
+    PinnedBuf pin;
+    std::vector<void *> owned;
+    // cycle graph cache
+    hipGraphExec_t graph = nullptr;
+    hp_buffer *g_buf = nullptr;
+    hp_norm *g_on = nullptr, *g_gn = nullptr;
+    hp_rng *g_rng = nullptr;
+    int64_t g_n_new = -1;
+    int g_n_batches = -1;
+    double g_future_p = -1, g_sq = -1;
+    void *g_stage = nullptr;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double prof_ms[PROF_N] = {0};
+    long long prof_cnt[PROF_N] = {0};
+    long long host_steps = 0;
+};
+
+// ---------------------------------------------------------------------------------- kernels
+// Grouped GEMM on v_mfma_f32_16x16x4_f32.  C[m][n] = sum_k A(m,k) * B(n,k) with generic element
+// strides, which covers   forward  Y = X W^T          (A = X,  a_sk = 1;  B = W,  b_sk = 1)
+//                         dX = dY W                   (A = dY, a_sk = 1;  B = W,  b_sj = 1, b_sk = ldw)
+//                         dW = dY^T X                 (A = dY, a_si = 1, a_sk = ldy;  B = X, b_sj = 1, b_sk = ldx)
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; accumulator register r holds D[row = 4 * (l >> 4) + r][col = l & 15].
+__global__ __launch_bounds__(256) void k_gemm_group(const GemmGroup grp) {
+    __shared__ float red[4][32 * 33];
+    __shared__ float bsum[4][32];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PROBS; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.p[i].tile0) pi = i;
+    const GemmProb &p = grp.p[pi];
+    const int t = blockIdx.x - p.tile0;
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const bool vm1 = (m0 + 16) < p.M, vn1 = (n0 + 16) < p.N;
+    const int ksl = p.K >> 2;  // reduction slice of this wavefront
+    const int kbeg = wave * ksl + q;
+    const float *a0 = p.A + (long long)(m0 + i) * p.a_si + (long long)kbeg * p.a_sk;
+    const float *b0 = p.B + (long long)(n0 + i) * p.b_sj + (long long)kbeg * p.b_sk;
+    const long long a16 = 16ll * p.a_si, b16 = 16ll * p.b_sj;
+    const long long astep = 4ll * p.a_sk, bstep = 4ll * p.b_sk;
+    f32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    float as0 = 0.f, as1 = 0.f;
+    const int steps = ksl >> 2;
+#pragma unroll 4
+    for (int s = 0; s < steps; ++s) {
+        const float av0 = a0[s * astep];
+        const float bv0 = b0[s * bstep];
+        const float av1 = vm1 ? a0[a16 + s * astep] : 0.f;
+        const float bv1 = vn1 ? b0[b16 + s * bstep] : 0.f;
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1, c11, 0, 0, 0);
+        as0 += av0;
+        as1 += av1;
+    }
+    // partial tiles -> LDS (row stride 33 spreads the 4 row groups over banks)
+    float *my = red[wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        my[row * 33 + i] = c00[r];
+        my[row * 33 + 16 + i] = c01[r];
+        my[(16 + row) * 33 + i] = c10[r];
+        my[(16 + row) * 33 + 16 + i] = c11[r];
+    }
+    if (p.bias_grad != nullptr && tn == 0) {  // wave-uniform
+        as0 += __shfl_xor(as0, 16);
+        as0 += __shfl_xor(as0, 32);
+        as1 += __shfl_xor(as1, 16);
+        as1 += __shfl_xor(as1, 32);
+        if (q == 0) {
+            bsum[wave][i] = as0;
+            bsum[wave][16 + i] = as1;
+        }
+    }
+    __syncthreads();
+    if (p.bias_grad != nullptr && tn == 0 && tid < 32 && m0 + tid < p.M)
+        p.bias_grad[m0 + tid] = (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
+    // each thread finishes 4 consecutive columns of one row
+    const int row = tid >> 3, col = (tid & 7) * 4;
+    const int m = m0 + row;
+    if (m >= p.M) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = row * 33 + col + j;
+        v[j] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    }
+    const int n = n0 + col;
+    if (n >= p.N) return;
+    switch (p.epi) {
+        case EPI_BIAS_RELU:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + p.bias[n + j], 0.f);
+            break;
+        case EPI_BIAS:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] + p.bias[n + j];
+            break;
+        case EPI_MASK:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (p.mask[(long long)m * p.ldmask + n + j] > 0.f) ? v[j] : 0.f;
+            break;
+        case EPI_BIAS_TANH: {
+            // models.py:24: actions = max_action * tanh(.); the critic consumes actions / max_action
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j < p.n_store) {
+                    const float th = tanhf(v[j] + p.bias[n + j]);
+                    p.C2[(long long)m * p.ldc2 + n + j] = th;
+                    p.C[(long long)m * p.ldc + n + j] = (p.max_action * th) / p.max_action;
+                }
+            }
+            return;
+        }
+        default: break;
+    }
+    if (n + 3 < p.n_store) {
+        *reinterpret_cast<float4 *>(p.C + (long long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < p.n_store) p.C[(long long)m * p.ldc + n + j] = v[j];
+    }
+}
+
+// HER gather + relabel + reward + clip + normalise, straight into the network input rows.
+// One wavefront per transition (64 lanes ~ 54 obs + 3 + 3 + 4 values of a bmirobot transition).
+// Reference: her.py:26-38, ddpg_agent.py:228-243, normalizer.py:67-70.  float64 in, float32 out
+// (torch.tensor(..., dtype=float32) rounds to nearest even, as the cast below does).
+__global__ __launch_bounds__(256) void k_gather_fused(const double *__restrict__ obs, const double *__restrict__ ag,
+                                                      const double *__restrict__ g, const double *__restrict__ act,
+                                                      const PlanRec *__restrict__ plan, int batch, int T, int obs_dim,
+                                                      int goal_dim, int act_dim, double sq_threshold,
+                                                      const NormDev *__restrict__ onz, const NormDev *__restrict__ gnz,
+                                                      double clip_obs, double clip_range, float max_action, int ldx,
+                                                      int act_off, float *XA, float *XP, float *XT, float *R) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= batch) return;
+    const PlanRec rec = plan[i];
+    const long long e = rec.e;
+    const int t = rec.t;
+    const double *obs_row = obs + (e * (T + 1) + t) * obs_dim;
+    const double *ag_next = ag + (e * (T + 1) + t + 1) * goal_dim;
+    const double *g_src = rec.her ? ag + (e * (T + 1) + rec.fut) * goal_dim : g + (e * T + t) * goal_dim;
+    const double *act_row = act + (e * T + t) * act_dim;
+    float *xa = XA + (long long)i * ldx, *xp = XP + (long long)i * ldx, *xt = XT + (long long)i * ldx;
+    for (int c = lane; c < 2 * obs_dim; c += 64) {
+        const int col = (c < obs_dim) ? c : c - obs_dim;
+        double v = fmin(fmax(obs_row[c], -clip_obs), clip_obs);                       // _preproc_og
+        v = __ddiv_rn(__dsub_rn(v, (double)onz->mean[col]), onz->std[col]);           // normalize
+        const float x = (float)fmin(fmax(v, -clip_range), clip_range);
+        if (c < obs_dim) {
+            xa[col] = x;
+            xp[col] = x;
+        } else {
+            xt[col] = x;
+        }
+    }
+    for (int c = lane; c < goal_dim; c += 64) {
+        double v = fmin(fmax(g_src[c], -clip_obs), clip_obs);
+        v = __ddiv_rn(__dsub_rn(v, (double)gnz->mean[c]), gnz->std[c]);
+        const float x = (float)fmin(fmax(v, -clip_range), clip_range);
+        xa[obs_dim + c] = x;
+        xp[obs_dim + c] = x;
+        xt[obs_dim + c] = x;   // g_next := g (ddpg_agent.py:231)
+    }
+    for (int c = lane; c < act_dim; c += 64) xa[act_off + c] = (float)act_row[c] / max_action;  // models.py:38
+    if (lane == 0) {
+        double s = 0.0;
+        for (int c = 0; c < goal_dim; ++c) {
+            const double d = __dsub_rn(ag_next[c], g_src[c]);
+            const double sq = __dmul_rn(d, d);
+            s = (c == 0) ? sq : __dadd_rn(s, sq);
+        }
+        R[i] = (s >= sq_threshold) ? -1.0f : -0.0f;
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+    // fixed-order tree: deterministic run to run
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return tot;
+}
+
+// ddpg_agent.py:255-267: targets, both losses and their first derivatives.  One workgroup.
+__global__ __launch_bounds__(256) void k_loss(const float *__restrict__ QT, const float *__restrict__ QA,
+                                              const float *__restrict__ QP, const float *__restrict__ R,
+                                              const float *__restrict__ XP, int ldx, int act_off, int act_dim, int B,
+                                              int Mp, float gamma, float clip_ret, float action_l2, float *dQA,
+                                              float *dQP, float *loss_log, AgentDevState *st) {
+    __shared__ float sh[4];
+    float sc = 0.f, sq = 0.f, sl2 = 0.f;
+    const float invB = 1.0f / (float)B;
+    for (int i = threadIdx.x; i < Mp; i += 256) {
+        if (i < B) {
+            float y = R[i] + gamma * QT[i * 16];          // target_q = r + gamma * q_next
+            y = fminf(fmaxf(y, -clip_ret), 0.f);          // clamp(-1/(1-gamma), 0)
+            const float d = y - QA[i * 16];
+            sc += d * d;
+            dQA[i * 16] = -2.f * d * invB;                // d/dq mean((y-q)^2)
+            sq += QP[i * 16];
+            dQP[i * 16] = -invB;                          // d/dq (-mean(q))
+            for (int j = 0; j < act_dim; ++j) {
+                const float u = XP[i * ldx + act_off + j];
+                sl2 += u * u;
+            }
+        } else {
+            dQA[i * 16] = 0.f;
+            dQP[i * 16] = 0.f;
+        }
+    }
+    const float tc = block_sum_256(sc, sh);
+    const float tq = block_sum_256(sq, sh);
+    const float tl = block_sum_256(sl2, sh);
+    if (threadIdx.x == 0) {
+        const long long k = st->n_logged;
+        const float critic_loss = tc * invB;
+        const float actor_loss = -(tq * invB) + action_l2 * (tl / (float)(B * act_dim));
+        loss_log[(k % LOSS_LOG) * 2 + 0] = actor_loss;
+        loss_log[(k % LOSS_LOG) * 2 + 1] = critic_loss;
+        st->n_logged = k + 1;
+        st->step += 1;
+    }
+}
+
+// actor head backward (autograd of ddpg_agent.py:265-267 w.r.t. the pre-tanh output):
+//   grad_u = action_l2 * 2u/(B*act_dim) + dXP[:, action block];  grad_pi = grad_u / max_action;
+//   grad_tanh = grad_pi * max_action;  dZ = grad_tanh * (1 - tanh^2)
+__global__ void k_actor_head(const float *__restrict__ dXP, const float *__restrict__ XP, const float *__restrict__ TP,
+                             int ldx, int act_off, int act_dim, int B, float action_l2, float max_action, float *dZ) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * act_dim) return;
+    const int i = idx / act_dim, j = idx - i * act_dim;
+    const float u = XP[i * ldx + act_off + j];
+    const float th = TP[i * 16 + j];
+    const float gu = action_l2 * (2.f * u / (float)(B * act_dim)) + dXP[i * ldx + act_off + j];
+    const float gt = (gu / max_action) * max_action;
+    dZ[i * 16 + j] = gt * (1.f - th * th);
+}
+
+// torch.optim.Adam (_single_tensor_adam, no weight decay / amsgrad) over the whole arena.
+__global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
+                                              float *__restrict__ m, float *__restrict__ v, int n, int n_actor,
+                                              double lr_actor, double lr_critic, double beta1, double beta2,
+                                              double eps, const AgentDevState *st) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double step = (double)st->step;
+    const double bc1 = 1.0 - pow(beta1, step);
+    const double bc2 = 1.0 - pow(beta2, step);
+    const double lr = (idx < n_actor) ? lr_actor : lr_critic;
+    const float neg_step_size = (float)(-(lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2), epsf = (float)eps;
+    const float gi = g[idx];
+    float mi = m[idx], vi = v[idx];
+    mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));                 // exp_avg.lerp_(grad, 1 - beta1)
+    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), epsf);
+    p[idx] = __fadd_rn(p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));  // addcdiv_(m, denom, -step_size)
+    m[idx] = mi;
+    v[idx] = vi;
+}
+
+// ddpg_agent.py:220-222: target = (1 - polyak) * param + polyak * target
+__global__ void k_polyak(float *__restrict__ tgt, const float *__restrict__ src, int n, float one_minus, float polyak) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    tgt[idx] = __fadd_rn(__fmul_rn(one_minus, src[idx]), __fmul_rn(polyak, tgt[idx]));
+}
+
+// actor forward for rollouts: x [rows, xdim] -> padded input rows
+__global__ void k_pack_rows(const float *__restrict__ src, int rows, int width, float *dst, int ld, int col0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * width) return;
+    const int r = idx / width, c = idx - r * width;
+    dst[(long long)r * ld + col0 + c] = src[idx];
+}
+
+__global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, int act_off, int act_dim,
+                                 float max_action, float *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * act_dim) return;
+    const int r = idx / act_dim, c = idx - r * act_dim;
+    out[idx] = X[(long long)r * ld + act_off + c] * max_action;   // stored value is actions / max_action
+}
+
+// ------------------------------------------------------------------------------- host side
+static NetLayout make_layout(int K1, int H) {
+    NetLayout l;
+    l.K1 = K1;
+    int o = 0;
+    l.w1 = o; o += H * K1;
+    l.b1 = o; o += H;
+    l.w2 = o; o += H * H;
+    l.b2 = o; o += H;
+    l.w3 = o; o += H * H;
+    l.b3 = o; o += H;
+    l.w4 = o; o += 16 * H;
+    l.b4 = o; o += 16;
+    l.total = o;
+    return l;
+}
+
+static int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Launch {  // builds one grouped launch
+    GemmGroup g;
+    int tiles = 0;
+    Launch() { g.n = 0; }
+    GemmProb &add(int M, int N, int K) {
+        GemmProb &p = g.p[g.n++];
+        memset(&p, 0, sizeof(p));
+        p.M = M; p.N = N; p.K = K;
+        p.n_store = N;
+        p.tiles_n = (N + 31) / 32;
+        p.tile0 = tiles;
+        tiles += ((M + 31) / 32) * p.tiles_n;
+        return p;
+    }
+};
+
+struct ProfScope {
+    hp_agent *a;
+    int which;
+    ProfScope(hp_agent *ag, int w) : a(ag), which(w) {
+        if (a->prof) (void)hipEventRecord(a->ev0, a->ctx->stream);
+    }
+    ~ProfScope() {
+        if (a->prof) {
+            (void)hipEventRecord(a->ev1, a->ctx->stream);
+            (void)hipEventSynchronize(a->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, a->ev0, a->ev1);
+            a->prof_ms[which] += ms;
+            a->prof_cnt[which] += 1;
+        }
+    }
+};
+
+static int launch_group(hp_agent *a, const Launch &L, int which) {
+    ProfScope ps(a, which);
+    hipLaunchKernelGGL(k_gemm_group, dim3(L.tiles), dim3(256), 0, a->ctx->stream, L.g);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// forward layer Y = act(X W^T + b)
+static void add_fwd(Launch &L, const float *X, int ldx, int K, const float *W, const float *bias, float *Y, int ldy,
+                    int M, int N, int epi) {
+    GemmProb &p = L.add(M, N, K);
+    p.A = X; p.a_si = ldx; p.a_sk = 1;
+    p.B = W; p.b_sj = K; p.b_sk = 1;
+    p.C = Y; p.ldc = ldy;
+    p.bias = bias;
+    p.epi = epi;
+}
+
+// dX = (dY W) * relu'(gate)
+static void add_dx(Launch &L, const float *dY, int ldy, int Nout, const float *W, int Kin, float *dX, int lddx, int M,
+                   const float *gate, int ldgate) {
+    GemmProb &p = L.add(M, Kin, Nout);
+    p.A = dY; p.a_si = ldy; p.a_sk = 1;
+    p.B = W; p.b_sj = 1; p.b_sk = Kin;
+    p.C = dX; p.ldc = lddx;
+    p.mask = gate; p.ldmask = ldgate;
+    p.epi = gate ? EPI_MASK : EPI_NONE;
+}
+
+// dW = dY^T X, db = column sums of dY
+static void add_dw(Launch &L, const float *dY, int ldy, int Nout, const float *X, int ldx, int Kin, float *dW,
+                   float *db, int Mrows) {
+    GemmProb &p = L.add(Nout, Kin, Mrows);
+    p.A = dY; p.a_si = 1; p.a_sk = ldy;
+    p.B = X; p.b_sj = 1; p.b_sk = ldx;
+    p.C = dW; p.ldc = Kin;
+    p.bias_grad = db;
+    p.epi = EPI_NONE;
+}
+
+static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq) {
+    ProfScope ps(a, PROF_SAMPLE);
+    hipLaunchKernelGGL(k_gather_fused, dim3((a->B + 3) / 4), dim3(256), 0, a->ctx->stream, b->d_obs, b->d_ag, b->d_g,
+                       b->d_act, plan, a->B, (int)b->T, (int)b->obs_dim, (int)b->goal_dim, (int)b->act_dim, sq, on->d,
+                       gn->d, a->cfg.clip_obs, a->cfg.clip_range, (float)a->cfg.max_action, a->ldx, a->act_off, a->XA,
+                       a->XP, a->XT, a->R);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// forwards + losses + backwards of one update, inputs already in XA/XP/XT/R (19 launches minus Adam)
+static int enqueue_forward_backward(hp_agent *a) {
+    const int H = a->H, Mp = a->Mp, ldx = a->ldx;
+    const NetLayout &la = a->la, &lc = a->lc;
+    float *Pa = a->params, *Pc = a->params + la.total;
+    float *Ta = a->targets, *Tc = a->targets + la.total;
+    float *Ga = a->grads, *Gc = a->grads + la.total;
+    const float maxa = (float)a->cfg.max_action;
+    hipStream_t s = a->ctx->stream;
+    {   // level 1-3: hidden layers of actor_target(x'), critic(x,a), actor(x)
+        Launch L;
+        add_fwd(L, a->XT, ldx, la.K1, Ta + la.w1, Ta + la.b1, a->AT.h1, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->XA, ldx, lc.K1, Pc + lc.w1, Pc + lc.b1, a->CA.h1, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->XP, ldx, la.K1, Pa + la.w1, Pa + la.b1, a->AP.h1, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {
+        Launch L;
+        add_fwd(L, a->AT.h1, H, H, Ta + la.w2, Ta + la.b2, a->AT.h2, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->CA.h1, H, H, Pc + lc.w2, Pc + lc.b2, a->CA.h2, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->AP.h1, H, H, Pa + la.w2, Pa + la.b2, a->AP.h2, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {
+        Launch L;
+        add_fwd(L, a->AT.h2, H, H, Ta + la.w3, Ta + la.b3, a->AT.h3, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->CA.h2, H, H, Pc + lc.w3, Pc + lc.b3, a->CA.h3, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->AP.h2, H, H, Pa + la.w3, Pa + la.b3, a->AP.h3, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {   // level 4: heads.  tanh outputs land in the action block of the critic inputs
+        Launch L;
+        add_fwd(L, a->AT.h3, H, H, Ta + la.w4, Ta + la.b4, a->XT + a->act_off, ldx, Mp, 16, EPI_BIAS_TANH);
+        L.g.p[0].n_store = a->cfg.act_dim; L.g.p[0].C2 = a->TP + 16 * (size_t)Mp; L.g.p[0].ldc2 = 16; L.g.p[0].max_action = maxa;
+        add_fwd(L, a->CA.h3, H, H, Pc + lc.w4, Pc + lc.b4, a->QA, 16, Mp, 16, EPI_BIAS);
+        add_fwd(L, a->AP.h3, H, H, Pa + la.w4, Pa + la.b4, a->XP + a->act_off, ldx, Mp, 16, EPI_BIAS_TANH);
+        L.g.p[2].n_store = a->cfg.act_dim; L.g.p[2].C2 = a->TP; L.g.p[2].ldc2 = 16; L.g.p[2].max_action = maxa;
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {   // level 5-8: critic_target(x', a') and critic(x, pi(x))
+        Launch L;
+        add_fwd(L, a->XT, ldx, lc.K1, Tc + lc.w1, Tc + lc.b1, a->CT.h1, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->XP, ldx, lc.K1, Pc + lc.w1, Pc + lc.b1, a->CP.h1, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {
+        Launch L;
+        add_fwd(L, a->CT.h1, H, H, Tc + lc.w2, Tc + lc.b2, a->CT.h2, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->CP.h1, H, H, Pc + lc.w2, Pc + lc.b2, a->CP.h2, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {
+        Launch L;
+        add_fwd(L, a->CT.h2, H, H, Tc + lc.w3, Tc + lc.b3, a->CT.h3, H, Mp, H, EPI_BIAS_RELU);
+        add_fwd(L, a->CP.h2, H, H, Pc + lc.w3, Pc + lc.b3, a->CP.h3, H, Mp, H, EPI_BIAS_RELU);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {
+        Launch L;
+        add_fwd(L, a->CT.h3, H, H, Tc + lc.w4, Tc + lc.b4, a->QT, 16, Mp, 16, EPI_BIAS);
+        add_fwd(L, a->CP.h3, H, H, Pc + lc.w4, Pc + lc.b4, a->QP, 16, Mp, 16, EPI_BIAS);
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    {   // level 9: losses and dL/dq
+        ProfScope ps(a, PROF_LOSS);
+        const double clip_ret = 1.0 / (1.0 - a->cfg.gamma);  // ddpg_agent.py:259
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, a->QT, a->QA, a->QP, a->R, a->XP, ldx, a->act_off,
+                           (int)a->cfg.act_dim, a->B, Mp, (float)a->cfg.gamma, (float)clip_ret,
+                           (float)a->cfg.action_l2, a->dQA, a->dQP, a->loss_log, a->d_state);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    {   // level 10-13: backward through the critic, for the critic loss (dX + dW) and for the actor loss (dX only)
+        Launch L;
+        add_dx(L, a->dQA, 16, 16, Pc + lc.w4, H, a->dA3, H, Mp, a->CA.h3, H);
+        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+        add_dx(L, a->dQP, 16, 16, Pc + lc.w4, H, a->dP3, H, Mp, a->CP.h3, H);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dx(L, a->dA3, H, H, Pc + lc.w3, H, a->dA2, H, Mp, a->CA.h2, H);
+        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
+        add_dx(L, a->dP3, H, H, Pc + lc.w3, H, a->dP2, H, Mp, a->CP.h2, H);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dx(L, a->dA2, H, H, Pc + lc.w2, H, a->dA1, H, Mp, a->CA.h1, H);
+        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
+        add_dx(L, a->dP2, H, H, Pc + lc.w2, H, a->dP1, H, Mp, a->CP.h1, H);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dw(L, a->dA1, H, H, a->XA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+        add_dx(L, a->dP1, H, H, Pc + lc.w1, lc.K1, a->dXP, ldx, Mp, nullptr, 0);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {   // level 14: through tanh and the action penalty
+        ProfScope ps(a, PROF_LOSS);
+        const int n = a->B * a->cfg.act_dim;
+        hipLaunchKernelGGL(k_actor_head, dim3((n + 255) / 256), dim3(256), 0, s, a->dXP, a->XP, a->TP, ldx, a->act_off,
+                           (int)a->cfg.act_dim, a->B, (float)a->cfg.action_l2, maxa, a->dZ);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    {   // level 15-18: actor backward
+        Launch L;
+        add_dx(L, a->dZ, 16, 16, Pa + la.w4, H, a->dK3, H, Mp, a->AP.h3, H);
+        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dx(L, a->dK3, H, H, Pa + la.w3, H, a->dK2, H, Mp, a->AP.h2, H);
+        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dx(L, a->dK2, H, H, Pa + la.w2, H, a->dK1, H, Mp, a->AP.h1, H);
+        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    {
+        Launch L;
+        add_dw(L, a->dK1, H, H, a->XP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    return HP_OK;
+}
+
+static int enqueue_adam(hp_agent *a) {
+    ProfScope ps(a, PROF_ADAM);
+    const int n = a->n_arena;
+    hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->params, a->grads, a->adam_m,
+                       a->adam_v, n, a->la.total, a->cfg.lr_actor, a->cfg.lr_critic, a->cfg.adam_beta1,
+                       a->cfg.adam_beta2, a->cfg.adam_eps, a->d_state);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+static int enqueue_polyak(hp_agent *a) {
+    ProfScope ps(a, PROF_ADAM);
+    const int n = a->n_arena;
+    const double om = 1.0 - a->cfg.polyak;
+    hipLaunchKernelGGL(k_polyak, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->targets, a->params, n, (float)om,
+                       (float)a->cfg.polyak);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+static int ensure_plan(hp_agent *a, int n_batches) {
+    if (n_batches > a->plan_batches) {
+        HP_TRY(a->plan.ensure((size_t)n_batches * a->B * sizeof(PlanRec)));
+        a->plan_batches = n_batches;
+    }
+    return HP_OK;
+}
+
+static int check_handles(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, const char *who) {
+    HP_REQUIRE(a && b && on && gn && rng, HP_ERR_INVALID, "%s: null handle", who);
+    HP_REQUIRE(b->obs_dim == a->cfg.obs_dim && b->goal_dim == a->cfg.goal_dim && b->act_dim == a->cfg.act_dim,
+               HP_ERR_INVALID, "%s: buffer dimensions do not match the agent", who);
+    HP_REQUIRE(on->size == a->cfg.obs_dim && gn->size == a->cfg.goal_dim, HP_ERR_INVALID,
+               "%s: normalizer sizes do not match the agent", who);
+    return HP_OK;
+}
+
+// n_updates x (sample + update); the index plan for all of them is drawn by one kernel up front
+// (nothing else consumes the stream in between, exactly like the reference's inner loop).
+static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq,
+                           int n_updates, bool with_adam) {
+    {
+        ProfScope ps(a, PROF_PLAN);
+        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, n_updates, future_p, a->plan.as<PlanRec>()));
+    }
+    for (int u = 0; u < n_updates; ++u) {
+        HP_TRY(enqueue_gather(a, b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq));
+        HP_TRY(enqueue_forward_backward(a));
+        if (with_adam) HP_TRY(enqueue_adam(a));
+    }
+    return HP_OK;
+}
+
+// reference flat order (utils.py:18-27): fc1.weight, fc1.bias, fc2.weight, ... out.weight, out.bias
+static void pack_net(const hp_agent *a, bool critic, const float *flat, float *arena_seg) {
+    const NetLayout &l = critic ? a->lc : a->la;
+    const int H = a->H, xdim = a->xdim, act = a->cfg.act_dim;
+    const int in1 = critic ? xdim + act : xdim;
+    const int out4 = critic ? 1 : act;
+    memset(arena_seg, 0, sizeof(float) * l.total);
+    const float *src = flat;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < in1; ++c) arena_seg[l.w1 + r * l.K1 + (c < xdim ? c : a->act_off + (c - xdim))] = *src++;
+    memcpy(arena_seg + l.b1, src, H * 4); src += H;
+    memcpy(arena_seg + l.w2, src, H * H * 4); src += H * H;
+    memcpy(arena_seg + l.b2, src, H * 4); src += H;
+    memcpy(arena_seg + l.w3, src, H * H * 4); src += H * H;
+    memcpy(arena_seg + l.b3, src, H * 4); src += H;
+    memcpy(arena_seg + l.w4, src, out4 * H * 4); src += out4 * H;
+    memcpy(arena_seg + l.b4, src, out4 * 4);
+}
+
+static void unpack_net(const hp_agent *a, bool critic, const float *arena_seg, float *flat) {
+    const NetLayout &l = critic ? a->lc : a->la;
+    const int H = a->H, xdim = a->xdim, act = a->cfg.act_dim;
+    const int in1 = critic ? xdim + act : xdim;
+    const int out4 = critic ? 1 : act;
+    float *dst = flat;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < in1; ++c) *dst++ = arena_seg[l.w1 + r * l.K1 + (c < xdim ? c : a->act_off + (c - xdim))];
+    memcpy(dst, arena_seg + l.b1, H * 4); dst += H;
+    memcpy(dst, arena_seg + l.w2, H * H * 4); dst += H * H;
+    memcpy(dst, arena_seg + l.b2, H * 4); dst += H;
+    memcpy(dst, arena_seg + l.w3, H * H * 4); dst += H * H;
+    memcpy(dst, arena_seg + l.b3, H * 4); dst += H;
+    memcpy(dst, arena_seg + l.w4, out4 * H * 4); dst += out4 * H;
+    memcpy(dst, arena_seg + l.b4, out4 * 4);
+}
+
+static int64_t flat_count(const hp_agent *a, bool critic) {
+    const int H = a->H, act = a->cfg.act_dim;
+    const int in1 = critic ? a->xdim + act : a->xdim;
+    const int out4 = critic ? 1 : act;
+    return (int64_t)H * in1 + H + 2ll * (H * H + H) + (int64_t)out4 * H + out4;
+}
+
+static int arena_read(hp_agent *a, const float *d_arena, bool critic, float *flat_host, int64_t n) {
+    HP_REQUIRE(n == flat_count(a, critic), HP_ERR_INVALID, "flat vector has %lld elements, expected %lld", (long long)n,
+               (long long)flat_count(a, critic));
+    const NetLayout &l = critic ? a->lc : a->la;
+    std::vector<float> seg(l.total);
+    HP_CHECK_HIP(hipMemcpyAsync(seg.data(), d_arena + (critic ? a->la.total : 0), sizeof(float) * l.total,
+                                hipMemcpyDeviceToHost, a->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+    unpack_net(a, critic, seg.data(), flat_host);
+    return HP_OK;
+}
+
+template <class T> static int dev_alloc(hp_agent *a, T **p, size_t count) {
+    void *q = nullptr;
+    HP_CHECK_HIP(hipMalloc(&q, count * sizeof(T)));
+    HP_CHECK_HIP(hipMemsetAsync(q, 0, count * sizeof(T), a->ctx->stream));
+    a->owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return HP_OK;
+}
+
+static void drop_graph(hp_agent *a) {
+    if (a->graph) (void)hipGraphExecDestroy(a->graph);
+    a->graph = nullptr;
+}
+
+// --------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
+    HP_REQUIRE(ctx && cfg && out, HP_ERR_INVALID, "hp_agent_create: null argument");
+    HP_REQUIRE(cfg->hidden > 0 && cfg->hidden % 32 == 0, HP_ERR_INVALID, "hp_agent_create: hidden must be a multiple of 32");
+    HP_REQUIRE(cfg->batch > 0, HP_ERR_INVALID, "hp_agent_create: batch must be positive");
+    HP_REQUIRE(cfg->obs_dim > 0 && cfg->goal_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16, HP_ERR_INVALID,
+               "hp_agent_create: need obs_dim, goal_dim > 0 and 0 < act_dim <= 16");
+    HP_REQUIRE(cfg->max_action > 0, HP_ERR_INVALID, "hp_agent_create: max_action must be positive");
+    hp_agent *a = new hp_agent();
+    a->ctx = ctx;
+    a->cfg = *cfg;
+    a->H = cfg->hidden;
+    a->B = cfg->batch;
+    a->Mp = roundup(cfg->batch, 32);
+    a->xdim = cfg->obs_dim + cfg->goal_dim;
+    a->act_off = roundup(a->xdim, 16);
+    a->ldx = roundup(a->act_off + cfg->act_dim, 16);
+    a->la = make_layout(a->act_off, a->H);
+    a->lc = make_layout(a->ldx, a->H);
+    a->n_arena = a->la.total + a->lc.total;
+    const size_t Mp = a->Mp, H = a->H, ldx = a->ldx;
+    int st = HP_OK;
+    auto A = [&](float **p, size_t n) { if (st == HP_OK) st = dev_alloc(a, p, n); };
+    A(&a->params, a->n_arena); A(&a->targets, a->n_arena); A(&a->grads, a->n_arena);
+    A(&a->adam_m, a->n_arena); A(&a->adam_v, a->n_arena);
+    A(&a->XA, Mp * ldx); A(&a->XP, Mp * ldx); A(&a->XT, Mp * ldx); A(&a->R, Mp); A(&a->TP, 2 * Mp * 16);
+    for (Pass *ps : {&a->AT, &a->CT, &a->CA, &a->AP, &a->CP}) { A(&ps->h1, Mp * H); A(&ps->h2, Mp * H); A(&ps->h3, Mp * H); }
+    A(&a->QT, Mp * 16); A(&a->QA, Mp * 16); A(&a->QP, Mp * 16); A(&a->dQA, Mp * 16); A(&a->dQP, Mp * 16);
+    A(&a->dA3, Mp * H); A(&a->dA2, Mp * H); A(&a->dA1, Mp * H);
+    A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
+    A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
+    A(&a->loss_log, LOSS_LOG * 2);
+    if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
+    if (st == HP_OK && hipEventCreate(&a->ev0) != hipSuccess) st = HP_ERR_HIP;
+    if (st == HP_OK && hipEventCreate(&a->ev1) != hipSuccess) st = HP_ERR_HIP;
+    if (st == HP_OK) st = ensure_plan(a, 1);
+    if (st != HP_OK) {
+        hp_agent_destroy(a);
+        return st;
+    }
+    *out = a;
+    return HP_OK;
+}
+
+int64_t hp_agent_param_count(hp_agent *a, int32_t net) {
+    if (!a) return -1;
+    return flat_count(a, net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET);
+}
+
+int hp_agent_set_params(hp_agent *a, int32_t net, const float *flat_host, int64_t n) {
+    HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_set_params: null argument");
+    HP_REQUIRE(net >= 0 && net <= 3, HP_ERR_INVALID, "hp_agent_set_params: net=%d not in 0..3", net);
+    const bool critic = (net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET);
+    const bool target = net >= 2;
+    HP_REQUIRE(n == flat_count(a, critic), HP_ERR_INVALID, "hp_agent_set_params: got %lld values, expected %lld",
+               (long long)n, (long long)flat_count(a, critic));
+    const NetLayout &l = critic ? a->lc : a->la;
+    std::vector<float> seg(l.total);
+    pack_net(a, critic, flat_host, seg.data());
+    float *dst = (target ? a->targets : a->params) + (critic ? a->la.total : 0);
+    HP_CHECK_HIP(hipMemcpyAsync(dst, seg.data(), sizeof(float) * l.total, hipMemcpyHostToDevice, a->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+    return HP_OK;
+}
+
+int hp_agent_get_params(hp_agent *a, int32_t net, float *flat_host, int64_t n) {
+    HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_get_params: null argument");
+    HP_REQUIRE(net >= 0 && net <= 3, HP_ERR_INVALID, "hp_agent_get_params: net=%d not in 0..3", net);
+    return arena_read(a, net >= 2 ? a->targets : a->params, net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET,
+                      flat_host, n);
+}
+
+int hp_agent_get_grads(hp_agent *a, int32_t net, float *flat_host, int64_t n) {
+    HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_get_grads: null argument");
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_CRITIC, HP_ERR_INVALID, "hp_agent_get_grads: net must be actor or critic");
+    return arena_read(a, a->grads, net == HP_NET_CRITIC, flat_host, n);
+}
+
+int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_get_adam: null handle");
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_CRITIC, HP_ERR_INVALID, "hp_agent_get_adam: net must be actor or critic");
+    if (m_host) HP_TRY(arena_read(a, a->adam_m, net == HP_NET_CRITIC, m_host, n));
+    if (v_host) HP_TRY(arena_read(a, a->adam_v, net == HP_NET_CRITIC, v_host, n));
+    if (step) {
+        AgentDevState h;
+        HP_CHECK_HIP(hipMemcpyAsync(&h, a->d_state, sizeof(h), hipMemcpyDeviceToHost, a->ctx->stream));
+        HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+        *step = h.step;
+    }
+    return HP_OK;
+}
+
+int hp_agent_sync_targets(hp_agent *a) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_sync_targets: null handle");
+    HP_CHECK_HIP(hipMemcpyAsync(a->targets, a->params, sizeof(float) * a->n_arena, hipMemcpyDeviceToDevice, a->ctx->stream));
+    return HP_OK;
+}
+
+int hp_agent_update_minibatch(hp_agent *a, const float *x, const float *x_next, const float *actions, const float *r,
+                              float *losses_host) {
+    HP_REQUIRE(a && x && x_next && actions && r, HP_ERR_INVALID, "hp_agent_update_minibatch: null argument");
+    const int B = a->B, Mp = a->Mp, ldx = a->ldx, xd = a->xdim, ad = a->cfg.act_dim;
+    std::vector<float> hxa((size_t)Mp * ldx, 0.f), hxp((size_t)Mp * ldx, 0.f), hxt((size_t)Mp * ldx, 0.f), hr(Mp, 0.f);
+    const float maxa = (float)a->cfg.max_action;
+    for (int i = 0; i < B; ++i) {
+        for (int c = 0; c < xd; ++c) {
+            hxa[(size_t)i * ldx + c] = x[(size_t)i * xd + c];
+            hxp[(size_t)i * ldx + c] = x[(size_t)i * xd + c];
+            hxt[(size_t)i * ldx + c] = x_next[(size_t)i * xd + c];
+        }
+        for (int c = 0; c < ad; ++c) hxa[(size_t)i * ldx + a->act_off + c] = actions[(size_t)i * ad + c] / maxa;
+        hr[i] = r[i];
+    }
+    hipStream_t s = a->ctx->stream;
+    HP_CHECK_HIP(hipMemcpyAsync(a->XA, hxa.data(), hxa.size() * 4, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(a->XP, hxp.data(), hxp.size() * 4, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(a->XT, hxt.data(), hxt.size() * 4, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(a->R, hr.data(), hr.size() * 4, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_TRY(enqueue_forward_backward(a));
+    HP_TRY(enqueue_adam(a));
+    a->host_steps += 1;
+    if (losses_host) HP_TRY(hp_agent_get_losses(a, losses_host, 1));
+    else HP_CHECK_HIP(hipStreamSynchronize(s));
+    return HP_OK;
+}
+
+int hp_agent_sample_and_update(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
+                               double sq_threshold, int32_t n_updates) {
+    HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_sample_and_update"));
+    HP_REQUIRE(n_updates > 0, HP_ERR_INVALID, "hp_agent_sample_and_update: n_updates must be positive");
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    HP_TRY(ensure_plan(a, n_updates));
+    HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq_threshold, n_updates, true));
+    a->host_steps += n_updates;
+    return HP_OK;
+}
+
+int hp_agent_forward_backward(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
+                              double sq_threshold) {
+    HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_forward_backward"));
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    HP_TRY(ensure_plan(a, 1));
+    return enqueue_updates(a, b, on, gn, rng, future_p, sq_threshold, 1, false);
+}
+
+int hp_agent_grad_buffer(hp_agent *a, void **dev_grads, int64_t *n_floats) {
+    HP_REQUIRE(a && dev_grads && n_floats, HP_ERR_INVALID, "hp_agent_grad_buffer: null argument");
+    *dev_grads = a->grads;
+    *n_floats = a->n_arena;
+    return HP_OK;
+}
+
+int hp_agent_param_buffer(hp_agent *a, void **dev_params, int64_t *n_floats) {
+    HP_REQUIRE(a && dev_params && n_floats, HP_ERR_INVALID, "hp_agent_param_buffer: null argument");
+    *dev_params = a->params;
+    *n_floats = a->n_arena;
+    return HP_OK;
+}
+
+int hp_agent_apply(hp_agent *a) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_apply: null handle");
+    HP_TRY(enqueue_adam(a));
+    a->host_steps += 1;
+    return HP_OK;
+}
+
+int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
+    HP_REQUIRE(a && out_host, HP_ERR_INVALID, "hp_agent_get_losses: null argument");
+    HP_REQUIRE(n_last > 0 && n_last <= LOSS_LOG, HP_ERR_INVALID, "hp_agent_get_losses: n_last must be in [1, %d]", LOSS_LOG);
+    hipStream_t s = a->ctx->stream;
+    AgentDevState h;
+    std::vector<float> log(LOSS_LOG * 2);
+    HP_CHECK_HIP(hipMemcpyAsync(&h, a->d_state, sizeof(h), hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipMemcpyAsync(log.data(), a->loss_log, log.size() * 4, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_REQUIRE(h.n_logged >= n_last, HP_ERR_STATE, "hp_agent_get_losses: only %lld updates logged", h.n_logged);
+    for (int i = 0; i < n_last; ++i) {
+        const long long k = h.n_logged - n_last + i;
+        out_host[2 * i] = log[(k % LOSS_LOG) * 2];
+        out_host[2 * i + 1] = log[(k % LOSS_LOG) * 2 + 1];
+    }
+    return HP_OK;
+}
+
+int hp_agent_soft_update(hp_agent *a) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_soft_update: null handle");
+    return enqueue_polyak(a);
+}
+
+int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_t rows, float *actions_host) {
+    HP_REQUIRE(a && x_host && actions_host, HP_ERR_INVALID, "hp_agent_actor_forward: null argument");
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_ACTOR_TARGET, HP_ERR_INVALID, "hp_agent_actor_forward: net must be an actor");
+    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_actor_forward: rows out of range");
+    const int H = a->H, ldx = a->ldx, xd = a->xdim, ad = a->cfg.act_dim;
+    const int Mp = roundup((int)rows, 32);
+    hipStream_t s = a->ctx->stream;
+    // scratch: raw x | X rows | h1 | h2 | h3 | tanh | actions
+    const size_t n_raw = (size_t)rows * xd, nX = (size_t)Mp * ldx, nH = (size_t)Mp * H, nT = (size_t)Mp * 16;
+    HP_TRY(a->fwd_ws.ensure((n_raw + nX + 3 * nH + nT + (size_t)rows * ad) * 4));
+    float *raw = a->fwd_ws.as<float>(), *X = raw + n_raw, *h1 = X + nX, *h2 = h1 + nH, *h3 = h2 + nH, *tp = h3 + nH,
+          *outp = tp + nT;
+    HP_CHECK_HIP(hipMemsetAsync(X, 0, nX * 4, s));
+    HP_CHECK_HIP(hipMemcpyAsync(raw, x_host, n_raw * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, s, raw, (int)rows, xd, X, ldx, 0);
+    const NetLayout &l = a->la;
+    const float *P = (net == HP_NET_ACTOR) ? a->params : a->targets;
+    { Launch L; add_fwd(L, X, ldx, l.K1, P + l.w1, P + l.b1, h1, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    { Launch L; add_fwd(L, h1, H, H, P + l.w2, P + l.b2, h2, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    { Launch L; add_fwd(L, h2, H, H, P + l.w3, P + l.b3, h3, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    {
+        Launch L;
+        add_fwd(L, h3, H, H, P + l.w4, P + l.b4, X + a->act_off, ldx, Mp, 16, EPI_BIAS_TANH);
+        L.g.p[0].n_store = ad; L.g.p[0].C2 = tp; L.g.p[0].ldc2 = 16; L.g.p[0].max_action = (float)a->cfg.max_action;
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    // actions = max_action * tanh(.)  (models.py:24); tp holds tanh
+    hipLaunchKernelGGL(k_unpack_actions, dim3((unsigned)((rows * ad + 255) / 256)), dim3(256), 0, s, tp, (int)rows, 16, 0, ad,
+                       (float)a->cfg.max_action, outp);
+    HP_CHECK_HIP(hipGetLastError());
+    HP_CHECK_HIP(hipMemcpyAsync(actions_host, outp, (size_t)rows * ad * 4, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    return HP_OK;
+}
+
+}  // extern "C"
+
+// device part of one cycle after the episodes are staged: slots+scatter happen in buffer_stage_and_store
+static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
+                              double sq, int n_batches, PlanRec *norm_plan) {
+    // ddpg_agent._update_normalizer (:187-212)
+    HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, b->T, 1, future_p, norm_plan));
+    HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs));
+    HP_TRY(norm_launch_begin(on));
+    HP_TRY(norm_launch_end(on));
+    HP_TRY(norm_launch_begin(gn));
+    HP_TRY(norm_launch_end(gn));
+    // ddpg_agent.py:145-150
+    HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq, n_batches, true));
+    HP_TRY(enqueue_polyak(a));
+    return HP_OK;
+}
+
+extern "C" {
+
+int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, const double *obs,
+                         const double *ag_host, const double *g, const double *actions, int64_t n_new,
+                         double future_p, double sq_threshold, int32_t n_batches) {
+    HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_train_cycle"));
+    HP_REQUIRE(obs && ag_host && g && actions, HP_ERR_INVALID, "hp_agent_train_cycle: null episode array");
+    HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "hp_agent_train_cycle: n_new and n_batches must be positive");
+    HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
+    HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_train_cycle: profiling mode uses the eager path (hp_agent_profile(0) first)");
+    hipStream_t s = a->ctx->stream;
+    // 1. episodes -> pinned -> device staging, slots, scatter (eager: the source pointers change per call)
+    HP_TRY(buffer_stage_and_store(b, rng, obs, ag_host, g, actions, n_new));
+    // 2. everything else is one graph; rebuild when a baked-in argument changes
+    const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
+                      a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&
+                      a->g_sq == sq_threshold && a->g_stage == b->st_obs.p;
+    if (!same) {
+        drop_graph(a);
+        HP_TRY(ensure_plan(a, n_batches));
+        HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
+        HP_CHECK_HIP(hipStreamSynchronize(s));
+        hipGraph_t graph = nullptr;
+        HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int st = enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>());
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (st != HP_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return st;
+        }
+        HP_CHECK_HIP(e);
+        e = hipGraphInstantiate(&a->graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HP_CHECK_HIP(e);
+        a->g_buf = b; a->g_on = on; a->g_gn = gn; a->g_rng = rng;
+        a->g_n_new = n_new; a->g_n_batches = n_batches; a->g_future_p = future_p; a->g_sq = sq_threshold;
+        a->g_stage = b->st_obs.p;
+    }
+    HP_CHECK_HIP(hipGraphLaunch(a->graph, s));
+    a->host_steps += n_batches;
+    return HP_OK;
+}
+
+int hp_agent_profile(hp_agent *a, int32_t enable) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_profile: null handle");
+    a->prof = enable != 0;
+    for (int i = 0; i < PROF_N; ++i) {
+        a->prof_ms[i] = 0;
+        a->prof_cnt[i] = 0;
+    }
+    return HP_OK;
+}
+
+// out[2*k] = total ms, out[2*k+1] = launches, k = sample, gemm_fwd, gemm_bwd, loss(+head), adam(+polyak), plan
+int hp_agent_profile_read(hp_agent *a, double *ms_out, int32_t n) {
+    HP_REQUIRE(a && ms_out, HP_ERR_INVALID, "hp_agent_profile_read: null argument");
+    for (int i = 0; i < PROF_N && 2 * i + 1 < n; ++i) {
+        ms_out[2 * i] = a->prof_ms[i];
+        ms_out[2 * i + 1] = (double)a->prof_cnt[i];
+    }
+    return HP_OK;
+}
+
+void hp_agent_destroy(hp_agent *a) {
+    if (!a) return;
+    drop_graph(a);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    for (void *p : a->owned) (void)hipFree(p);
+    a->plan.release();
+    a->norm_plan.release();
+    a->fwd_ws.release();
+    a->pin.release();
+    if (a->ev0) (void)hipEventDestroy(a->ev0);
+    if (a->ev1) (void)hipEventDestroy(a->ev1);
+    delete a;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// buffer.hip -- episodic replay storage in HBM + the HER gather/relabel/reward kernel
+// (reference: replay_buffer.py:11-71, her.py:26-39, bmirobot_env_push_F.py:20-23,84-90).
+//
+// HBM layout (float64, identical to the reference's numpy arrays so that episodes can be
+// memcpy'd in and read back verbatim):
+//   obs  [size][T+1][obs_dim]   ag [size][T+1][goal_dim]
+//   g    [size][T][goal_dim]    actions [size][T][act_dim]
+// A sampled transition touches obs[e][t..t+1] (one contiguous 2*obs_dim run), ag[e][t..t+1],
+// g[e][t], actions[e][t] and, when relabelled, ag[e][future_t].
+//
+// Built with -ffp-contract=off: the reward must round exactly like numpy's
+// (x0*x0 + x1*x1) + x2*x2 in float64, so no multiply-add may be fused.
+#include "internal.h"
+
+// ----------------------------------------------------------------------------- kernels
+// One wavefront per transition; lanes stride over the row elements (coalesced 8-byte loads).
+// dict-mode output = the arrays her_sampler.sample_her_transitions returns (her.py:39).
+__global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ obs, const double *__restrict__ ag,
+                                                     const double *__restrict__ g, const double *__restrict__ act,
+                                                     const PlanRec *__restrict__ plan, long long batch, int T,
+                                                     int obs_dim, int goal_dim, int act_dim, double sq_threshold,
+                                                     double *o_obs, double *o_ag, double *o_g, double *o_act,
+                                                     double *o_obs_next, double *o_ag_next, float *o_r) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= batch) return;
+    const PlanRec rec = plan[i];
+    const long long e = rec.e;
+    const int t = rec.t;
+    const double *obs_row = obs + (e * (T + 1) + t) * obs_dim;        // rows t and t+1 are adjacent
+    const double *ag_row = ag + (e * (T + 1) + t) * goal_dim;
+    const double *g_src = rec.her ? ag + (e * (T + 1) + rec.fut) * goal_dim  // her.py:35-36
+                                  : g + (e * T + t) * goal_dim;
+    const double *act_row = act + (e * T + t) * act_dim;
+    for (int c = lane; c < obs_dim; c += 64) {
+        o_obs[i * obs_dim + c] = obs_row[c];
+        o_obs_next[i * obs_dim + c] = obs_row[obs_dim + c];
+    }
+    for (int c = lane; c < goal_dim; c += 64) {
+        o_ag[i * goal_dim + c] = ag_row[c];
+        o_ag_next[i * goal_dim + c] = ag_row[goal_dim + c];
+        o_g[i * goal_dim + c] = g_src[c];
+    }
+    for (int c = lane; c < act_dim; c += 64) o_act[i * act_dim + c] = act_row[c];
+    if (lane == 0) {
+        // goal_distance: sqrt(sum((ag_next - g)^2)) > thr  <=>  sum >= sq_threshold  (sqrt is monotone;
+        // sq_threshold is the smallest double whose correctly rounded sqrt exceeds thr).  numpy's
+        // add.reduce over a contiguous axis of < 8 elements is a plain left-to-right sum.
+        double s = 0.0;
+        for (int c = 0; c < goal_dim; ++c) {
+            double d = __dsub_rn(ag_row[goal_dim + c], g_src[c]);
+            double sq = __dmul_rn(d, d);
+            s = (c == 0) ? sq : __dadd_rn(s, sq);
+        }
+        o_r[i] = (s >= sq_threshold) ? -1.0f : -0.0f;  // -(d > thr).astype(float32)
+    }
+}
+
+// scatter the staged episodes into their slots.  numpy's `buffers[idxs] = mb` lets the LAST
+// occurrence of a repeated slot win, so an episode is dropped when a later one has its slot.
+__global__ __launch_bounds__(256) void k_store_scatter(const long long *__restrict__ slots, long long n_new,
+                                                       const double *s_obs, const double *s_ag, const double *s_g,
+                                                       const double *s_act, double *obs, double *ag, double *g,
+                                                       double *act, long long ep_obs, long long ep_ag,
+                                                       long long ep_g, long long ep_act) {
+    const long long i = blockIdx.x;
+    const long long slot = slots[i];
+    int dup = 0;
+    for (long long j = i + 1 + threadIdx.x; j < n_new; j += blockDim.x) dup |= (slots[j] == slot);
+    if (__syncthreads_or(dup)) return;
+    for (long long k = threadIdx.x; k < ep_obs; k += blockDim.x) obs[slot * ep_obs + k] = s_obs[i * ep_obs + k];
+    for (long long k = threadIdx.x; k < ep_ag; k += blockDim.x) ag[slot * ep_ag + k] = s_ag[i * ep_ag + k];
+    for (long long k = threadIdx.x; k < ep_g; k += blockDim.x) g[slot * ep_g + k] = s_g[i * ep_g + k];
+    for (long long k = threadIdx.x; k < ep_act; k += blockDim.x) act[slot * ep_act + k] = s_act[i * ep_act + k];
+}
+
+// ------------------------------------------------------------------------------ launchers
+int buffer_launch_gather_dict(hp_buffer *b, const PlanRec *d_plan, int64_t batch, double sq_threshold, double *d_out,
+                              float *d_r) {
+    const int od = b->obs_dim, gd = b->goal_dim, ad = b->act_dim;
+    double *o_obs = d_out;
+    double *o_ag = o_obs + batch * od;
+    double *o_g = o_ag + batch * gd;
+    double *o_act = o_g + batch * gd;
+    double *o_obs_next = o_act + batch * ad;
+    double *o_ag_next = o_obs_next + batch * od;
+    const int waves_per_block = 4;
+    dim3 grid((unsigned)((batch + waves_per_block - 1) / waves_per_block));
+    hipLaunchKernelGGL(k_gather_dict, grid, dim3(256), 0, b->ctx->stream, b->d_obs, b->d_ag, b->d_g, b->d_act, d_plan,
+                       (long long)batch, (int)b->T, od, gd, ad, sq_threshold, o_obs, o_ag, o_g, o_act, o_obs_next,
+                       o_ag_next, d_r);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// stage host episodes on the device (st_*), pick slots, scatter.  Shared by hp_buffer_store and
+// the train-cycle path.
+int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
+                           const double *actions, int64_t n_new) {
+    hipStream_t s = b->ctx->stream;
+    HP_TRY(b->st_obs.ensure(n_new * b->ep_obs() * 8));
+    HP_TRY(b->st_ag.ensure(n_new * b->ep_ag() * 8));
+    HP_TRY(b->st_g.ensure(n_new * b->ep_g() * 8));
+    HP_TRY(b->st_act.ensure(n_new * b->ep_act() * 8));
+    HP_TRY(b->st_slots.ensure(n_new * 8));
+    // copy-in semantics (replay_buffer.py:39-42): the caller's arrays are read by the CPU memcpy
+    // below and never again; the DMA reads our pinned staging.
+    const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
+                 n3 = n_new * b->ep_act() * 8;
+    HP_TRY(b->pin.ensure(n0 + n1 + n2 + n3));
+    char *h = static_cast<char *>(b->pin.p);
+    memcpy(h, obs, n0);
+    memcpy(h + n0, ag, n1);
+    memcpy(h + n0 + n1, g, n2);
+    memcpy(h + n0 + n1 + n2, actions, n3);
+    HP_CHECK_HIP(hipMemcpyAsync(b->st_obs.p, h, n0, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(b->st_ag.p, h + n0, n1, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(b->st_g.p, h + n0 + n1, n2, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(b->st_act.p, h + n0 + n1 + n2, n3, hipMemcpyHostToDevice, s));
+    HP_TRY(b->pin.mark(s));
+    b->staged_n = n_new;
+    HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
+    hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)n_new), dim3(256), 0, s, b->st_slots.as<long long>(),
+                       (long long)n_new, b->st_obs.as<double>(), b->st_ag.as<double>(), b->st_g.as<double>(),
+                       b->st_act.as<double>(), b->d_obs, b->d_ag, b->d_g, b->d_act, (long long)b->ep_obs(),
+                       (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
+    HP_CHECK_HIP(hipGetLastError());
+    // host mirror of replay_buffer.py:68 and :43
+    b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
+    b->n_transitions_stored += (int64_t)b->T * n_new;
+    return HP_OK;
+}
+
+// --------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int hp_buffer_create(hp_ctx *ctx, int64_t size_episodes, int32_t T, int32_t obs_dim, int32_t goal_dim,
+                     int32_t act_dim, hp_buffer **out) {
+    HP_REQUIRE(ctx && out, HP_ERR_INVALID, "hp_buffer_create: null argument");
+    HP_REQUIRE(size_episodes > 0 && size_episodes < (1ll << 31), HP_ERR_INVALID,
+               "hp_buffer_create: size_episodes=%lld must be in [1, 2^31)", (long long)size_episodes);
+    HP_REQUIRE(T > 0 && obs_dim > 0 && goal_dim > 0 && act_dim > 0, HP_ERR_INVALID,
+               "hp_buffer_create: dimensions must be positive");
+    hp_buffer *b = new hp_buffer();
+    b->ctx = ctx;
+    b->size = size_episodes;
+    b->T = T;
+    b->obs_dim = obs_dim;
+    b->goal_dim = goal_dim;
+    b->act_dim = act_dim;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_obs, size_episodes * b->ep_obs() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_ag, size_episodes * b->ep_ag() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_g, size_episodes * b->ep_g() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_act, size_episodes * b->ep_act() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_meta, sizeof(BufMeta));
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_meta, 0, sizeof(BufMeta), ctx->stream);
+    if (e != hipSuccess) {
+        hp_set_error("hp_buffer_create: device allocation failed: %s", hipGetErrorString(e));
+        hp_buffer_destroy(b);
+        return HP_ERR_HIP;
+    }
+    *out = b;
+    return HP_OK;
+}
+
+int hp_buffer_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
+                    const double *actions, int64_t n_new) {
+    HP_REQUIRE(b && rng && obs && ag && g && actions, HP_ERR_INVALID, "hp_buffer_store: null argument");
+    HP_REQUIRE(n_new > 0, HP_ERR_INVALID, "hp_buffer_store: n_new must be positive");
+    // replay_buffer.py:64 with current_size == 0 and inc > size: np.random.randint(0, 0, k) raises
+    HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
+    return buffer_stage_and_store(b, rng, obs, ag, g, actions, n_new);
+}
+
+int hp_buffer_info(hp_buffer *b, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored, int32_t *T) {
+    HP_REQUIRE(b, HP_ERR_INVALID, "hp_buffer_info: null handle");
+    if (size) *size = b->size;
+    if (current_size) *current_size = b->current_size;
+    if (n_transitions_stored) *n_transitions_stored = b->n_transitions_stored;
+    if (T) *T = b->T;
+    return HP_OK;
+}
+
+int hp_buffer_last_slots(hp_buffer *b, int64_t *host_out, int64_t n) {
+    HP_REQUIRE(b && host_out, HP_ERR_INVALID, "hp_buffer_last_slots: null argument");
+    HP_REQUIRE(n >= 0 && n <= b->staged_n, HP_ERR_INVALID, "hp_buffer_last_slots: n=%lld exceeds last store (%lld)",
+               (long long)n, (long long)b->staged_n);
+    HP_CHECK_HIP(hipMemcpyAsync(host_out, b->st_slots.p, n * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    return HP_OK;
+}
+
+int hp_buffer_read(hp_buffer *b, int32_t which, int64_t first, int64_t n, double *host_out) {
+    HP_REQUIRE(b && host_out, HP_ERR_INVALID, "hp_buffer_read: null argument");
+    HP_REQUIRE(first >= 0 && n >= 0 && first + n <= b->size, HP_ERR_INVALID, "hp_buffer_read: range out of bounds");
+    const double *src;
+    size_t ep;
+    switch (which) {
+        case 0: src = b->d_obs; ep = b->ep_obs(); break;
+        case 1: src = b->d_ag; ep = b->ep_ag(); break;
+        case 2: src = b->d_g; ep = b->ep_g(); break;
+        case 3: src = b->d_act; ep = b->ep_act(); break;
+        default: hp_set_error("hp_buffer_read: which=%d not in 0..3", which); return HP_ERR_INVALID;
+    }
+    if (n == 0) return HP_OK;
+    HP_CHECK_HIP(hipMemcpyAsync(host_out, src + first * ep, n * ep * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    return HP_OK;
+}
+
+int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
+                     const hp_sample_out *o) {
+    HP_REQUIRE(b && rng && o, HP_ERR_INVALID, "hp_buffer_sample: null argument");
+    HP_REQUIRE(batch > 0, HP_ERR_INVALID, "hp_buffer_sample: batch must be positive");
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");  // np.random.randint(0, 0, B), her.py:24
+    hipStream_t s = b->ctx->stream;
+    const int od = b->obs_dim, gd = b->goal_dim, ad = b->act_dim;
+    const size_t row = (size_t)(2 * od + 3 * gd + ad);
+    HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
+    HP_TRY(b->out.ensure(batch * row * 8 + batch * 4));
+    PlanRec *d_plan = b->plan.as<PlanRec>();
+    double *d_out = b->out.as<double>();
+    float *d_r = reinterpret_cast<float *>(d_out + batch * row);
+    HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));
+    double *p = d_out;
+    auto pull = [&](double *dst, size_t n) -> hipError_t {
+        hipError_t e = dst ? hipMemcpyAsync(dst, p, n * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
+        p += n;
+        return e;
+    };
+    HP_CHECK_HIP(pull(o->obs, batch * od));
+    HP_CHECK_HIP(pull(o->ag, batch * gd));
+    HP_CHECK_HIP(pull(o->g, batch * gd));
+    HP_CHECK_HIP(pull(o->actions, batch * ad));
+    HP_CHECK_HIP(pull(o->obs_next, batch * od));
+    HP_CHECK_HIP(pull(o->ag_next, batch * gd));
+    if (o->r) HP_CHECK_HIP(hipMemcpyAsync(o->r, d_r, batch * 4, hipMemcpyDeviceToHost, s));
+    std::vector<PlanRec> hplan;
+    if (o->e || o->t || o->future_t || o->her) {
+        hplan.resize(batch);
+        HP_CHECK_HIP(hipMemcpyAsync(hplan.data(), d_plan, batch * sizeof(PlanRec), hipMemcpyDeviceToHost, s));
+    }
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < hplan.size(); ++i) {
+        if (o->e) o->e[i] = hplan[i].e;
+        if (o->t) o->t[i] = hplan[i].t;
+        if (o->future_t) o->future_t[i] = hplan[i].fut;
+        if (o->her) o->her[i] = (uint8_t)hplan[i].her;
+    }
+    return HP_OK;
+}
+
+void hp_buffer_destroy(hp_buffer *b) {
+    if (!b) return;
+    if (b->d_obs) (void)hipFree(b->d_obs);
+    if (b->d_ag) (void)hipFree(b->d_ag);
+    if (b->d_g) (void)hipFree(b->d_g);
+    if (b->d_act) (void)hipFree(b->d_act);
+    if (b->d_meta) (void)hipFree(b->d_meta);
+    b->st_obs.release();
+    b->st_ag.release();
+    b->st_g.release();
+    b->st_act.release();
+    b->st_slots.release();
+    b->pin.release();
+    b->plan.release();
+    b->out.release();
+    delete b;
+}
+
+}  // extern "C"

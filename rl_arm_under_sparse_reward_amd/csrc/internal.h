@@ -1,0 +1,191 @@
+// internal.h -- shared declarations of librlarm_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rlarm_hip.h"
+
+// ------------------------------------------------------------------ error plumbing
+void hp_set_error(const char *fmt, ...);
+
+#define HP_CHECK_HIP(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            hp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return HP_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define HP_REQUIRE(cond, code, ...)   \
+    do {                              \
+        if (!(cond)) {                \
+            hp_set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+#define HP_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != HP_OK) return _s; \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+struct hp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream kernels are enqueued on
+    hipStream_t own_stream = nullptr;  // created by the context
+    int cu_count = 0;
+    char name[128] = {0};
+};
+
+// small RAII-less device buffer helper (grow-only)
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return HP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HP_CHECK_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return HP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// pinned host staging for async H2D copies of caller-owned (pageable) arrays: the caller's memory
+// is only touched by a CPU memcpy during the call; `fence` marks the last DMA that read the buffer.
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t fence = nullptr;
+    bool pending = false;
+    int ensure(size_t need) {
+        if (!fence) HP_CHECK_HIP(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
+        if (pending) {
+            HP_CHECK_HIP(hipEventSynchronize(fence));
+            pending = false;
+        }
+        if (need <= bytes) return HP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        HP_CHECK_HIP(hipHostMalloc(&p, need, hipHostMallocDefault));
+        bytes = need;
+        return HP_OK;
+    }
+    int mark(hipStream_t s) {
+        HP_CHECK_HIP(hipEventRecord(fence, s));
+        pending = true;
+        return HP_OK;
+    }
+    void release() {
+        if (pending && fence) (void)hipEventSynchronize(fence);
+        if (p) (void)hipHostFree(p);
+        if (fence) (void)hipEventDestroy(fence);
+        p = nullptr;
+        fence = nullptr;
+        bytes = 0;
+        pending = false;
+    }
+};
+
+// ------------------------------------------------------------------ random stream
+#define MT_N 624
+struct MtState {  // device-resident, same fields as numpy's legacy state tuple
+    uint32_t key[MT_N];
+    int32_t pos;
+    int32_t pad[3];
+};
+
+struct hp_rng {
+    hp_ctx *ctx = nullptr;
+    MtState *d_state = nullptr;
+    DevBuf scratch;  // test-hook outputs
+};
+
+// one drawn transition index record (her.py:24-33)
+struct __attribute__((aligned(16))) PlanRec {
+    int32_t e;    // episode index
+    int32_t t;    // timestep
+    int32_t fut;  // t + 1 + int(u2 * (T - t))
+    int32_t her;  // u1 < future_p
+};
+
+// ------------------------------------------------------------------ replay buffer
+struct BufMeta {  // device-resident mirror of replay_buffer's counters
+    int64_t current_size;
+    int64_t n_transitions_stored;
+};
+
+struct hp_buffer {
+    hp_ctx *ctx = nullptr;
+    int64_t size = 0;  // capacity in episodes
+    int32_t T = 0, obs_dim = 0, goal_dim = 0, act_dim = 0;
+    double *d_obs = nullptr, *d_ag = nullptr, *d_g = nullptr, *d_act = nullptr;
+    BufMeta *d_meta = nullptr;
+    // host mirror (slot policy is deterministic given n_new, so the host can track it)
+    int64_t current_size = 0, n_transitions_stored = 0;
+    // staging of the most recent store_episode batch (also the source of _update_normalizer)
+    DevBuf st_obs, st_ag, st_g, st_act, st_slots;
+    PinnedBuf pin;
+    int64_t staged_n = 0;
+    // sampling scratch
+    DevBuf plan, out;
+    size_t ep_obs() const { return (size_t)(T + 1) * obs_dim; }
+    size_t ep_ag() const { return (size_t)(T + 1) * goal_dim; }
+    size_t ep_g() const { return (size_t)T * goal_dim; }
+    size_t ep_act() const { return (size_t)T * act_dim; }
+};
+
+// ------------------------------------------------------------------ normalizer
+struct NormDev {  // device-resident state; size <= 64 columns
+    float local_sum[64], local_sumsq[64], local_count[4];
+    float total_sum[64], total_sumsq[64], total_count[4];
+    float sync[132];  // sum | sumsq | count snapshot exchanged between ranks
+    float mean[64];
+    double std[64];  // float64-valued (std_f32: float32 value widened)
+};
+
+struct hp_norm {
+    hp_ctx *ctx = nullptr;
+    int32_t size = 0;
+    double eps = 1e-2, clip = 0;
+    int32_t std_f32 = 0;
+    NormDev *d = nullptr;
+    DevBuf scratch, scratch2;
+    PinnedBuf pin;
+    bool in_recompute = false;
+};
+
+// launchers implemented in the .hip files -------------------------------------------------
+// rng.hip
+int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,
+                    int32_t n_batches, double future_p, PlanRec *d_plan);
+int rng_launch_slots(hp_rng *rng, hp_buffer *buf, int64_t n_new, int64_t *d_slots);
+
+// buffer.hip
+int buffer_launch_gather_dict(hp_buffer *buf, const PlanRec *d_plan, int64_t batch, double sq_threshold,
+                              double *d_out, float *d_r);
+int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
+                           const double *actions, int64_t n_new);
+
+// norm.hip
+int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,
+                                 double clip_obs);
+int norm_launch_begin(hp_norm *nz);
+int norm_launch_end(hp_norm *nz);

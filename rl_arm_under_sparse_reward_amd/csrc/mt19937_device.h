@@ -1,0 +1,166 @@
+// mt19937_device.h -- workgroup-cooperative MT19937 + numpy-legacy draws for gfx950.
+//
+// Stands in for numpy's legacy global RandomState on the reference's hot path
+// (her.py:24,25,29,31; replay_buffer.py:64,67).  The sequence of 32-bit words is that of
+// numpy/random/src/mt19937/mt19937.c; the derived draws are
+//   randint(low, high)  : masked rejection on single words (distributions.c,
+//                         random_bounded_uint64_fill, use_masked, rng <= 0xFFFFFFFF)
+//   uniform()/random    : ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53
+// Rejection makes the number of words per sample data dependent and the four draws of
+// one HER batch are consecutive in ONE stream, so the draw is inherently sequential in
+// the stream position.  Design: ONE 256-thread workgroup owns the stream.
+//   * the 624-word key blocks live in an LDS ring of 4 blocks; block j+1 is produced from
+//     block j by a 3-phase parallel twist (k<227 reads only old words, 227<=k<454 reads the
+//     first phase's outputs, k>=454 the second's);
+//   * a draw consumes the stream in chunks of 256 (bounded) or 512 (double) words:
+//     each thread tempers one candidate, a ballot/popcount prefix sum compacts the
+//     accepted ones, and the position of the last accepted word advances the cursor;
+//   * the final (key, pos) is written back in numpy's own representation, so
+//     np.random.get_state() / set_state() interoperate at any point.
+// All control flow below is workgroup-uniform; only `tid`-indexed work differs.
+#pragma once
+#include "internal.h"
+
+#define MT_M 397
+#define MT_THREADS 256
+
+struct MtWg {
+    uint32_t (*blk)[MT_N];  // LDS ring [4][624]
+    int *ibuf;              // LDS ints [8]: wave totals [0..3], last-accept position [4]
+    long long cursor;       // absolute stream index of the next unconsumed word (block 0 = loaded key)
+    int nblk;               // blocks generated so far (ring holds blocks nblk-4 .. nblk-1)
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__device__ __forceinline__ uint32_t mt_twist_one(const uint32_t *src, const uint32_t *dst, int k) {
+    uint32_t nxt = (k + 1 < MT_N) ? src[k + 1] : dst[0];
+    uint32_t y = (src[k] & 0x80000000u) | (nxt & 0x7fffffffu);
+    uint32_t far = (k + MT_M < MT_N) ? src[k + MT_M] : dst[k + MT_M - MT_N];
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// produce block nblk from block nblk-1 (workgroup-wide)
+__device__ __forceinline__ void mt_generate_block(MtWg &g) {
+    const uint32_t *src = g.blk[(g.nblk - 1) & 3];
+    uint32_t *dst = g.blk[g.nblk & 3];
+    const int tid = threadIdx.x;
+    if (tid < MT_N - MT_M) dst[tid] = mt_twist_one(src, dst, tid);  // k in [0,227)
+    __syncthreads();
+    if (tid < MT_N - MT_M) dst[227 + tid] = mt_twist_one(src, dst, 227 + tid);  // k in [227,454)
+    __syncthreads();
+    if (tid < MT_N - 454) dst[454 + tid] = mt_twist_one(src, dst, 454 + tid);  // k in [454,624)
+    __syncthreads();
+    g.nblk += 1;
+}
+
+__device__ __forceinline__ void mt_ensure(MtWg &g, long long abs_end) {
+    while ((long long)g.nblk * MT_N < abs_end) mt_generate_block(g);
+}
+
+__device__ __forceinline__ uint32_t mt_word(const MtWg &g, long long abs) {
+    int b = (int)(abs / MT_N);
+    int o = (int)(abs - (long long)b * MT_N);
+    return mt_temper(g.blk[b & 3][o]);
+}
+
+__device__ __forceinline__ void mt_load(MtWg &g, const MtState *st, uint32_t (*ring)[MT_N], int *ibuf) {
+    g.blk = ring;
+    g.ibuf = ibuf;
+    for (int k = threadIdx.x; k < MT_N; k += MT_THREADS) ring[0][k] = st->key[k];
+    g.cursor = st->pos;
+    g.nblk = 1;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void mt_store(const MtWg &g, MtState *st) {
+    // numpy keeps (block, pos) with pos in [0,624]; a cursor on a block boundary belongs to the
+    // block just finished (pos == 624 -> "twist before the next word").
+    long long c = g.cursor;
+    int b, pos;
+    if (c > 0 && c % MT_N == 0) {
+        b = (int)(c / MT_N) - 1;
+        pos = MT_N;
+    } else {
+        b = (int)(c / MT_N);
+        pos = (int)(c % MT_N);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < MT_N; k += MT_THREADS) st->key[k] = g.blk[b & 3][k];
+    if (threadIdx.x == 0) st->pos = pos;
+}
+
+// exclusive prefix of a predicate over the 256-thread workgroup; returns this thread's rank among the
+// accepting threads and the workgroup total.  Two barriers.
+__device__ __forceinline__ int mt_prefix(MtWg &g, bool acc, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m = __ballot(acc);
+    int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) g.ibuf[wave] = __popcll(m);
+    __syncthreads();
+    int w0 = g.ibuf[0], w1 = g.ibuf[1], w2 = g.ibuf[2], w3 = g.ibuf[3];
+    int off = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return off + within;
+}
+
+// legacy randint: `count` values uniform in [0, rng] by masked rejection; emit(i, value).
+template <class Emit>
+__device__ __forceinline__ void mt_draw_bounded(MtWg &g, uint32_t rng, long long count, Emit emit) {
+    if (rng == 0u) {  // numpy consumes nothing
+        for (long long i = threadIdx.x; i < count; i += MT_THREADS) emit(i, 0u);
+        return;
+    }
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    long long produced = 0;
+    while (produced < count) {
+        mt_ensure(g, g.cursor + MT_THREADS);
+        uint32_t v = mt_word(g, g.cursor + threadIdx.x) & mask;
+        bool acc = v <= rng;
+        int total;
+        int rank = mt_prefix(g, acc, total);
+        long long idx = produced + rank;
+        if (acc && idx < count) emit(idx, v);
+        if (produced + total >= count) {
+            if (acc && idx == count - 1) g.ibuf[4] = threadIdx.x;
+            __syncthreads();
+            g.cursor += g.ibuf[4] + 1;
+            produced = count;
+            __syncthreads();
+        } else {
+            g.cursor += MT_THREADS;
+            produced += total;
+        }
+    }
+}
+
+// `count` doubles in [0,1): two words each; emit(i, u).
+template <class Emit>
+__device__ __forceinline__ void mt_draw_double(MtWg &g, long long count, Emit emit) {
+    long long produced = 0;
+    while (produced < count) {
+        long long n = count - produced;
+        if (n > MT_THREADS) n = MT_THREADS;
+        mt_ensure(g, g.cursor + 2 * n);
+        if ((long long)threadIdx.x < n) {
+            uint32_t a = mt_word(g, g.cursor + 2 * threadIdx.x) >> 5;
+            uint32_t b = mt_word(g, g.cursor + 2 * threadIdx.x + 1) >> 6;
+            double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+            emit(produced + threadIdx.x, u);
+        }
+        g.cursor += 2 * n;
+        produced += n;
+    }
+}

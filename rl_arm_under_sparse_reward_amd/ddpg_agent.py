@@ -1,0 +1,314 @@
+"""ddpg_agent -- the learner half of the reference's ddpg_agent.py on the MI355X.
+
+Same wiring as ddpg_agent.py:18-53 (actor/critic + targets, Adam x2, her_sampler,
+replay_buffer, two normalizers, optional demo preload) and the same method names for the
+pieces on the hot path:
+
+    _update_network()                 ddpg_agent.py:225-277   one sample + DDPG update
+    _soft_update_target_network()     :220-222 (both nets at once, as :149-150 calls it twice)
+    _update_normalizer(episode_batch) :187-212
+    _preproc_og(o, g)                 :214-217
+    _init_demo_buffer()               :82-90
+    save_checkpoint()                 :158-161  (same 5-element list, same state_dict keys)
+
+plus `train_cycle(episode_batch)`: lines :143-150 (store -> normalizer -> n_batches updates ->
+polyak) as ONE cached hipGraph launch.  The rollout half (`learn`, :92-161) is host-side glue
+around any gym-GoalEnv-like object and lives in `learn()`.
+
+Data never leaves the device between sampling and the optimizer step; the methods that
+return numpy (`buffer.sample`, normalizer attributes, `state_dict`) copy out on demand.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import random as _random
+from .her import her_sampler
+from .models import actor, critic
+from .normalizer import normalizer
+from .replay_buffer import replay_buffer
+from .utils import Communicator
+
+NET_ACTOR, NET_CRITIC, NET_ACTOR_TARGET, NET_CRITIC_TARGET = 0, 1, 2, 3
+
+
+class ddpg_agent:
+    def __init__(self, args, env, env_params, comm: Communicator | None = None, ctx=None, rng=None):
+        self.savetime = 0
+        self.args = args
+        self.env = env
+        self.env_params = env_params
+        self.ctx = ctx or _lib.Context.default()
+        self.lib = self.ctx.lib
+        self.comm = comm or Communicator(self.ctx.device_id)
+        self.rng = rng or _random.global_state()
+        # networks: host containers initialised like the reference (consumes the torch RNG identically)
+        self.actor_network = actor(env_params)
+        self.critic_network = critic(env_params)
+        self.actor_target_network = actor(env_params)       # re-initialised from the online nets below
+        self.critic_target_network = critic(env_params)
+        cfg = _lib.AgentCfg(
+            obs_dim=env_params['obs'], goal_dim=env_params['goal'], act_dim=env_params['action'], hidden=256,
+            batch=int(args.batch_size), grad_world_size=self.comm.world_size,
+            max_action=float(env_params['action_max']), gamma=float(args.gamma), action_l2=float(args.action_l2),
+            lr_actor=float(args.lr_actor), lr_critic=float(args.lr_critic), polyak=float(args.polyak),
+            clip_obs=float(args.clip_obs), clip_range=float(args.clip_range),
+            adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.hp_agent_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
+        for slot, net in ((NET_ACTOR, self.actor_network), (NET_CRITIC, self.critic_network),
+                          (NET_ACTOR_TARGET, self.actor_target_network),
+                          (NET_CRITIC_TARGET, self.critic_target_network)):
+            net.attach(self, slot)
+        self.actor_network.push()
+        self.critic_network.push()
+        self._broadcast_params(self.comm)                       # sync_networks x2 (ddpg_agent.py:27-28)
+        _lib.check(self.lib.hp_agent_sync_targets(self.h))      # targets := online (ddpg_agent.py:33-34)
+        # her sampler + replay buffer (ddpg_agent.py:45-47)
+        reward_func = getattr(env, "compute_reward", None)
+        self.her_module = her_sampler(args.replay_strategy, args.replay_k, reward_func,
+                                      distance_threshold=None if reward_func is not None and hasattr(
+                                          getattr(reward_func, "__self__", None), "distance_threshold")
+                                      else getattr(args, "distance_threshold", 0.05), rng=self.rng)
+        self.buffer = replay_buffer(self.env_params, self.args.buffer_size, self.her_module.sample_her_transitions,
+                                    rng=self.rng, ctx=self.ctx)
+        if getattr(self.args, "add_demo", False):
+            self._init_demo_buffer()
+        # normalizers (ddpg_agent.py:52-53)
+        self.o_norm = normalizer(size=env_params['obs'], default_clip_range=self.args.clip_range, ctx=self.ctx,
+                                 comm=self.comm)
+        self.g_norm = normalizer(size=env_params['goal'], default_clip_range=self.args.clip_range, ctx=self.ctx,
+                                 comm=self.comm)
+        self.success_rates = []
+        self.model_path = os.path.join(self.args.save_dir, self.args.env_name)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _count(self, slot):
+        return int(self.lib.hp_agent_param_count(self.h, slot))
+
+    def _get_flat(self, slot):
+        out = np.empty(self._count(slot), np.float32)
+        _lib.check(self.lib.hp_agent_get_params(self.h, slot, _lib.ptr(out, C.c_float), out.size))
+        return out
+
+    def _set_flat(self, slot, flat):
+        flat = _lib.as_f32(flat)
+        _lib.check(self.lib.hp_agent_set_params(self.h, slot, _lib.ptr(flat, C.c_float), flat.size))
+
+    def get_flat_grads(self, slot):
+        out = np.empty(self._count(slot), np.float32)
+        _lib.check(self.lib.hp_agent_get_grads(self.h, slot, _lib.ptr(out, C.c_float), out.size))
+        return out
+
+    def get_adam_state(self, slot):
+        n = self._count(slot)
+        m, v, step = np.empty(n, np.float32), np.empty(n, np.float32), C.c_int64()
+        _lib.check(self.lib.hp_agent_get_adam(self.h, slot, _lib.ptr(m, C.c_float), _lib.ptr(v, C.c_float), n,
+                                              C.byref(step)))
+        return m, v, step.value
+
+    def _broadcast_params(self, comm):
+        if comm.world_size == 1:
+            return
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.hp_agent_param_buffer(self.h, C.byref(p), C.byref(n)))
+        self.ctx.use_torch_stream()
+        comm.broadcast_device(p.value, n.value, 0)
+
+    def _allreduce_grads(self, comm):
+        if comm.world_size == 1:
+            return
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.hp_agent_grad_buffer(self.h, C.byref(p), C.byref(n)))
+        comm.allreduce_sum_device(p.value, n.value)
+
+    def _actor_forward(self, slot, x):
+        x = _lib.as_f32(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        out = np.empty((x2.shape[0], self.env_params['action']), np.float32)
+        _lib.check(self.lib.hp_agent_actor_forward(self.h, slot, _lib.ptr(x2, C.c_float), x2.shape[0],
+                                                   _lib.ptr(out, C.c_float)))
+        return out.reshape(x.shape[:-1] + (out.shape[-1],))
+
+    # ------------------------------------------------------------------ hot path
+    def _handles(self):
+        return (self.h, self.buffer._dev.h, self.o_norm.h, self.g_norm.h, self.rng.h)
+
+    def _update_network(self, n_updates=1):
+        """ddpg_agent.py:225-277, `n_updates` times back to back (the reference's inner loop :145-147)."""
+        fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
+        if self.comm.world_size == 1:
+            _lib.check(self.lib.hp_agent_sample_and_update(*self._handles(), fp, sq, int(n_updates)))
+            return
+        for _ in range(int(n_updates)):          # data-parallel ranks: grads are SUMmed between backward and Adam
+            _lib.check(self.lib.hp_agent_forward_backward(*self._handles(), fp, sq))
+            self._allreduce_grads(self.comm)
+            _lib.check(self.lib.hp_agent_apply(self.h))
+
+    def update_on_minibatch(self, x, x_next, actions, r):
+        """One update on a caller-supplied normalised minibatch (parity hook); returns (actor_loss, critic_loss)."""
+        x, xn, a = _lib.as_f32(x), _lib.as_f32(x_next), _lib.as_f32(actions)
+        r = _lib.as_f32(r).reshape(-1)
+        B = int(self.args.batch_size)
+        if x.shape[0] != B or xn.shape != x.shape or a.shape[0] != B or r.shape[0] != B:
+            raise ValueError("minibatch shapes do not match args.batch_size")
+        losses = np.empty(2, np.float32)
+        f = C.c_float
+        _lib.check(self.lib.hp_agent_update_minibatch(self.h, _lib.ptr(x, f), _lib.ptr(xn, f), _lib.ptr(a, f),
+                                                      _lib.ptr(r, f), _lib.ptr(losses, f)))
+        return float(losses[0]), float(losses[1])
+
+    def last_losses(self, n=1):
+        """(actor_loss, critic_loss) of the n most recent updates, oldest first.  Synchronises."""
+        out = np.empty(2 * n, np.float32)
+        _lib.check(self.lib.hp_agent_get_losses(self.h, _lib.ptr(out, C.c_float), n))
+        return out.reshape(n, 2)
+
+    def _soft_update_target_network(self, target=None, source=None):
+        """ddpg_agent.py:220-222.  The reference calls it once per net (:149-150); the device pass covers
+        both nets, so it acts when called for the actor pair (or with no arguments) and is a no-op for the
+        critic pair."""
+        if target is None or target is self.actor_target_network:
+            _lib.check(self.lib.hp_agent_soft_update(self.h))
+
+    def _preproc_og(self, o, g):
+        o = np.clip(o, -self.args.clip_obs, self.args.clip_obs)
+        g = np.clip(g, -self.args.clip_obs, self.args.clip_obs)
+        return o, g
+
+    def _update_normalizer(self, episode_batch=None):
+        """ddpg_agent.py:187-212 on the episodes most recently stored (they are still staged on the
+        device).  `episode_batch` is accepted for signature compatibility; passing episodes that were
+        not just stored is an error."""
+        fp = float(self.her_module.future_p)
+        _lib.check(self.lib.hp_norm_update_from_staged(self.buffer._dev.h, self.rng.h, self.o_norm.h, self.g_norm.h,
+                                                       fp, float(self.args.clip_obs)))
+        self.o_norm.recompute_stats()
+        self.g_norm.recompute_stats()
+
+    def train_cycle(self, episode_batch, n_batches=None):
+        """ddpg_agent.py:143-150 as one hipGraph: store_episode, _update_normalizer, n_batches x
+        _update_network, soft update of both targets.  Asynchronous; single rank only."""
+        n_batches = int(n_batches or self.args.n_batches)
+        if self.comm.world_size != 1:
+            self.buffer.store_episode(episode_batch)
+            self._update_normalizer(episode_batch)
+            self._update_network(n_batches)
+            self._soft_update_target_network()
+            return
+        obs, ag, g, act = (_lib.as_f64(a) for a in episode_batch)
+        d = C.c_double
+        _lib.check(self.lib.hp_agent_train_cycle(
+            *self._handles(), _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d), _lib.ptr(act, d), obs.shape[0],
+            float(self.her_module.future_p), float(self.her_module.sq_threshold), n_batches))
+
+    # ------------------------------------------------------------------ demos / checkpoints (formats preserved)
+    def _init_demo_buffer(self):
+        """ddpg_agent.py:82-90: keys obs, acs, ag, g of a get_demo_data_*.py file (info is ignored)."""
+        demo = np.load(self.args.demo_name, allow_pickle=True)
+        self.buffer.store_episode([np.array(demo['obs']), np.array(demo['ag']), np.array(demo['g']),
+                                   np.array(demo['acs'])])
+
+    def checkpoint_payload(self):
+        """The 5-element list the reference saves (ddpg_agent.py:158-161)."""
+        return [self.o_norm.mean, self.o_norm.std, self.g_norm.mean, self.g_norm.std,
+                self.actor_network.state_dict()]
+
+    def save_checkpoint(self, path=None):
+        if path is None:
+            os.makedirs(self.model_path, exist_ok=True)
+            self.savetime += 1
+            path = os.path.join(self.model_path, f"{self.args.seed}_{self.args.add_demo}{self.savetime}_model.pt")
+        torch.save(self.checkpoint_payload(), path)
+        return path
+
+    def load_checkpoint(self, path):
+        """Warm start from a reference-format checkpoint (the block commented out at ddpg_agent.py:54-62)."""
+        o_mean, o_std, g_mean, g_std, model = torch.load(path, map_location="cpu", weights_only=False)
+        self.actor_network.load_state_dict(model)
+        self.o_norm.set_stats(o_mean, o_std)
+        self.g_norm.set_stats(g_mean, g_std)
+
+    # ------------------------------------------------------------------ rollout side (host glue)
+    def _preproc_inputs(self, obs, g):
+        inputs = np.concatenate([self.o_norm.normalize(obs), self.g_norm.normalize(g)])
+        return torch.tensor(inputs, dtype=torch.float32).unsqueeze(0)
+
+    def _select_actions(self, pi):
+        """ddpg_agent.py:174-184: Gaussian noise, clip, epsilon-random (numpy global RNG, like the reference)."""
+        amax = self.env_params['action_max']
+        action = pi.cpu().numpy().squeeze()
+        action = action + self.args.noise_eps * amax * np.random.randn(*action.shape)
+        action = np.clip(action, -amax, amax)
+        random_actions = np.random.uniform(low=-amax, high=amax, size=self.env_params['action'])
+        action += np.random.binomial(1, self.args.random_eps, 1)[0] * (random_actions - action)
+        return action
+
+    def collect_episodes(self, n_rollouts, epoch=0, explore=True):
+        """Roll the policy out in self.env (gym GoalEnv dict API) and return the four episode arrays."""
+        T = int(self.env_params['max_timesteps'])
+        mb = ([], [], [], [])
+        for _ in range(n_rollouts):
+            ep_obs, ep_ag, ep_g, ep_act = [], [], [], []
+            observation = self.env.reset()
+            obs, ag, g = observation['observation'], observation['achieved_goal'], observation['desired_goal']
+            for _t in range(T):
+                pi = self.actor_network(self._preproc_inputs(obs, g))
+                action = self._select_actions(pi) if explore else pi.numpy().squeeze()
+                if epoch >= 100:
+                    action = np.clip(action, -0.15, 0.15)            # ddpg_agent.py:118-119
+                observation_new, _, _, info = self.env.step(action)
+                ep_obs.append(obs.copy()); ep_ag.append(ag.copy()); ep_g.append(g.copy()); ep_act.append(action.copy())
+                obs, ag = observation_new['observation'], observation_new['achieved_goal']
+            ep_obs.append(obs.copy()); ep_ag.append(ag.copy())
+            for dst, src in zip(mb, (ep_obs, ep_ag, ep_g, ep_act)):
+                dst.append(src)
+        return [np.array(a) for a in mb]
+
+    def learn(self):
+        """ddpg_agent.py:92-161 with the learner half on the device."""
+        for epoch in range(self.args.n_epochs):
+            start = time.time()
+            for _ in range(self.args.n_cycles):
+                # the exploration noise uses numpy's global stream; the device stream is the sampler's
+                episodes = self.collect_episodes(self.args.num_rollouts_per_mpi, epoch)
+                self.train_cycle(episodes)
+            self.ctx.synchronize()
+            print(str(time.time() - start))
+            rate = self._eval_agent()
+            self.success_rates.append(rate)
+            if self.comm.rank == 0:
+                print('[{}] epoch is: {}, eval success rate is: {:.3f}'.format(datetime.now(), epoch, rate))
+                self.save_checkpoint()
+
+    def _eval_agent(self):
+        """ddpg_agent.py:280-304."""
+        wins = []
+        for _ in range(self.args.n_test_rollouts):
+            observation = self.env.reset()
+            obs, g = observation['observation'], observation['desired_goal']
+            last = 0.0
+            for _t in range(int(self.env_params['max_timesteps'])):
+                actions = self.actor_network(self._preproc_inputs(obs, g)).numpy().squeeze()
+                observation_new, _, _, info = self.env.step(actions)
+                obs, g = observation_new['observation'], observation_new['desired_goal']
+                last = float(info.get('is_success', last))
+            wins.append(last)
+        local = torch.tensor([float(np.mean(wins))], dtype=torch.float64)
+        if self.comm.world_size > 1:
+            local = local.to(f"cuda:{self.ctx.device_id}")
+        self.comm.allreduce_mean_(local)
+        return float(local.item())
+
+    def __del__(self):
+        try:
+            self.lib.hp_agent_destroy(self.h)
+        except Exception:
+            pass

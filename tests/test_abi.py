@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/rlarm_hip.h declares, the ctypes table covers the header, and the product never
+imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "rlarm_hip.h")
+PKG = os.path.join(REPO, "rl_arm_under_sparse_reward_amd")
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    so = os.path.join(PKG, "librlarm_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(so)
+    syms = header_symbols()
+    assert len(syms) > 40
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header():
+    from rl_arm_under_sparse_reward_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == header_symbols()
+
+
+def test_no_device_fails_loudly_not_silently():
+    from rl_arm_under_sparse_reward_amd import _lib
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.HpError, match="no CPU fallback"):
+        _lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    offenders = []
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f), encoding="utf-8").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "oracle/" in src.replace(
+                        "oracle/running_norm.py for the probe", ""):
+                    offenders.append(f)
+    assert not offenders, offenders
+
+
+def test_squared_threshold_matches_oracle():
+    from oracle.her_replay import squared_distance_threshold
+    from rl_arm_under_sparse_reward_amd.her import squared_threshold
+    for thr in (0.05, 0.01, 0.1, 1.0, 0.049999999, 3.3e-3):
+        assert squared_threshold(thr) == squared_distance_threshold(thr)

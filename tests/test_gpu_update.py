@@ -1,0 +1,210 @@
+"""HIP DDPG update (csrc/agent.hip) vs the reference-generated one-update golden and the oracle.
+Tolerances (float32 network arithmetic, different but fixed summation order):
+  losses   1e-5 relative  (BASELINE.json north_star)
+  grads    2e-5 * max|g| absolute (per tensor group), post-Adam params 2e-6 absolute (lr = 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits, load_golden
+from gpu_common import ENV_PARAMS, fresh_rng, state_equal
+from oracle import ddpg_update as oupd
+from oracle.her_replay import EpisodeStore, future_probability
+from oracle.running_norm import RunningNorm, update_normalizers
+from rl_arm_under_sparse_reward_amd.arguments import Args
+from rl_arm_under_sparse_reward_amd.ddpg_agent import (NET_ACTOR, NET_ACTOR_TARGET, NET_CRITIC, NET_CRITIC_TARGET,
+                                                        ddpg_agent)
+from rl_arm_under_sparse_reward_amd.synthetic import episode_checksum, make_episodes
+
+pytestmark = pytest.mark.gpu
+LOSS_RTOL = 1e-5
+
+
+def make_agent(batch=256, n_eps=64, seed=125, replay_k=4, **kw):
+    args = Args(batch_size=batch, buffer_size=n_eps * 100, replay_k=replay_k, **kw)
+    rng = fresh_rng(seed)
+    return ddpg_agent(args, None, dict(ENV_PARAMS), rng=rng), rng
+
+
+def close(a, b, atol):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) <= atol
+
+
+def test_one_update_on_identical_minibatch_golden():
+    g = load_golden("ddpg_update.npz")
+    agent, _ = make_agent()
+    agent._set_flat(NET_ACTOR, g["init_actor"]); agent._set_flat(NET_CRITIC, g["init_critic"])
+    agent._set_flat(NET_ACTOR_TARGET, g["init_actor"]); agent._set_flat(NET_CRITIC_TARGET, g["init_critic"])
+    assert np.array_equal(agent._get_flat(NET_ACTOR), g["init_actor"])          # pack/unpack is lossless
+    assert np.array_equal(agent._get_flat(NET_CRITIC_TARGET), g["init_critic"])
+    la, lc = agent.update_on_minibatch(g["x_step1"], g["x_next_step1"], g["a_step1"], g["r_step1"])
+    assert abs(la - g["actor_loss"][0]) <= LOSS_RTOL * abs(g["actor_loss"][0]), (la, g["actor_loss"][0])
+    assert abs(lc - g["critic_loss"][0]) <= LOSS_RTOL * abs(g["critic_loss"][0]), (lc, g["critic_loss"][0])
+    ga, gc = agent.get_flat_grads(NET_ACTOR), agent.get_flat_grads(NET_CRITIC)
+    assert close(ga, g["actor_grads_step1"], 2e-5 * np.abs(g["actor_grads_step1"]).max())
+    assert close(gc, g["critic_grads_step1"], 2e-5 * np.abs(g["critic_grads_step1"]).max())
+    # relative check on the well-conditioned entries as well
+    big = np.abs(g["critic_grads_step1"]) > 1e-3 * np.abs(g["critic_grads_step1"]).max()
+    assert np.allclose(gc[big], g["critic_grads_step1"][big], rtol=2e-3, atol=0)
+    assert close(agent._get_flat(NET_ACTOR), g["actor_after_step1"], 2e-6)
+    assert close(agent._get_flat(NET_CRITIC), g["critic_after_step1"], 2e-6)
+    m, v, step = agent.get_adam_state(NET_CRITIC)
+    assert step == 1
+    assert np.allclose(m, 0.1 * g["critic_grads_step1"], rtol=1e-3, atol=1e-9)
+    # targets untouched by the update; polyak after one step
+    assert np.array_equal(agent._get_flat(NET_ACTOR_TARGET), g["init_actor"])
+    agent._soft_update_target_network()
+    want = np.float32(0.05) * agent._get_flat(NET_ACTOR) + np.float32(0.95) * g["init_actor"]
+    assert np.array_equal(agent._get_flat(NET_ACTOR_TARGET), want.astype(np.float32))
+
+
+def _golden_pipeline(agent, rng, g, use_graph):
+    n_eps, dseed, np_seed, B, k = (int(x) for x in g["meta"])
+    eps = make_episodes(n_eps, seed=dseed, mode="walk")
+    assert episode_checksum(eps) == float(g["checksum"])
+    agent._set_flat(NET_ACTOR, g["init_actor"]); agent._set_flat(NET_CRITIC, g["init_critic"])
+    agent._set_flat(NET_ACTOR_TARGET, g["init_actor"]); agent._set_flat(NET_CRITIC_TARGET, g["init_critic"])
+    if use_graph:
+        # the reference run stored all 64 episodes, then normalised on the first two: reproduce by storing
+        # 62 episodes eagerly and running the last two... is a different slot order; instead store all, then
+        # re-stage episodes 0-1 is not possible without a second store.  So the graph variant is checked
+        # against the eager variant in test_train_cycle_graph_equals_eager.
+        raise AssertionError("unused")
+    agent.buffer.store_episode(eps)
+    # _update_normalizer([first two episodes]): stage exactly those two in a scratch buffer sharing the stream
+    from rl_arm_under_sparse_reward_amd import _lib
+    from gpu_common import DeviceEpisodeBuffer
+    scratch = DeviceEpisodeBuffer(2, 100, 27, 3, 4)
+    scratch.store(rng, [a[:2] for a in eps])
+    _lib.check(agent.lib.hp_norm_update_from_staged(scratch.h, rng.h, agent.o_norm.h, agent.g_norm.h,
+                                                    agent.her_module.future_p, 200.0))
+    agent.o_norm.recompute_stats(); agent.g_norm.recompute_stats()
+
+
+def test_three_sampled_updates_from_seed_golden():
+    """End to end from the numpy seed: store -> normalizer -> 3 x (sample + update) -> polyak."""
+    g = load_golden("ddpg_update.npz")
+    agent, rng = make_agent()
+    _golden_pipeline(agent, rng, g, use_graph=False)
+    for nm, a in (("o_mean", agent.o_norm.mean), ("o_std", agent.o_norm.std), ("g_mean", agent.g_norm.mean),
+                  ("g_std", agent.g_norm.std)):
+        assert np.array_equal(bits(a), bits(g[nm])), nm
+    agent._update_network(3)
+    losses = agent.last_losses(3)
+    for i in range(3):
+        assert abs(losses[i, 0] - g["actor_loss"][i]) <= 3 * LOSS_RTOL * abs(g["actor_loss"][i]), (i, losses[i])
+        assert abs(losses[i, 1] - g["critic_loss"][i]) <= 3 * LOSS_RTOL * abs(g["critic_loss"][i]), (i, losses[i])
+    assert close(agent._get_flat(NET_ACTOR), g["actor_after_step3"], 8e-6)
+    assert close(agent._get_flat(NET_CRITIC), g["critic_after_step3"], 8e-6)
+    agent._soft_update_target_network(agent.actor_target_network, agent.actor_network)
+    agent._soft_update_target_network(agent.critic_target_network, agent.critic_network)   # no-op by design
+    assert close(agent._get_flat(NET_ACTOR_TARGET), g["actor_target_after_polyak"], 1e-6)
+    assert close(agent._get_flat(NET_CRITIC_TARGET), g["critic_target_after_polyak"], 1e-6)
+    assert state_equal(rng, g["key"], g["pos"])            # sampler consumed exactly the reference's words
+
+
+@pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (1024, 4)])
+def test_updates_track_oracle_over_a_cycle(batch, k):
+    """40 updates + polyak against the torch-CPU oracle fed the same (bit-identical) minibatches."""
+    torch.set_num_threads(4)
+    n_eps = 64
+    eps = make_episodes(n_eps, seed=3, mode="walk")
+    agent, rng = make_agent(batch=batch, n_eps=n_eps, seed=7, replay_k=k)
+    torch.manual_seed(0)
+    a0 = {kk: v.detach().clone() for kk, v in agent.actor_network.state_dict().items()}
+    c0 = {kk: v.detach().clone() for kk, v in agent.critic_network.state_dict().items()}
+    learner = oupd.DDPGLearner(a0, c0)
+    rs = np.random.RandomState(7)
+    st = EpisodeStore(100, 27, 3, 4, n_eps * 100)
+    fp = future_probability("future", k)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    st.store_episode(eps, rs)
+    agent.buffer.store_episode(eps)
+    # normaliser on the last two stored episodes (they are what is staged): same on both sides
+    two = [a[-2:] for a in eps]
+    from gpu_common import DeviceEpisodeBuffer
+    from rl_arm_under_sparse_reward_amd import _lib
+    scratch = DeviceEpisodeBuffer(2, 100, 27, 3, 4); scratch.store(rng, two)
+    _lib.check(agent.lib.hp_norm_update_from_staged(scratch.h, rng.h, agent.o_norm.h, agent.g_norm.h, fp, 200.0))
+    agent.o_norm.recompute_stats(); agent.g_norm.recompute_stats()
+    update_normalizers(on, gn, two, fp, rs)
+    n_up = 40
+    agent._update_network(n_up)
+    got = agent.last_losses(n_up)
+    for i in range(n_up):
+        tr, _ = st.sample(batch, fp, rs)
+        res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
+        # trajectories drift apart slowly (fp32 summation order feeds back through Adam): tolerance grows with i
+        tol = LOSS_RTOL * (1 + i) * 3
+        assert abs(got[i, 0] - res["actor_loss"]) <= tol * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
+        assert abs(got[i, 1] - res["critic_loss"]) <= tol * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
+    assert state_equal(rng, *rs.get_state()[1:3])
+    agent._soft_update_target_network(); learner.soft_update()
+    assert close(agent._get_flat(NET_ACTOR), learner.flat("actor"), 2e-4)
+    assert close(agent._get_flat(NET_CRITIC_TARGET), learner.flat("critic_target"), 2e-5)
+
+
+def test_train_cycle_graph_equals_eager_bitwise():
+    """The cached hipGraph cycle and the call-by-call path must produce identical bits."""
+    outs = []
+    for use_graph in (False, True):
+        agent, rng = make_agent(batch=256, n_eps=16, seed=11)       # small buffer: cycles overflow it
+        agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
+        for cycle in range(4):
+            eps = make_episodes(2, seed=100 + cycle, mode="walk")
+            if use_graph:
+                agent.train_cycle(eps, n_batches=5)
+            else:
+                agent.buffer.store_episode(eps)
+                agent._update_normalizer(eps)
+                agent._update_network(5)
+                agent._soft_update_target_network()
+        outs.append((agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_ACTOR_TARGET),
+                     agent.last_losses(20), agent.o_norm.mean, agent.g_norm.std, rng.get_state()[1], rng.get_state()[2],
+                     agent.buffer.buffers["ag"], agent.buffer.current_size))
+    for a, b in zip(*outs):
+        assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def test_actor_forward_matches_oracle():
+    agent, _ = make_agent()
+    torch.manual_seed(1)
+    x = torch.randn(37, 30)
+    p = {k: v.detach().clone() for k, v in agent.actor_network.state_dict().items()}
+    want = oupd.actor_forward(p, x, 0.5).numpy()
+    got = agent.actor_network(x).numpy()
+    assert got.shape == (37, 4) and np.allclose(got, want, rtol=1e-5, atol=1e-6)
+    one = agent.actor_network(x[:1])
+    assert np.allclose(one.numpy(), want[:1], rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    """ddpg_agent.py:158-161 format: [o_mean, o_std, g_mean, g_std, actor.state_dict()]."""
+    agent, _ = make_agent()
+    agent.o_norm.update(np.random.RandomState(0).normal(size=(50, 27))); agent.o_norm.recompute_stats()
+    path = agent.save_checkpoint(str(tmp_path / "1_model.pt"))
+    o_mean, o_std, g_mean, g_std, model = torch.load(path, map_location="cpu", weights_only=False)
+    assert list(model.keys()) == ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias",
+                                  "action_out.weight", "action_out.bias"]
+    assert model["fc1.weight"].shape == (256, 30) and model["action_out.weight"].shape == (4, 256)
+    assert o_mean.dtype == np.float32 and o_mean.shape == (27,) and g_std.shape == (3,)
+    other, _ = make_agent(seed=1)
+    other.load_checkpoint(path)
+    assert np.array_equal(other._get_flat(NET_ACTOR), agent._get_flat(NET_ACTOR))
+    assert np.array_equal(other.o_norm.mean, o_mean)
+
+
+def test_demo_npz_preload():
+    """ddpg_agent._init_demo_buffer with a file in the get_demo_data_push.py schema (pickled `info`)."""
+    import os
+    from conftest import GOLDEN
+    demo = os.path.join(GOLDEN, "bmirobot_8_push_demo.npz")
+    args = Args(batch_size=64, buffer_size=2000, add_demo=True, demo_name=demo)
+    rng = fresh_rng(5)
+    agent = ddpg_agent(args, None, dict(ENV_PARAMS), rng=rng)
+    assert agent.buffer.current_size == 8
+    d = np.load(demo, allow_pickle=True)
+    assert np.array_equal(agent.buffer.buffers["obs"][:8], d["obs"]) and np.array_equal(agent.buffer.buffers["actions"][:8], d["acs"])
+    assert agent.o_norm.total_count[0] == 1.0          # demos never feed the normalizer
+    agent._update_network(2)
+    assert np.all(np.isfinite(agent.last_losses(2)))
