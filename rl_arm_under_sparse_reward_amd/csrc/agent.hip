@@ -362,8 +362,9 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
     float mi = m[idx], vi = v[idx];
     mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));                 // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), epsf);
-    p[idx] = __fadd_rn(p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));  // addcdiv_(m, denom, -step_size)
+    const float sq = (float)__dsqrt_rn((double)vi);                     // correctly rounded float32 sqrt
+    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), epsf);
+    p[idx] = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));  // addcdiv_(m, denom, -step_size)
     m[idx] = mi;
     v[idx] = vi;
 }

@@ -95,11 +95,12 @@ __global__ void k_norm_end(NormDev *nz, int size, double eps_sq, int std_f32) {
         const float tss = __fadd_rn(nz->total_sumsq[c], nz->sync[size + c]);
         nz->total_sum[c] = ts;
         nz->total_sumsq[c] = tss;
-        const float m = __fdiv_rn(ts, cnt);
+        const float m = (float)__ddiv_rn((double)ts, (double)cnt);   // correctly rounded float32 quotient
         nz->mean[c] = m;
-        const float var = __fsub_rn(__fdiv_rn(tss, cnt), __fmul_rn(m, m));
+        const float var = __fsub_rn((float)__ddiv_rn((double)tss, (double)cnt), __fmul_rn(m, m));
         if (std_f32) {
-            nz->std[c] = (double)__fsqrt_rn(fmaxf((float)eps_sq, var));
+            // float32 sqrt via float64: innocuous double rounding (53 >= 2*24+2), correctly rounded
+            nz->std[c] = (double)(float)__dsqrt_rn((double)fmaxf((float)eps_sq, var));
         } else {
             nz->std[c] = __dsqrt_rn(fmax(eps_sq, (double)var));
         }

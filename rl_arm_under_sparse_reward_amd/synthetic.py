@@ -39,13 +39,15 @@ def make_episodes(n_episodes, seed=1, T=100, obs_dim=27, goal_dim=3, act_dim=4, 
 
 
 def episode_checksum(episode_batch) -> float:
-    """Order-sensitive float64 checksum used by fixtures to assert the generator did not drift."""
-    acc = 0.0
+    """Exact, platform-independent checksum of the float64 bit patterns (integer arithmetic only, so it
+    cannot depend on BLAS/libm code paths); returned as a float64-representable integer < 2^53."""
+    acc = 0
     for i, a in enumerate(episode_batch):
-        flat = np.asarray(a, dtype=np.float64).ravel()
-        w = np.cos(np.arange(flat.size, dtype=np.float64) * (0.37 + 0.11 * i))
-        acc += float(np.dot(flat, w))
-    return acc
+        u = np.ascontiguousarray(a, dtype=np.float64).ravel().view(np.uint64)
+        w = (np.arange(u.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(i + 1)) | np.uint64(1)
+        with np.errstate(over="ignore"):
+            acc = (acc + int(np.sum(u * w, dtype=np.uint64))) & ((1 << 64) - 1)
+    return float(acc >> 11)
 
 
 def write_demo_npz(path, n_episodes=8, seed=7, T=100):
