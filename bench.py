@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- HER-relabelled transitions sampled+updated per second on MI355X.
+
+Metric (BASELINE.json): transitions/s = B x (completed `_update_network` equivalents) / wall time,
+steady state, replay buffer resident in HBM, PyBullet excluded.  A "step" is one pass of the hot
+path over one minibatch: draw B indices, gather + relabel + reward + clip + normalise, 5 forwards,
+3 backwards, Adam x2.  Every 40 steps (one training cycle, ddpg_agent.py:143-150) the cycle
+boundary work is included in the timed region: store 2 fresh episodes (random-slot overwrite of a
+full buffer), normalizer update + recompute, polyak update of both targets.
+
+Workload at N=1 = BASELINE.json configs[1]: push task, buffer 5e5 (5000 episodes x 100 steps),
+batch 256, replay_k=4.  N>1 (launched by torchrun, one rank per GPU): every rank owns a 5000-episode
+shard and its own sampler stream (seed + rank, train.py:36); per step the gradients are all-reduced
+(SUM, utils.py:47) between backward and Adam, per cycle the normalizer statistics are all-reduced
+(mean, normalizer.py:60-64).  Weak scaling: global batch = N x 256.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_BATCHES = 40            # arguments.py:77
+ROLLOUTS_PER_CYCLE = 2    # arguments.py:100
+FLOP_PER_TRANSITION = 2.0 * 1_382_912   # minimal algorithm, SURVEY.md section 8(d): 5 fwd + 3 bwd
+FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 (no TF32 on gfx950)
+HBM_PEAK_GBPS = 8000.0
+# sample kernel algorithmic bytes / transition with this build's float64 storage:
+#   reads  64 f64 (obs 27 + obs_next 27 + ag_next 3 + g-or-future-ag 3 + action 4) + one 16 B index record
+#   writes 95 f32 (x 30 -> critic input and actor input, x' 30, a/max_action 4, reward 1)
+SAMPLE_BYTES_PER_TRANSITION = 64 * 8 + 16 + 95 * 4
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--episodes", type=int, default=5000, help="episodes resident per GPU (buffer 5e5)")
+    ap.add_argument("--replay-k", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    return ap.parse_args()
+
+
+class Runner:
+    """Builds the device-side state for one rank and advances it in units of steps."""
+
+    def __init__(self, a, rank, world):
+        import torch
+
+        from rl_arm_under_sparse_reward_amd import _lib
+        from rl_arm_under_sparse_reward_amd.arguments import Args
+        from rl_arm_under_sparse_reward_amd.ddpg_agent import ddpg_agent
+        from rl_arm_under_sparse_reward_amd.random import DeviceRandomState
+        from rl_arm_under_sparse_reward_amd.synthetic import ENV_PARAMS, make_episodes
+        from rl_arm_under_sparse_reward_amd.utils import Communicator
+
+        self.torch = torch
+        self.world = world
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        self.ctx = _lib.Context(local)
+        if world > 1:
+            self.ctx.use_torch_stream()      # order our kernels with the RCCL collectives torch enqueues
+        args = Args(batch_size=a.batch, buffer_size=a.episodes * 100, replay_k=a.replay_k, seed=125 + rank)
+        self.rng = DeviceRandomState(args.seed, ctx=self.ctx)
+        torch.manual_seed(0)                 # same initial networks on every rank (plus the broadcast)
+        self.agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=Communicator(local), ctx=self.ctx, rng=self.rng)
+        # resident shard (BASELINE.md section 3 recipe)
+        eps = make_episodes(a.episodes, seed=1 + rank)
+        self.agent.buffer.store_episode(eps)
+        self.agent._update_normalizer()      # prime the normalizer (on the staged episodes' first T samples)
+        self.pool = [make_episodes(ROLLOUTS_PER_CYCLE, seed=10_000 + 977 * rank + i) for i in range(16)]
+        self.cycle = 0
+        self.in_cycle = 0                    # steps done in the current cycle
+        self.ctx.synchronize()
+
+    def _open_cycle_eager(self):
+        ag = self.agent
+        ag.buffer.store_episode(self.pool[self.cycle % len(self.pool)])
+        ag._update_normalizer()
+
+    def run_steps(self, k):
+        """Advance exactly k steps, including every cycle boundary crossed."""
+        ag = self.agent
+        while k > 0:
+            if self.in_cycle == 0 and k >= N_BATCHES and self.world == 1:
+                ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
+                self.cycle += 1
+                k -= N_BATCHES
+                continue
+            if self.in_cycle == 0:
+                self._open_cycle_eager()
+            n = min(k, N_BATCHES - self.in_cycle)
+            ag._update_network(n)
+            self.in_cycle += n
+            k -= n
+            if self.in_cycle == N_BATCHES:
+                ag._soft_update_target_network()
+                self.in_cycle = 0
+                self.cycle += 1
+
+    def sync(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+
+
+def profile_kernels(r: Runner, cycles=3):
+    """Per-kernel-family device time measured with HIP events on the launch stream (eager launches,
+    one event pair per launch; csrc/agent.hip ProfScope)."""
+    import ctypes as C
+
+    from rl_arm_under_sparse_reward_amd import _lib
+
+    ag = r.agent
+    _lib.check(ag.lib.hp_agent_profile(ag.h, 1))
+    steps = 0
+    for _ in range(cycles):
+        r._open_cycle_eager()
+        ag._update_network(N_BATCHES)
+        ag._soft_update_target_network()
+        r.cycle += 1
+        steps += N_BATCHES
+    r.sync()
+    out = (C.c_double * 12)()
+    _lib.check(ag.lib.hp_agent_profile_read(ag.h, out, 12))
+    _lib.check(ag.lib.hp_agent_profile(ag.h, 0))
+    names = ("sample", "gemm_fwd", "gemm_bwd", "loss_head", "adam_polyak", "index_plan")
+    prof = {}
+    for i, nm in enumerate(names):
+        ms, cnt = out[2 * i], out[2 * i + 1]
+        prof[nm] = {"ms_per_step": ms / steps, "launches_per_step": cnt / steps, "avg_us": (1e3 * ms / cnt) if cnt else 0.0}
+    return prof
+
+
+def cpu_baseline(a, seconds):
+    """The oracle ("port": numpy sampler + torch-CPU update, the reference's own arithmetic) on the
+    host cores, same workload, bounded sample.  Checker code used as a timed baseline only."""
+    import torch
+
+    from oracle import ddpg_update as oupd
+    from oracle.her_replay import EpisodeStore, future_probability
+    from oracle.running_norm import RunningNorm, update_normalizers
+    from rl_arm_under_sparse_reward_amd.synthetic import make_episodes
+
+    n_eps = a.episodes
+    eps = make_episodes(n_eps, seed=1)
+    rs = np.random.RandomState(125)
+    st = EpisodeStore(100, 27, 3, 4, n_eps * 100)
+    st.store_episode(eps, rs)
+    fp = future_probability("future", a.replay_k)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    update_normalizers(on, gn, [x[:2] for x in eps], fp, rs)
+    res = {}
+    cores = os.cpu_count() or 1
+    for threads in sorted({1, cores}):
+        torch.set_num_threads(threads)
+        learner = oupd.DDPGLearner(oupd.init_actor(27, 3, 4, 0), oupd.init_critic(27, 3, 4, 1))
+        for _ in range(5):
+            tr, _ = st.sample(a.batch, fp, rs)
+            learner.update(*oupd.minibatch_tensors(tr, on, gn))
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2:
+            tr, _ = st.sample(a.batch, fp, rs)
+            learner.update(*oupd.minibatch_tensors(tr, on, gn))
+            n += 1
+            if n % N_BATCHES == 0:
+                learner.soft_update()
+        dt = time.perf_counter() - t0
+        res[threads] = (n * a.batch / dt, n, dt)
+    best = max(res, key=lambda k: res[k][0])
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": round(res[best][0], 1), "unit": "transitions/s", "cores": best, "kind": "port",
+        "sample": f"{res[best][1]} sample+update steps at batch {a.batch} on a {n_eps}-episode buffer "
+                  f"({res[best][2]:.1f} s), oracle = numpy legacy-RNG sampler + torch-CPU update",
+        "value_1_thread": round(res[1][0], 1), "host_cpu": model, "host_cores": cores,
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    r = Runner(a, rank, world)
+    r.run_steps(a.warmup)
+    r.sync()
+    barrier(world)
+    r.sync()
+    t0 = time.perf_counter()
+    r.run_steps(a.steps)
+    r.sync()
+    barrier(world)
+    r.sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = r.agent.last_losses(1)[0]
+    prof = None
+    if rank == 0 and not a.no_profile:
+        prof = profile_kernels(r)
+    if world > 1:
+        barrier(world)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_per_step = 1e3 * dt / a.steps
+    value = world * a.batch * a.steps / dt
+    out = {
+        "metric": "HER-relabelled transitions sampled+updated per second",
+        "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
+                               f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
+                               "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
+                   "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
+                   "parallelism": f"dp{world}" + (" (RCCL grad SUM + normalizer MEAN all-reduce)" if world > 1 else ""),
+                   "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
+                   "final_losses": [float(losses[0]), float(losses[1])]},
+    }
+    if prof:
+        gemm_ms = prof["gemm_fwd"]["ms_per_step"] + prof["gemm_bwd"]["ms_per_step"]
+        gemm_launches = prof["gemm_fwd"]["launches_per_step"] + prof["gemm_bwd"]["launches_per_step"]
+        flops_step = FLOP_PER_TRANSITION * a.batch
+        achieved = flops_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "k_gemm_group (grouped FP32 v_mfma_f32_16x16x4_f32, all 16 launches of a step)",
+            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "flop_per_launch": round(flops_step / gemm_launches, 1) if gemm_launches else None,
+            "avg_launch_us": round(1e3 * gemm_ms / gemm_launches, 3) if gemm_launches else None,
+            "note": "launch/dependency-latency bound at batch 256: 0.71 GFLOP per step over 16 dependent grouped "
+                    "launches; durations from HIP events around each eager launch",
+        }
+        s_ms = prof["sample"]["ms_per_step"]
+        s_gbps = SAMPLE_BYTES_PER_TRANSITION * a.batch / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+        out["roofline_sample_kernel"] = {"bound": "hbm", "kernel": "k_gather_fused", "achieved": round(s_gbps, 2),
+                                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(s_gbps / HBM_PEAK_GBPS, 6),
+                                         "avg_launch_us": round(prof["sample"]["avg_us"], 3), "traffic": None}
+        out["kernel_time_us_per_step"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

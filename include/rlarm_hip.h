@@ -56,6 +56,11 @@ int hp_ctx_create(int device_id, hp_ctx **out);
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
+/* diagnostic: average microseconds per dependent trivial kernel on the context's stream, measured
+ * as an n-node captured hipGraph (graph != 0) or n eager launches (the launch floor in DESIGN.md) */
+int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel);
+/* diagnostic: shader clock in MHz observed by a probe kernel enqueued now (DVFS state under this load) */
+int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz);
 void hp_ctx_destroy(hp_ctx *ctx);
 
 /* ---- random stream ------------------------------------------------------------------
@@ -197,6 +202,10 @@ int hp_agent_train_cycle(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm 
 
 /* timing hook for bench.py: average device time (ms) of the kernels tagged `which` over the
  * last recorded region; see DESIGN.md "Measurement". */
+/* diagnostic: microseconds per launch of ONE stage of the update, repeated n times in a captured
+ * hipGraph (kind: 0 loss, 1 actor head, 2 forward hidden level, 3 forward first level, 4 q heads,
+ * 5 backward hidden level, 6 adam, 8 polyak) -- the per-stage numbers quoted in DESIGN.md */
+int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_launch);
 int hp_agent_profile(hp_agent *ag, int32_t enable);
 int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
 

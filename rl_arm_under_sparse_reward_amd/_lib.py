@@ -48,6 +48,8 @@ PROTOTYPES = {
     "hp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "hp_ctx_launch_floor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p]),
+    "hp_ctx_clock_mhz": (C.c_int, [C.c_void_p, f64p]),
     "hp_ctx_destroy": (None, [C.c_void_p]),
     "hp_rng_create": (C.c_int, [C.c_void_p, c_void_pp]),
     "hp_rng_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -93,6 +95,7 @@ PROTOTYPES = {
     "hp_agent_sync_targets": (C.c_int, [C.c_void_p]),
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
                                        f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
+    "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
     "hp_agent_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_profile_read": (C.c_int, [C.c_void_p, f64p, C.c_int32]),
     "hp_agent_destroy": (None, [C.c_void_p]),

@@ -27,6 +27,8 @@
 // the actor reads columns 0..31, the critic 0..47 (its W1 columns are permuted to match).
 #include "internal.h"
 
+#include <cstdlib>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------- structures
@@ -118,6 +120,35 @@ struct hp_agent {
 //                         dW = dY^T X                 (A = dY, a_si = 1, a_sk = ldy;  B = X, b_sj = 1, b_sk = ldx)
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l & 15][k = l >> 4] and
 // B[k = l >> 4][j = l & 15]; accumulator register r holds D[row = 4 * (l >> 4) + r][col = l & 15].
+#include "gemm_lds.h"
+
+struct Acc {
+    f32x4 c00, c01, c10, c11;
+    float as0, as1;
+};
+
+template <int S>
+__device__ __forceinline__ void mma_chunk(Acc &acc, const float *a0, const float *b0, long long a16, long long b16,
+                                          long long astep, long long bstep, bool vm1, bool vn1) {
+    float av0[S], av1[S], bv0[S], bv1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        av0[s] = a0[s * astep];
+        bv0[s] = b0[s * bstep];
+        av1[s] = vm1 ? a0[a16 + s * astep] : 0.f;
+        bv1[s] = vn1 ? b0[b16 + s * bstep] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        acc.c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv0[s], acc.c00, 0, 0, 0);
+        acc.c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv1[s], acc.c01, 0, 0, 0);
+        acc.c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv0[s], acc.c10, 0, 0, 0);
+        acc.c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv1[s], acc.c11, 0, 0, 0);
+        acc.as0 += av0[s];
+        acc.as1 += av1[s];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroup grp) {
     __shared__ float red[4][32 * 33];
     __shared__ float bsum[4][32];
@@ -137,22 +168,36 @@ __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroup grp) {
     const float *b0 = p.B + (long long)(n0 + i) * p.b_sj + (long long)kbeg * p.b_sk;
     const long long a16 = 16ll * p.a_si, b16 = 16ll * p.b_sj;
     const long long astep = 4ll * p.a_sk, bstep = 4ll * p.b_sk;
-    f32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-    float as0 = 0.f, as1 = 0.f;
-    const int steps = ksl >> 2;
-#pragma unroll 4
-    for (int s = 0; s < steps; ++s) {
-        const float av0 = a0[s * astep];
-        const float bv0 = b0[s * bstep];
-        const float av1 = vm1 ? a0[a16 + s * astep] : 0.f;
-        const float bv1 = vn1 ? b0[b16 + s * bstep] : 0.f;
-        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1, c11, 0, 0, 0);
-        as0 += av0;
-        as1 += av1;
+    Acc acc;
+    acc.c00 = acc.c01 = acc.c10 = acc.c11 = f32x4{0, 0, 0, 0};
+    acc.as0 = acc.as1 = 0.f;
+    // epilogue operands do not depend on the products: fetch them now so their (cold-cache) latency
+    // overlaps the operand loads instead of following the LDS reduction
+    const int erow = tid >> 3, ecol = (tid & 7) * 4;
+    const int em = m0 + erow, en = n0 + ecol;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (em < p.M && en < p.N) {
+        if (p.epi == EPI_BIAS_RELU || p.epi == EPI_BIAS || p.epi == EPI_BIAS_TANH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ev[j] = p.bias[en + j];
+        } else if (p.epi == EPI_MASK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ev[j] = p.mask[(long long)em * p.ldmask + en + j];
+        }
     }
+    int steps = ksl >> 2;
+    // every kernel starts with cold caches (the boundary invalidates them), so a dependent load costs
+    // ~0.7 us: issue a whole chunk of operand loads before the first MFMA consumes any of them
+    while (steps >= 16) {
+        mma_chunk<16>(acc, a0, b0, a16, b16, astep, bstep, vm1, vn1);
+        a0 += 16 * astep; b0 += 16 * bstep; steps -= 16;
+    }
+    if (steps >= 8) { mma_chunk<8>(acc, a0, b0, a16, b16, astep, bstep, vm1, vn1); a0 += 8 * astep; b0 += 8 * bstep; steps -= 8; }
+    if (steps >= 4) { mma_chunk<4>(acc, a0, b0, a16, b16, astep, bstep, vm1, vn1); a0 += 4 * astep; b0 += 4 * bstep; steps -= 4; }
+    if (steps >= 2) { mma_chunk<2>(acc, a0, b0, a16, b16, astep, bstep, vm1, vn1); a0 += 2 * astep; b0 += 2 * bstep; steps -= 2; }
+    if (steps >= 1) { mma_chunk<1>(acc, a0, b0, a16, b16, astep, bstep, vm1, vn1); }
+    const f32x4 c00 = acc.c00, c01 = acc.c01, c10 = acc.c10, c11 = acc.c11;
+    float as0 = acc.as0, as1 = acc.as1;
     // partial tiles -> LDS (row stride 33 spreads the 4 row groups over banks)
     float *my = red[wave];
 #pragma unroll
@@ -191,22 +236,22 @@ __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroup grp) {
     switch (p.epi) {
         case EPI_BIAS_RELU:
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + p.bias[n + j], 0.f);
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + ev[j], 0.f);
             break;
         case EPI_BIAS:
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = v[j] + p.bias[n + j];
+            for (int j = 0; j < 4; ++j) v[j] = v[j] + ev[j];
             break;
         case EPI_MASK:
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (p.mask[(long long)m * p.ldmask + n + j] > 0.f) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = (ev[j] > 0.f) ? v[j] : 0.f;
             break;
         case EPI_BIAS_TANH: {
             // models.py:24: actions = max_action * tanh(.); the critic consumes actions / max_action
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (n + j < p.n_store) {
-                    const float th = tanhf(v[j] + p.bias[n + j]);
+                    const float th = tanhf(v[j] + ev[j]);
                     p.C2[(long long)m * p.ldc2 + n + j] = th;
                     p.C[(long long)m * p.ldc + n + j] = (p.max_action * th) / p.max_action;
                 }
@@ -445,9 +490,17 @@ struct ProfScope {
     }
 };
 
+static bool use_direct_gemm() {  // A/B switch: RLARM_GEMM=direct selects the first (global-fed) kernel
+    static const bool v = [] { const char *e = getenv("RLARM_GEMM"); return e && strcmp(e, "direct") == 0; }();
+    return v;
+}
+
 static int launch_group(hp_agent *a, const Launch &L, int which) {
     ProfScope ps(a, which);
-    hipLaunchKernelGGL(k_gemm_group, dim3(L.tiles), dim3(256), 0, a->ctx->stream, L.g);
+    if (use_direct_gemm())
+        hipLaunchKernelGGL(k_gemm_group, dim3(L.tiles), dim3(256), 0, a->ctx->stream, L.g);
+    else
+        hipLaunchKernelGGL(k_gemm_lds, dim3(L.tiles), dim3(GL_THREADS), 0, a->ctx->stream, L.g);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -1033,6 +1086,81 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
     }
     HP_CHECK_HIP(hipGraphLaunch(a->graph, s));
     a->host_steps += n_batches;
+    return HP_OK;
+}
+
+// diagnostic: time `n` back-to-back launches of ONE stage of the update as a captured hipGraph.
+//   kind 0: k_loss   1: k_actor_head   2: forward level 2 (3 x 256x256x256)   3: forward level 1 (K=32/48)
+//   4: forward heads (N=16)   5: backward level (dX+dW+dX, 256^3)   6: k_adam   7: k_gather_fused is not
+//   available here (needs a buffer); 8: k_polyak
+int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_launch) {
+    HP_REQUIRE(a && us_per_launch && n > 0, HP_ERR_INVALID, "hp_agent_debug_chain: bad argument");
+    hipStream_t s = a->ctx->stream;
+    const int H = a->H, Mp = a->Mp, ldx = a->ldx;
+    const NetLayout &la = a->la, &lc = a->lc;
+    float *Pa = a->params, *Pc = a->params + la.total, *Ta = a->targets, *Gc = a->grads + la.total;
+    auto one = [&]() -> int {
+        switch (kind) {
+            case 0:
+                hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, a->QT, a->QA, a->QP, a->R, a->XP, ldx, a->act_off,
+                                   (int)a->cfg.act_dim, a->B, Mp, 0.98f, 50.f, 1.f, a->dQA, a->dQP, a->loss_log, a->d_state);
+                return HP_OK;
+            case 1:
+                hipLaunchKernelGGL(k_actor_head, dim3((a->B * a->cfg.act_dim + 255) / 256), dim3(256), 0, s, a->dXP, a->XP,
+                                   a->TP, ldx, a->act_off, (int)a->cfg.act_dim, a->B, 1.f, 0.5f, a->dZ);
+                return HP_OK;
+            case 2: {
+                Launch L;
+                add_fwd(L, a->AT.h1, H, H, Ta + la.w2, Ta + la.b2, a->AT.h2, H, Mp, H, EPI_BIAS_RELU);
+                add_fwd(L, a->CA.h1, H, H, Pc + lc.w2, Pc + lc.b2, a->CA.h2, H, Mp, H, EPI_BIAS_RELU);
+                add_fwd(L, a->AP.h1, H, H, Pa + la.w2, Pa + la.b2, a->AP.h2, H, Mp, H, EPI_BIAS_RELU);
+                return launch_group(a, L, PROF_GEMM_FWD);
+            }
+            case 3: {
+                Launch L;
+                add_fwd(L, a->XT, ldx, la.K1, Ta + la.w1, Ta + la.b1, a->AT.h1, H, Mp, H, EPI_BIAS_RELU);
+                add_fwd(L, a->XA, ldx, lc.K1, Pc + lc.w1, Pc + lc.b1, a->CA.h1, H, Mp, H, EPI_BIAS_RELU);
+                add_fwd(L, a->XP, ldx, la.K1, Pa + la.w1, Pa + la.b1, a->AP.h1, H, Mp, H, EPI_BIAS_RELU);
+                return launch_group(a, L, PROF_GEMM_FWD);
+            }
+            case 4: {
+                Launch L;
+                add_fwd(L, a->CA.h3, H, H, Pc + lc.w4, Pc + lc.b4, a->QA, 16, Mp, 16, EPI_BIAS);
+                add_fwd(L, a->CP.h3, H, H, Pc + lc.w4, Pc + lc.b4, a->QP, 16, Mp, 16, EPI_BIAS);
+                return launch_group(a, L, PROF_GEMM_FWD);
+            }
+            case 5: {
+                Launch L;
+                add_dx(L, a->dA3, H, H, Pc + lc.w3, H, a->dA2, H, Mp, a->CA.h2, H);
+                add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
+                add_dx(L, a->dP3, H, H, Pc + lc.w3, H, a->dP2, H, Mp, a->CP.h2, H);
+                return launch_group(a, L, PROF_GEMM_BWD);
+            }
+            case 6: return enqueue_adam(a);
+            case 8: return enqueue_polyak(a);
+            default: hp_set_error("hp_agent_debug_chain: unknown kind %d", kind); return HP_ERR_INVALID;
+        }
+    };
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int st = HP_OK;
+    for (int i = 0; i < n && st == HP_OK; ++i) st = one();
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (st != HP_OK) return st;
+    HP_CHECK_HIP(e);
+    HP_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HP_CHECK_HIP(hipGraphLaunch(ge, s));
+    HP_CHECK_HIP(hipEventRecord(a->ev0, s));
+    HP_CHECK_HIP(hipGraphLaunch(ge, s));
+    HP_CHECK_HIP(hipEventRecord(a->ev1, s));
+    HP_CHECK_HIP(hipEventSynchronize(a->ev1));
+    float ms = 0.f;
+    HP_CHECK_HIP(hipEventElapsedTime(&ms, a->ev0, a->ev1));
+    *us_per_launch = 1e3 * ms / n;
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
     return HP_OK;
 }
 

@@ -3,6 +3,21 @@
 
 static thread_local char g_err[512] = "";
 
+// shader-clock probe: s_memtime ticks (shader cycles) per wall_clock64 tick (100 MHz constant clock)
+__global__ void k_clock_probe(unsigned long long *out, int spin) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    unsigned long long c1 = c0;
+    while ((long long)(c1 - c0) < spin) c1 = __builtin_readcyclecounter();
+    const unsigned long long w1 = wall_clock64();
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+}
+
+__global__ void k_floor_probe(int *p) {
+    if (threadIdx.x == 0) p[0] += 1;
+}
+
 void hp_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -63,6 +78,61 @@ int hp_ctx_synchronize(hp_ctx *ctx) {
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len) {
     HP_REQUIRE(ctx && buf && len > 0, HP_ERR_INVALID, "hp_ctx_device_name: bad argument");
     snprintf(buf, len, "%s", ctx->name);
+    return HP_OK;
+}
+
+// diagnostic: average cost of one dependent trivial kernel on the context's stream, as a captured
+// hipGraph of n nodes (graph != 0) or n eager launches.  Used by DESIGN.md's launch-floor numbers.
+int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel) {
+    HP_REQUIRE(ctx && us_per_kernel && n > 0, HP_ERR_INVALID, "hp_ctx_launch_floor: bad argument");
+    hipStream_t s = ctx->stream;
+    int *d = nullptr;
+    HP_CHECK_HIP(hipMalloc((void **)&d, 4));
+    HP_CHECK_HIP(hipMemsetAsync(d, 0, 4, s));
+    hipEvent_t e0, e1;
+    HP_CHECK_HIP(hipEventCreate(&e0));
+    HP_CHECK_HIP(hipEventCreate(&e1));
+    float ms = 0.f;
+    if (graph) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        HP_CHECK_HIP(hipStreamSynchronize(s));
+        HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_floor_probe, dim3(1), dim3(64), 0, s, d);
+        HP_CHECK_HIP(hipStreamEndCapture(s, &g));
+        HP_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HP_CHECK_HIP(hipGraphLaunch(ge, s));
+        HP_CHECK_HIP(hipEventRecord(e0, s));
+        HP_CHECK_HIP(hipGraphLaunch(ge, s));
+        HP_CHECK_HIP(hipEventRecord(e1, s));
+        HP_CHECK_HIP(hipEventSynchronize(e1));
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+    } else {
+        for (int i = 0; i < 64; ++i) hipLaunchKernelGGL(k_floor_probe, dim3(1), dim3(64), 0, s, d);
+        HP_CHECK_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_floor_probe, dim3(1), dim3(64), 0, s, d);
+        HP_CHECK_HIP(hipEventRecord(e1, s));
+        HP_CHECK_HIP(hipEventSynchronize(e1));
+    }
+    HP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_kernel = 1e3 * ms / n;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return HP_OK;
+}
+
+// diagnostic: shader clock (MHz) seen by a kernel enqueued right now on the context's stream
+int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz) {
+    HP_REQUIRE(ctx && mhz, HP_ERR_INVALID, "hp_ctx_clock_mhz: bad argument");
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    HP_CHECK_HIP(hipMalloc((void **)&d, 16));
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, ctx->stream, d, 40000);
+    HP_CHECK_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return HP_OK;
 }
 

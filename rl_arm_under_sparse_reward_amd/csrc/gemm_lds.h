@@ -1,0 +1,187 @@
+// gemm_lds.h -- grouped FP32-MFMA GEMM, LDS-staged operands (included by agent.hip).
+//
+// Why a second kernel: the first version fed v_mfma_f32_16x16x4_f32 straight from global memory
+// with one dword per lane, i.e. 16 rows x 16 B per wave-instruction for K-contiguous operands.
+// Measured on MI355X (rocprofv3, profiles/): a 3 x [256x256x256] level took 10.5 us and even the
+// 16-column head level 8.5 us -- texture-address bound, not math bound.  Here every operand chunk
+// is brought in with full-line float4 loads by all 512 threads (one cold-cache round trip for the
+// whole tile), parked in LDS, and the MFMA fragments are read from there:
+//   * operand with a contiguous reduction index ("rowK": X, W in the forward pass, dY in dX)
+//       LDS image [32][KC + 4] floats; lane (i, q) reads ONE float4 = A[i][16S + 4q .. +3] per
+//       super-step S and feeds its 4 components to 4 consecutive MFMAs (the reduction index is
+//       permuted identically for both operands, so the sum is the same set of products);
+//       row stride 260 floats puts the 16 lanes of a ds_read_b128 group on 16 different
+//       4-bank slots (conflict free).
+//   * operand with a strided reduction index ("kmajor": W in dX, dY and X in dW)
+//       LDS image [KC][36] floats; lane (i, q) reads lds[16S + 4q + c][i], c = 0..3: lanes i are
+//       consecutive banks and the q groups are 4 rows = 144 floats = 16 banks apart.
+// 8 wavefronts split the super-steps of a chunk (short dependent MFMA chains), partial tiles are
+// combined through LDS in a fixed order, bias / ReLU / tanh / ReLU-mask run in the epilogue, whose
+// operands are prefetched before the products (every kernel starts cache-cold).
+#pragma once
+
+#define GL_THREADS 512
+#define GL_WAVES 8
+#define GL_KC 256
+#define GL_ROWK_LD (GL_KC + 4)
+#define GL_KMAJ_LD 36
+#define GL_OPERAND_FLOATS (GL_KC * GL_KMAJ_LD)  // 9216 floats = larger of the two images (rowK: 32*260 = 8320)
+
+// stage one 32 x kc operand chunk into LDS.  `valid` = number of real rows/cols (16 or 32).
+__device__ __forceinline__ void gl_stage(float *lds, const float *base, long long s_idx, long long s_k, int valid,
+                                         int kc, bool rowk) {
+    const int tid = threadIdx.x;
+    if (rowk) {
+        const int per_row = kc >> 2;  // float4 per row
+        const int total = 32 * per_row;
+        for (int f = tid; f < total; f += GL_THREADS) {
+            const int idx = f / per_row, k4 = f - idx * per_row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < valid) v = *reinterpret_cast<const float4 *>(base + idx * s_idx + 4 * k4);
+            *reinterpret_cast<float4 *>(lds + idx * GL_ROWK_LD + 4 * k4) = v;
+        }
+    } else {
+        const int total = kc * 8;  // 8 float4 per reduction row
+        for (int f = tid; f < total; f += GL_THREADS) {
+            const int k = f >> 3, i4 = f & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * i4 < valid) v = *reinterpret_cast<const float4 *>(base + k * s_k + 4 * i4);
+            *reinterpret_cast<float4 *>(lds + k * GL_KMAJ_LD + 4 * i4) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag, int S, int i, int q) {
+    if (rowk) return *reinterpret_cast<const float4 *>(lds + (frag * 16 + i) * GL_ROWK_LD + 16 * S + 4 * q);
+    const float *p = lds + (16 * S + 4 * q) * GL_KMAJ_LD + frag * 16 + i;
+    return make_float4(p[0], p[GL_KMAJ_LD], p[2 * GL_KMAJ_LD], p[3 * GL_KMAJ_LD]);
+}
+
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * GL_OPERAND_FLOATS];  // A image | B image; reused for the reduction
+    __shared__ float bsum[GL_WAVES][32];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PROBS; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.p[i].tile0) pi = i;
+    const GemmProb &p = grp.p[pi];
+    const int t = blockIdx.x - p.tile0;
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
+    const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
+    float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
+    // epilogue operands first (cold-cache latency overlaps the operand staging)
+    const int erow = tid >> 3, ecol = (tid & 7) * 4;
+    const int em = m0 + erow, en = n0 + ecol;
+    const bool etile = tid < 256 && erow < vm && ecol < vn;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (etile) {
+        if (p.epi == EPI_BIAS_RELU || p.epi == EPI_BIAS || p.epi == EPI_BIAS_TANH) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + en);
+            ev[0] = b4.x; ev[1] = b4.y; ev[2] = b4.z; ev[3] = b4.w;
+        } else if (p.epi == EPI_MASK) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(p.mask + (long long)em * p.ldmask + en);
+            ev[0] = b4.x; ev[1] = b4.y; ev[2] = b4.z; ev[3] = b4.w;
+        }
+    }
+    f32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    float as0 = 0.f, as1 = 0.f;
+    const float *Abase = p.A + (long long)m0 * p.a_si;
+    const float *Bbase = p.B + (long long)n0 * p.b_sj;
+    for (int k0 = 0; k0 < p.K; k0 += GL_KC) {
+        const int kc = (p.K - k0) < GL_KC ? (p.K - k0) : GL_KC;
+        if (k0 > 0) __syncthreads();  // previous chunk fully consumed
+        gl_stage(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
+        gl_stage(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
+        __syncthreads();
+        const int nS = kc >> 4;
+        for (int S = wave; S < nS; S += GL_WAVES) {
+            const float4 a0 = gl_frag(ldsA, a_rowk, 0, S, i, q), a1 = gl_frag(ldsA, a_rowk, 1, S, i, q);
+            const float4 b0 = gl_frag(ldsB, b_rowk, 0, S, i, q), b1 = gl_frag(ldsB, b_rowk, 1, S, i, q);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv0[c], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv1[c], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv0[c], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv1[c], c11, 0, 0, 0);
+                as0 += av0[c];
+                as1 += av1[c];
+            }
+        }
+    }
+    __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
+    float *my = lds + wave * (32 * 33);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        my[row * 33 + i] = c00[r];
+        my[row * 33 + 16 + i] = c01[r];
+        my[(16 + row) * 33 + i] = c10[r];
+        my[(16 + row) * 33 + 16 + i] = c11[r];
+    }
+    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0;
+    if (want_bias_grad) {
+        as0 += __shfl_xor(as0, 16);
+        as0 += __shfl_xor(as0, 32);
+        as1 += __shfl_xor(as1, 16);
+        as1 += __shfl_xor(as1, 32);
+        if (q == 0) {
+            bsum[wave][i] = as0;
+            bsum[wave][16 + i] = as1;
+        }
+    }
+    __syncthreads();
+    if (want_bias_grad && tid < vm) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < GL_WAVES; ++w) s += bsum[w][tid];
+        p.bias_grad[m0 + tid] = s;
+    }
+    if (!etile) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = erow * 33 + ecol + j;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < GL_WAVES; ++w) s += lds[w * (32 * 33) + o];
+        v[j] = s;
+    }
+    switch (p.epi) {
+        case EPI_BIAS_RELU:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + ev[j], 0.f);
+            break;
+        case EPI_BIAS:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] + ev[j];
+            break;
+        case EPI_MASK:
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (ev[j] > 0.f) ? v[j] : 0.f;
+            break;
+        case EPI_BIAS_TANH: {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (en + j < p.n_store) {
+                    const float th = tanhf(v[j] + ev[j]);
+                    p.C2[(long long)em * p.ldc2 + en + j] = th;
+                    p.C[(long long)em * p.ldc + en + j] = (p.max_action * th) / p.max_action;
+                }
+            }
+            return;
+        }
+        default: break;
+    }
+    if (en + 3 < p.n_store) {
+        *reinterpret_cast<float4 *>(p.C + (long long)em * p.ldc + en) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (en + j < p.n_store) p.C[(long long)em * p.ldc + en + j] = v[j];
+    }
+}

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace sqlite database: per-kernel count / avg / share, plus the
+per-launch sequence of one update step (durations in us).  Usage: trace_summary.py trace_results.db"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+rows = cur.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
+                   "from kernels group by name order by 6 desc").fetchall()
+tot = sum(r[5] for r in rows)
+print(f"{'kernel':44s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'share':>6s}")
+for r in rows:
+    print(f"{r[0][:44]:44s} {r[1]:7d} {r[2]/1e3:8.2f} {r[3]/1e3:8.2f} {r[4]/1e3:8.2f} {100*r[5]/tot:5.1f}%")
+ks = cur.execute("select start,end,name,grid_x from kernels order by start").fetchall()
+g = [i for i, k in enumerate(ks) if k[2].startswith("k_gather_fused")]
+if len(g) > 4:
+    i0 = g[len(g) // 2]
+    i1 = g[len(g) // 2 + 1]
+    seq = ks[i0:i1]
+    print("one update step:", " ".join(f"{k[2].split('(')[0][2:8]}:{(k[1]-k[0])/1e3:.1f}" for k in seq),
+          f"| total {(seq[-1][1]-seq[0][0])/1e3:.1f} us, {len(seq)} launches")
