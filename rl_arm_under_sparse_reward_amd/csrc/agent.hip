@@ -56,7 +56,7 @@ struct GemmProb {
     float max_action;    // EPI_BIAS_TANH
 };
 
-#define MAX_PROBS 6
+#define MAX_PROBS 8
 struct GemmGroup {
     int n;
     GemmProb p[MAX_PROBS];
@@ -69,9 +69,27 @@ struct Pass {  // hidden activations of one forward pass
 struct AgentDevState {      // small device-resident scalars
     long long step;         // Adam step counter (both optimizers step together)
     long long n_logged;     // number of loss pairs written
+    // per-step Adam scalars (torch computes them in Python doubles and narrows where used)
+    float neg_step_actor, neg_step_critic, bc2_sqrt, pad;
 };
 
+struct AdamCfg {
+    double lr_actor, lr_critic, beta1, beta2, eps;
+};
+
+// bias corrections of torch.optim.Adam for the step that is about to be applied
+__device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c) {
+    const double step = (double)st->step;
+    const double bc1 = 1.0 - pow(c.beta1, step);
+    const double bc2 = 1.0 - pow(c.beta2, step);
+    st->neg_step_actor = (float)(-(c.lr_actor / bc1));
+    st->neg_step_critic = (float)(-(c.lr_critic / bc1));
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+
 #define LOSS_LOG 4096
+
+#include "slab.h"
 
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_N = 6 };
 
@@ -91,6 +109,9 @@ struct hp_agent {
     float *dZ = nullptr, *dK3 = nullptr, *dK2 = nullptr, *dK1 = nullptr;   // actor
     float *loss_log = nullptr;
     AgentDevState *d_state = nullptr;
+    // row-slab engine: fragment-ordered weight copies (online forward / online dX / target forward), loss partials
+    float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
+    bool slab = true;
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(256) void k_loss(const float *__restrict__ QT, cons
                                               const float *__restrict__ QP, const float *__restrict__ R,
                                               const float *__restrict__ XP, int ldx, int act_off, int act_dim, int B,
                                               int Mp, float gamma, float clip_ret, float action_l2, float *dQA,
-                                              float *dQP, float *loss_log, AgentDevState *st) {
+                                              float *dQP, float *loss_log, AgentDevState *st, const AdamCfg adam) {
     __shared__ float sh[4];
     float sc = 0.f, sq = 0.f, sl2 = 0.f;
     const float invB = 1.0f / (float)B;
@@ -371,6 +392,7 @@ __global__ __launch_bounds__(256) void k_loss(const float *__restrict__ QT, cons
         loss_log[(k % LOSS_LOG) * 2 + 1] = critic_loss;
         st->n_logged = k + 1;
         st->step += 1;
+        adam_prepare(st, adam);
     }
 }
 
@@ -392,24 +414,18 @@ __global__ void k_actor_head(const float *__restrict__ dXP, const float *__restr
 // torch.optim.Adam (_single_tensor_adam, no weight decay / amsgrad) over the whole arena.
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
                                               float *__restrict__ m, float *__restrict__ v, int n, int n_actor,
-                                              double lr_actor, double lr_critic, double beta1, double beta2,
-                                              double eps, const AgentDevState *st) {
+                                              float w, float b2, float omb2, float epsf, const AgentDevState *st) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const double step = (double)st->step;
-    const double bc1 = 1.0 - pow(beta1, step);
-    const double bc2 = 1.0 - pow(beta2, step);
-    const double lr = (idx < n_actor) ? lr_actor : lr_critic;
-    const float neg_step_size = (float)(-(lr / bc1));
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2), epsf = (float)eps;
+    const float neg_step_size = (idx < n_actor) ? st->neg_step_actor : st->neg_step_critic;
+    const float bc2_sqrt = st->bc2_sqrt;
     const float gi = g[idx];
     float mi = m[idx], vi = v[idx];
     mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));                 // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float sq = (float)__dsqrt_rn((double)vi);                     // correctly rounded float32 sqrt
     const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), epsf);
-    p[idx] = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));  // addcdiv_(m, denom, -step_size)
+    p[idx] = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
     m[idx] = mi;
     v[idx] = vi;
 }
@@ -419,6 +435,59 @@ __global__ void k_polyak(float *__restrict__ tgt, const float *__restrict__ src,
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     tgt[idx] = __fadd_rn(__fmul_rn(one_minus, src[idx]), __fmul_rn(polyak, tgt[idx]));
+}
+
+// slab engine: Adam that also refreshes the fragment-ordered copies and finishes the loss log
+__global__ __launch_bounds__(256) void k_adam_frag(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, float *fragF,
+                                                   float *fragD, int n, int n_actor, float w, float b2, float omb2,
+                                                   float epsf, AgentDevState *st, const ArenaMap am,
+                                                   const float *__restrict__ part, int nslab, int B, int act_dim,
+                                                   float action_l2, float *loss_log) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {  // mean over slabs in slab order: deterministic
+        float tc = 0.f, tq = 0.f, tl = 0.f;
+        for (int s = 0; s < nslab; ++s) {
+            tc += part[s];
+            tq += part[nslab + s];
+            tl += part[2 * nslab + s];
+        }
+        const float invB = 1.0f / (float)B;
+        const long long k = st->n_logged;
+        loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + action_l2 * (tl / (float)(B * act_dim));
+        loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
+        st->n_logged = k + 1;
+    }
+    if (idx >= n) return;
+    const float neg_step_size = (idx < n_actor) ? st->neg_step_actor : st->neg_step_critic;
+    const float bc2_sqrt = st->bc2_sqrt;
+    const float gi = g[idx];
+    float mi = m[idx], vi = v[idx];
+    mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));
+    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
+    const float sq = (float)__dsqrt_rn((double)vi);
+    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), epsf);
+    const float pn = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
+    p[idx] = pn;
+    m[idx] = mi;
+    v[idx] = vi;
+    int of, od;
+    frag_offsets(am, idx, of, od);
+    if (of >= 0) {
+        fragF[of] = pn;
+        fragD[od] = pn;
+    }
+}
+
+__global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__ src, float *fragFT, int n,
+                              float one_minus, float polyak, const ArenaMap am) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float t = __fadd_rn(__fmul_rn(one_minus, src[idx]), __fmul_rn(polyak, tgt[idx]));
+    tgt[idx] = t;
+    int of, od;
+    frag_offsets(am, idx, of, od);
+    if (of >= 0) fragFT[of] = t;
 }
 
 // actor forward for rollouts: x [rows, xdim] -> padded input rows
@@ -438,6 +507,10 @@ __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, 
 }
 
 // ------------------------------------------------------------------------------- host side
+static AdamCfg adam_cfg(const hp_agent *a) {
+    return AdamCfg{a->cfg.lr_actor, a->cfg.lr_critic, a->cfg.adam_beta1, a->cfg.adam_beta2, a->cfg.adam_eps};
+}
+
 static NetLayout make_layout(int K1, int H) {
     NetLayout l;
     l.K1 = K1;
@@ -548,8 +621,10 @@ static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, c
     return HP_OK;
 }
 
-// forwards + losses + backwards of one update, inputs already in XA/XP/XT/R (19 launches minus Adam)
-static int enqueue_forward_backward(hp_agent *a) {
+static int enqueue_forward_backward_slab(hp_agent *a);
+
+// layer-per-launch engine: forwards + losses + backwards of one update, inputs in XA/XP/XT/R (18 launches)
+static int enqueue_forward_backward_layers(hp_agent *a) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     float *Pa = a->params, *Pc = a->params + la.total;
@@ -616,7 +691,7 @@ static int enqueue_forward_backward(hp_agent *a) {
         const double clip_ret = 1.0 / (1.0 - a->cfg.gamma);  // ddpg_agent.py:259
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, a->QT, a->QA, a->QP, a->R, a->XP, ldx, a->act_off,
                            (int)a->cfg.act_dim, a->B, Mp, (float)a->cfg.gamma, (float)clip_ret,
-                           (float)a->cfg.action_l2, a->dQA, a->dQP, a->loss_log, a->d_state);
+                           (float)a->cfg.action_l2, a->dQA, a->dQP, a->loss_log, a->d_state, adam_cfg(a));
         HP_CHECK_HIP(hipGetLastError());
     }
     {   // level 10-13: backward through the critic, for the critic loss (dX + dW) and for the actor loss (dX only)
@@ -679,12 +754,97 @@ static int enqueue_forward_backward(hp_agent *a) {
     return HP_OK;
 }
 
+static int enqueue_forward_backward(hp_agent *a) {
+    return a->slab ? enqueue_forward_backward_slab(a) : enqueue_forward_backward_layers(a);
+}
+
+static ArenaMap arena_map(const hp_agent *a) {
+    ArenaMap am;
+    am.la = a->la;
+    am.lc = a->lc;
+    am.H = a->H;
+    return am;
+}
+
+static int enqueue_relayout(hp_agent *a, bool targets) {
+    const int n = a->n_arena;
+    hipLaunchKernelGGL(k_relayout, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream,
+                       targets ? a->targets : a->params, targets ? a->fragFT : a->fragF,
+                       targets ? (float *)nullptr : a->fragD, n, arena_map(a));
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
+static int enqueue_forward_backward_slab(hp_agent *a) {
+    const int H = a->H, Mp = a->Mp, ldx = a->ldx;
+    const NetLayout &la = a->la, &lc = a->lc;
+    hipStream_t s = a->ctx->stream;
+    const int nslab = Mp / SL_ROWS;
+    {
+        ProfScope ps(a, PROF_GEMM_FWD);
+        FwdSlabArgs A;
+        A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
+        A.target = SlabNetPtrs{a->fragFT, nullptr, a->targets};
+        A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim; A.Mp = Mp;
+        A.max_action = (float)a->cfg.max_action;
+        A.XA = a->XA; A.XT = a->XT; A.XP = a->XP; A.TP = a->TP;
+        A.CAh1 = a->CA.h1; A.CAh2 = a->CA.h2; A.CAh3 = a->CA.h3;
+        A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
+        A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
+        A.QT = a->QT; A.QA = a->QA; A.QP = a->QP;
+        hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, A);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(a, PROF_GEMM_BWD);
+        BwdSlabArgs A;
+        A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
+        A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim;
+        A.B = a->B; A.Mp = Mp;
+        A.max_action = (float)a->cfg.max_action; A.gamma = (float)a->cfg.gamma;
+        A.clip_ret = (float)(1.0 / (1.0 - a->cfg.gamma)); A.action_l2 = (float)a->cfg.action_l2;
+        A.QT = a->QT; A.QA = a->QA; A.QP = a->QP; A.R = a->R; A.XP = a->XP; A.TP = a->TP;
+        A.CAh1 = a->CA.h1; A.CAh2 = a->CA.h2; A.CAh3 = a->CA.h3;
+        A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
+        A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
+        A.dQA = a->dQA; A.dA3 = a->dA3; A.dA2 = a->dA2; A.dA1 = a->dA1;
+        A.dZ = a->dZ; A.dK3 = a->dK3; A.dK2 = a->dK2; A.dK1 = a->dK1;
+        A.part = a->part; A.st = a->d_state; A.adam = adam_cfg(a);
+        hipLaunchKernelGGL(k_bwd_slab, dim3(nslab, 2), dim3(SL_THREADS), 0, s, A);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    {   // all weight gradients: the only products that reduce over the batch
+        float *Ga = a->grads, *Gc = a->grads + la.total;
+        Launch L;
+        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
+        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
+        add_dw(L, a->dA1, H, H, a->XA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
+        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+        add_dw(L, a->dK1, H, H, a->XP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+    }
+    return HP_OK;
+}
+
 static int enqueue_adam(hp_agent *a) {
     ProfScope ps(a, PROF_ADAM);
     const int n = a->n_arena;
+    if (a->slab) {
+        hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->params, a->grads,
+                           a->adam_m, a->adam_v, a->fragF, a->fragD, n, a->la.total,
+                           (float)(1.0 - a->cfg.adam_beta1), (float)a->cfg.adam_beta2,
+                           (float)(1.0 - a->cfg.adam_beta2), (float)a->cfg.adam_eps, a->d_state, arena_map(a), a->part,
+                           a->Mp / SL_ROWS, a->B, (int)a->cfg.act_dim, (float)a->cfg.action_l2, a->loss_log);
+        HP_CHECK_HIP(hipGetLastError());
+        return HP_OK;
+    }
     hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->params, a->grads, a->adam_m,
-                       a->adam_v, n, a->la.total, a->cfg.lr_actor, a->cfg.lr_critic, a->cfg.adam_beta1,
-                       a->cfg.adam_beta2, a->cfg.adam_eps, a->d_state);
+                       a->adam_v, n, a->la.total, (float)(1.0 - a->cfg.adam_beta1), (float)a->cfg.adam_beta2,
+                       (float)(1.0 - a->cfg.adam_beta2), (float)a->cfg.adam_eps, a->d_state);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -693,6 +853,12 @@ static int enqueue_polyak(hp_agent *a) {
     ProfScope ps(a, PROF_ADAM);
     const int n = a->n_arena;
     const double om = 1.0 - a->cfg.polyak;
+    if (a->slab) {
+        hipLaunchKernelGGL(k_polyak_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->targets, a->params,
+                           a->fragFT, n, (float)om, (float)a->cfg.polyak, arena_map(a));
+        HP_CHECK_HIP(hipGetLastError());
+        return HP_OK;
+    }
     hipLaunchKernelGGL(k_polyak, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->targets, a->params, n, (float)om,
                        (float)a->cfg.polyak);
     HP_CHECK_HIP(hipGetLastError());
@@ -835,6 +1001,11 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
     A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
     A(&a->loss_log, LOSS_LOG * 2);
+    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / SL_ROWS));
+    {
+        const char *e = getenv("RLARM_ENGINE");   // "layers" selects the layer-per-launch engine (A/B and debugging)
+        a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
+    }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK && hipEventCreate(&a->ev0) != hipSuccess) st = HP_ERR_HIP;
     if (st == HP_OK && hipEventCreate(&a->ev1) != hipSuccess) st = HP_ERR_HIP;
@@ -864,6 +1035,7 @@ int hp_agent_set_params(hp_agent *a, int32_t net, const float *flat_host, int64_
     pack_net(a, critic, flat_host, seg.data());
     float *dst = (target ? a->targets : a->params) + (critic ? a->la.total : 0);
     HP_CHECK_HIP(hipMemcpyAsync(dst, seg.data(), sizeof(float) * l.total, hipMemcpyHostToDevice, a->ctx->stream));
+    HP_TRY(enqueue_relayout(a, target));
     HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
     return HP_OK;
 }
@@ -898,7 +1070,7 @@ int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, in
 int hp_agent_sync_targets(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_sync_targets: null handle");
     HP_CHECK_HIP(hipMemcpyAsync(a->targets, a->params, sizeof(float) * a->n_arena, hipMemcpyDeviceToDevice, a->ctx->stream));
-    return HP_OK;
+    return enqueue_relayout(a, true);
 }
 
 int hp_agent_update_minibatch(hp_agent *a, const float *x, const float *x_next, const float *actions, const float *r,
@@ -1103,7 +1275,8 @@ int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_la
         switch (kind) {
             case 0:
                 hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, s, a->QT, a->QA, a->QP, a->R, a->XP, ldx, a->act_off,
-                                   (int)a->cfg.act_dim, a->B, Mp, 0.98f, 50.f, 1.f, a->dQA, a->dQP, a->loss_log, a->d_state);
+                                   (int)a->cfg.act_dim, a->B, Mp, 0.98f, 50.f, 1.f, a->dQA, a->dQP, a->loss_log, a->d_state,
+                                   adam_cfg(a));
                 return HP_OK;
             case 1:
                 hipLaunchKernelGGL(k_actor_head, dim3((a->B * a->cfg.act_dim + 255) / 256), dim3(256), 0, s, a->dXP, a->XP,
@@ -1138,6 +1311,7 @@ int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_la
             }
             case 6: return enqueue_adam(a);
             case 8: return enqueue_polyak(a);
+            case 10: return enqueue_forward_backward(a);   // whole forward+backward of the active engine
             default: hp_set_error("hp_agent_debug_chain: unknown kind %d", kind); return HP_ERR_INVALID;
         }
     };

@@ -1,0 +1,419 @@
+// slab.h -- "row-slab" engine for the DDPG update (included by agent.hip).
+//
+// Measured on MI355X (profiles/, DESIGN.md "launch floor"): a dependent kernel boundary costs
+// ~1.55 us for a trivial kernel and 4-6 us for any kernel that has to pull its operands through
+// cold caches (the boundary write-backs/invalidates the non-coherent per-XCD L2s).  The layer-per-
+// launch engine needs 20 such boundaries per update, ~130 us, for 4.6 us worth of FP32-MFMA math.
+// Every product in the forward passes and in the dX half of the backward passes is ROW-independent:
+// row m of layer l+1 depends only on row m of layer l.  So one workgroup can carry a slab of 16
+// batch rows through an entire chain of layers with the activations parked in LDS, and no other
+// workgroup ever needs its intermediate results:
+//     k_fwd_slab   chain T: actor_target(x') -> critic_target(x', a')            -> Q'
+//                  chain A: critic(x, a)                                          -> Q,  h1..h3 kept
+//                  chain P: actor(x) -> critic(x, pi(x))                          -> Qpi, h1..h3 of both kept
+//     k_bwd_slab   chain A: dL_c/dq -> dX through critic layers 4,3,2              (dY of every layer kept)
+//                  chain P: dL_a/dq -> critic 4,3,2,1 -> tanh/L2 head -> actor 4,3,2 (dY of actor layers kept)
+// Only the weight gradients reduce over the batch; they are one grouped GEMM launch (gemm_lds.h)
+// over the kept activations / dY, followed by the fused Adam.  5 launches per update instead of 20.
+//
+// Per layer a workgroup streams the whole weight matrix once (256 KB for 256x256) from L2; to make
+// that stream full-line and conflict free the weights are kept in a second, fragment-ordered copy:
+//   forward  Wf[(nf * K/16 + S) * 256 + lane * 4 + c] = W[16 nf + (lane & 15)][16 S + 4 (lane >> 4) + c]
+//   dX       Wd[(kf * N/16 + S) * 256 + lane * 4 + c] = W[16 S + 4 (lane >> 4) + c][16 kf + (lane & 15)]
+// so the B operand of v_mfma_f32_16x16x4_f32 for super-step S (16 reduction indices, 4 MFMAs) is ONE
+// float4 per lane, 1 KiB contiguous per wavefront.  Adam / polyak write these copies together with
+// the canonical row-major parameters.  A operands (activations, dY) are read from LDS rows of 260
+// floats, one ds_read_b128 per lane per super-step (conflict free, see gemm_lds.h).
+#pragma once
+
+#define SL_THREADS 512
+#define SL_WAVES 8
+#define SL_ROWS 16
+#define SL_LD 260  // LDS row stride of a 256-wide activation slab (floats)
+#define SL_LDX 52  // LDS row stride of the 48-wide network-input slab
+
+__host__ __device__ __forceinline__ int frag_fwd_index(int n, int k, int K) {
+    return (((n >> 4) * (K >> 4) + (k >> 4)) << 8) + (((n & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3);
+}
+__host__ __device__ __forceinline__ int frag_dx_index(int n, int k, int N) {
+    return (((k >> 4) * (N >> 4) + (n >> 4)) << 8) + (((k & 15) + 16 * ((n & 15) >> 2)) << 2) + (n & 3);
+}
+
+struct ArenaMap {  // enough of the arena geometry to find (layer, n, k) of a flat index on the device
+    NetLayout la, lc;
+    int H;
+};
+
+// canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases
+__host__ __device__ __forceinline__ void frag_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d) {
+    const bool critic = idx >= am.la.total;
+    const NetLayout &l = critic ? am.lc : am.la;
+    const int base = critic ? am.la.total : 0;
+    const int r = idx - base;
+    int w0, N, K;
+    if (r < l.b1) { w0 = l.w1; N = am.H; K = l.K1; }
+    else if (r < l.w2) { off_f = off_d = -1; return; }
+    else if (r < l.b2) { w0 = l.w2; N = am.H; K = am.H; }
+    else if (r < l.w3) { off_f = off_d = -1; return; }
+    else if (r < l.b3) { w0 = l.w3; N = am.H; K = am.H; }
+    else if (r < l.w4) { off_f = off_d = -1; return; }
+    else if (r < l.b4) { w0 = l.w4; N = 16; K = am.H; }
+    else { off_f = off_d = -1; return; }
+    const int e = r - w0, n = e / K, k = e - n * K;
+    off_f = base + w0 + frag_fwd_index(n, k, K);
+    off_d = base + w0 + frag_dx_index(n, k, N);
+}
+
+__global__ void k_relayout(const float *__restrict__ canon, float *fragF, float *fragD, int n, const ArenaMap am) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int of, od;
+    frag_offsets(am, idx, of, od);
+    if (of >= 0) {
+        const float v = canon[idx];
+        fragF[of] = v;
+        if (fragD) fragD[od] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+enum { SE_BIAS_RELU = 0, SE_MASK = 1 };
+
+__device__ __forceinline__ void slab_mma8(f32x4 &c0, f32x4 &c1, const float4 a, const float4 b0, const float4 b1) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, c1, 0, 0, 0);
+}
+
+template <int NS>
+__device__ __forceinline__ void slab_mma(f32x4 &c0, f32x4 &c1, const float4 *__restrict__ w0,
+                                         const float4 *__restrict__ w1, const float *ap) {
+    float4 b0[NS], b1[NS];
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        b0[S] = w0[S * 64];
+        b1[S] = w1[S * 64];
+    }
+    // hipcc otherwise sinks every load next to its MFMA (load, wait, use): pin the load phase
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * S);
+        slab_mma8(c0, c1, a, b0[S], b1[S]);
+    }
+}
+
+// One dense layer on a 16-row slab held in LDS:  out[16][16*nfrag] = epi(in[16][K] . Wfrag)
+//   lin   LDS input rows (stride ld_in), K a multiple of 16
+//   wf    fragment-ordered weights of this layer (forward or dX copy)
+//   epi   SE_BIAS_RELU: out = max(acc + aux[col], 0)         (aux = bias vector)
+//         SE_MASK:      out = aux[row * ldaux + col] > 0 ? acc : 0   (aux = kept activation of the layer below, global)
+//   lout  LDS output rows (stride ld_out)
+// Each wavefront owns output fragments nf = wave, wave + 8, ...; both of its fragments share the A read.
+__device__ __forceinline__ void slab_layer(const float *lin, int ld_in, int K, const float *__restrict__ wf, int nfrag,
+                                           int epi, const float *__restrict__ aux, int ldaux, float *lout,
+                                           int ld_out) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int nS = K >> 4;
+    for (int nf0 = wave; nf0 < nfrag; nf0 += 2 * SL_WAVES) {
+        const int nf1 = nf0 + SL_WAVES;
+        const bool two = nf1 < nfrag;
+        const float4 *w0 = reinterpret_cast<const float4 *>(wf) + (size_t)nf0 * nS * 64 + lane;
+        const float4 *w1 = reinterpret_cast<const float4 *>(wf) + (size_t)(two ? nf1 : nf0) * nS * 64 + lane;
+        f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+        const float *ap = lin + i * ld_in + 4 * q;
+        switch (nS) {   // compile-time trip counts: every weight load of the layer is in flight before the first MFMA
+            case 16: slab_mma<16>(c0, c1, w0, w1, ap); break;
+            case 3: slab_mma<3>(c0, c1, w0, w1, ap); break;
+            case 2: slab_mma<2>(c0, c1, w0, w1, ap); break;
+            case 1: slab_mma<1>(c0, c1, w0, w1, ap); break;
+            default:
+                for (int S = 0; S < nS; ++S) {
+                    const float4 b0 = w0[S * 64];
+                    const float4 b1 = w1[S * 64];
+                    const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * S);
+                    slab_mma8(c0, c1, a, b0, b1);
+                }
+        }
+        // accumulator register r holds out[row = 4q + r][col = 16 nf + i]
+        const int col0 = 16 * nf0 + i, col1 = 16 * nf1 + i;
+        if (epi == SE_BIAS_RELU) {
+            const float bb0 = aux[col0], bb1 = two ? aux[col1] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lout[(4 * q + r) * ld_out + col0] = fmaxf(c0[r] + bb0, 0.f);
+                if (two) lout[(4 * q + r) * ld_out + col1] = fmaxf(c1[r] + bb1, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q + r;
+                lout[row * ld_out + col0] = (aux[(size_t)row * ldaux + col0] > 0.f) ? c0[r] : 0.f;
+                if (two) lout[row * ld_out + col1] = (aux[(size_t)row * ldaux + col1] > 0.f) ? c1[r] : 0.f;
+            }
+        }
+    }
+}
+
+// 16-output head on a 16-row slab: the 8 wavefronts split the reduction, partials meet in LDS.
+// Returns (to threads 0..255: row = tid >> 4, col = tid & 15) the raw sum; caller adds bias etc.
+__device__ __forceinline__ float slab_head(const float *lin, int ld_in, int K, const float *__restrict__ wf,
+                                           float *scratch /* >= 8*256 floats */) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int nS = K >> 4;
+    const float4 *w0 = reinterpret_cast<const float4 *>(wf) + lane;
+    f32x4 c0 = {0, 0, 0, 0};
+    const float *ap = lin + i * ld_in + 4 * q;
+    for (int S = wave; S < nS; S += SL_WAVES) {
+        const float4 b0 = w0[S * 64];
+        const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * S);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, c0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * q + r) * 16 + i] = c0[r];
+    __syncthreads();
+    float s = 0.f;
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < SL_WAVES; ++w) s += scratch[w * 256 + tid];
+    }
+    return s;
+}
+
+// copy a 16 x width LDS slab (stride ld) to global rows (stride ldg), float4, all threads
+__device__ __forceinline__ void slab_store(const float *l, int ld, int width, float *g, int ldg) {
+    const int per_row = width >> 2;
+    for (int f = threadIdx.x; f < SL_ROWS * per_row; f += SL_THREADS) {
+        const int r = f / per_row, c4 = f - r * per_row;
+        *reinterpret_cast<float4 *>(g + (size_t)r * ldg + 4 * c4) = *reinterpret_cast<const float4 *>(l + r * ld + 4 * c4);
+    }
+}
+
+__device__ __forceinline__ void slab_load(float *l, int ld, int width, const float *g, int ldg) {
+    const int per_row = width >> 2;
+    for (int f = threadIdx.x; f < SL_ROWS * per_row; f += SL_THREADS) {
+        const int r = f / per_row, c4 = f - r * per_row;
+        *reinterpret_cast<float4 *>(l + r * ld + 4 * c4) = *reinterpret_cast<const float4 *>(g + (size_t)r * ldg + 4 * c4);
+    }
+}
+
+struct SlabNetPtrs {
+    const float *wf;     // forward-fragment copy of the whole arena this net lives in
+    const float *wd;     // dX-fragment copy (online nets only)
+    const float *canon;  // canonical arena (biases, head rows)
+};
+
+struct FwdSlabArgs {
+    SlabNetPtrs online, target;   // arenas: [actor | critic]
+    NetLayout la, lc;
+    int H, ldx, act_off, act_dim, Mp;
+    float max_action;
+    const float *XA, *XT;
+    float *XP;                    // x part read, action block written
+    float *TP;                    // raw tanh of the online actor
+    float *CAh1, *CAh2, *CAh3, *APh1, *APh2, *APh3, *CPh1, *CPh2, *CPh3;
+    float *QT, *QA, *QP;          // [Mp][16], column 0
+};
+
+// trunk of one network on the slab: xin (K1 wide) -> h1 -> h2 -> h3, optionally keeping copies in global
+__device__ __forceinline__ void slab_trunk(const float *xin, const NetLayout &l, const float *wf, const float *canon,
+                                           int H, float *bufA, float *bufB, float *g1, float *g2, float *g3,
+                                           size_t row0) {
+    slab_layer(xin, SL_LDX, l.K1, wf + l.w1, H >> 4, SE_BIAS_RELU, canon + l.b1, 0, bufA, SL_LD);
+    __syncthreads();
+    if (g1) slab_store(bufA, SL_LD, H, g1 + row0 * H, H);
+    slab_layer(bufA, SL_LD, H, wf + l.w2, H >> 4, SE_BIAS_RELU, canon + l.b2, 0, bufB, SL_LD);
+    __syncthreads();
+    if (g2) slab_store(bufB, SL_LD, H, g2 + row0 * H, H);
+    slab_layer(bufB, SL_LD, H, wf + l.w3, H >> 4, SE_BIAS_RELU, canon + l.b3, 0, bufA, SL_LD);
+    __syncthreads();
+    if (g3) slab_store(bufA, SL_LD, H, g3 + row0 * H, H);
+}
+
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fwd_slab(const FwdSlabArgs A) {
+    __shared__ __attribute__((aligned(16))) float xin[SL_ROWS * SL_LDX];
+    __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[SL_ROWS * SL_LD];
+    __shared__ float scratch[SL_WAVES * 256];
+    const int slab = blockIdx.x, chain = blockIdx.y;
+    const size_t row0 = (size_t)slab * SL_ROWS;
+    const int tid = threadIdx.x;
+    const int H = A.H;
+    const NetLayout &la = A.la, &lc = A.lc;
+    const int ca = la.total;  // critic segment offset inside an arena
+    if (chain == 1) {
+        // critic(x, a)
+        slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
+        __syncthreads();
+        slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0);
+        const float s = slab_head(bufA, SL_LD, H, A.online.wf + ca + lc.w4, scratch);
+        if (tid < 256 && (tid & 15) == 0) A.QA[(row0 + (tid >> 4)) * 16] = s + A.online.canon[ca + lc.b4];
+        return;
+    }
+    const bool tgt = (chain == 0);
+    const SlabNetPtrs &net = tgt ? A.target : A.online;
+    float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
+    slab_load(xin, SL_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
+    __syncthreads();
+    // actor
+    slab_trunk(xin, la, net.wf, net.canon, H, bufA, bufB, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
+               tgt ? nullptr : A.APh3, row0);
+    {
+        const float s = slab_head(bufA, SL_LD, H, net.wf + la.w4, scratch);
+        if (tid < 256) {
+            const int r = tid >> 4, c = tid & 15;
+            if (c < A.act_dim) {
+                const float th = tanhf(s + net.canon[la.b4 + c]);
+                const float u = (A.max_action * th) / A.max_action;   // models.py:24 then :38
+                xin[r * SL_LDX + A.act_off + c] = u;
+                X[(row0 + r) * A.ldx + A.act_off + c] = u;
+                if (!tgt) A.TP[(row0 + r) * 16 + c] = th;
+            }
+        }
+    }
+    __syncthreads();
+    // critic on (x, pi(x))
+    slab_trunk(xin, lc, net.wf + ca, net.canon + ca, H, bufA, bufB, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
+               tgt ? nullptr : A.CPh3, row0);
+    {
+        const float s = slab_head(bufA, SL_LD, H, net.wf + ca + lc.w4, scratch);
+        float *Q = tgt ? A.QT : A.QP;
+        if (tid < 256 && (tid & 15) == 0) Q[(row0 + (tid >> 4)) * 16] = s + net.canon[ca + lc.b4];
+    }
+}
+
+struct BwdSlabArgs {
+    SlabNetPtrs online;
+    NetLayout la, lc;
+    int H, ldx, act_off, act_dim, B, Mp;
+    float max_action, gamma, clip_ret, action_l2;
+    const float *QT, *QA, *QP, *R, *XP, *TP;
+    const float *CAh1, *CAh2, *CAh3, *APh1, *APh2, *APh3, *CPh1, *CPh2, *CPh3;
+    float *dQA;                       // [Mp][16] col 0 (for dW4 of the critic)
+    float *dA3, *dA2, *dA1;           // critic-loss dY of critic layers 3,2,1
+    float *dZ, *dK3, *dK2, *dK1;      // actor dY: head (16 wide), layers 3,2,1
+    float *part;                      // [3][nslab] partial sums: sum (y-q)^2, sum q_pi, sum u^2
+    AgentDevState *st;
+    AdamCfg adam;
+};
+
+// dY of the top hidden layer from a scalar-per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0)
+__device__ __forceinline__ void slab_head_bwd(const float *dq_rows /*LDS [16]*/, const float *__restrict__ w4row,
+                                              const float *__restrict__ h3, int H, float *lout) {
+    for (int f = threadIdx.x; f < SL_ROWS * H; f += SL_THREADS) {
+        const int r = f / H, c = f - r * H;
+        lout[r * SL_LD + c] = (h3[(size_t)r * H + c] > 0.f) ? dq_rows[r] * w4row[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bwd_slab(const BwdSlabArgs A) {
+    __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[SL_ROWS * SL_LD];
+    __shared__ float scratch[SL_WAVES * 256];
+    __shared__ float dq[SL_ROWS];
+    __shared__ __attribute__((aligned(16))) float dz[SL_ROWS * 20];
+    const int slab = blockIdx.x, chain = blockIdx.y, nslab = gridDim.x;
+    const size_t row0 = (size_t)slab * SL_ROWS;
+    const int tid = threadIdx.x, H = A.H;
+    const NetLayout &la = A.la, &lc = A.lc;
+    const int ca = la.total;
+    const float invB = 1.0f / (float)A.B;
+    if (slab == 0 && chain == 0 && tid == 0) {  // bookkeeping for the optimizer step that follows
+        A.st->step += 1;
+        adam_prepare(A.st, A.adam);
+    }
+    if (chain == 0) {
+        // ---- critic loss: y = clamp(r + gamma q', -1/(1-gamma), 0); L = mean((y - q)^2)   (ddpg_agent.py:255-263)
+        if (tid < SL_ROWS) {
+            const size_t m = row0 + tid;
+            float g = 0.f, sq = 0.f;
+            if ((int)m < A.B) {
+                float y = A.R[m] + A.gamma * A.QT[m * 16];
+                y = fminf(fmaxf(y, -A.clip_ret), 0.f);
+                const float d = y - A.QA[m * 16];
+                sq = d * d;
+                g = -2.f * d * invB;
+            }
+            dq[tid] = g;
+            A.dQA[m * 16] = g;
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_down(sq, o, 16);
+            if (tid == 0) A.part[slab] = sq;
+        }
+        __syncthreads();
+        slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CAh3 + row0 * H, H, bufA);
+        __syncthreads();
+        slab_store(bufA, SL_LD, H, A.dA3 + row0 * H, H);
+        slab_layer(bufA, SL_LD, H, A.online.wd + ca + lc.w3, H >> 4, SE_MASK, A.CAh2 + row0 * H, H, bufB, SL_LD);
+        __syncthreads();
+        slab_store(bufB, SL_LD, H, A.dA2 + row0 * H, H);
+        slab_layer(bufB, SL_LD, H, A.online.wd + ca + lc.w2, H >> 4, SE_MASK, A.CAh1 + row0 * H, H, bufA, SL_LD);
+        __syncthreads();
+        slab_store(bufA, SL_LD, H, A.dA1 + row0 * H, H);
+        return;
+    }
+    // ---- actor loss: L = -mean(Q(x, pi(x))) + action_l2 * mean((pi/max_action)^2)   (ddpg_agent.py:265-267)
+    if (tid < SL_ROWS) {
+        const size_t m = row0 + tid;
+        const bool live = (int)m < A.B;
+        dq[tid] = live ? -invB : 0.f;
+        float sq = live ? A.QP[m * 16] : 0.f, su = 0.f;
+        if (live)
+            for (int j = 0; j < A.act_dim; ++j) {
+                const float u = A.XP[m * A.ldx + A.act_off + j];
+                su += u * u;
+            }
+        for (int o = 8; o > 0; o >>= 1) {
+            sq += __shfl_down(sq, o, 16);
+            su += __shfl_down(su, o, 16);
+        }
+        if (tid == 0) {
+            A.part[nslab + slab] = sq;
+            A.part[2 * nslab + slab] = su;
+        }
+    }
+    __syncthreads();
+    slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CPh3 + row0 * H, H, bufA);
+    __syncthreads();
+    slab_layer(bufA, SL_LD, H, A.online.wd + ca + lc.w3, H >> 4, SE_MASK, A.CPh2 + row0 * H, H, bufB, SL_LD);
+    __syncthreads();
+    slab_layer(bufB, SL_LD, H, A.online.wd + ca + lc.w2, H >> 4, SE_MASK, A.CPh1 + row0 * H, H, bufA, SL_LD);
+    __syncthreads();
+    {
+        // dL/d(input) of the critic, action block only: fragment kf = act_off/16 of the dX copy of W1
+        const int nSred = H >> 4;
+        const float s = slab_head(bufA, SL_LD, H, A.online.wd + ca + lc.w1 + (size_t)(A.act_off >> 4) * nSred * 256, scratch);
+        if (tid < 256) {
+            const int r = tid >> 4, c = tid & 15;
+            float v = 0.f;
+            const size_t m = row0 + r;
+            if (c < A.act_dim && (int)m < A.B) {
+                const float u = A.XP[m * A.ldx + A.act_off + c];
+                const float th = A.TP[m * 16 + c];
+                const float gu = A.action_l2 * (2.f * u / (float)(A.B * A.act_dim)) + s;
+                const float gt = (gu / A.max_action) * A.max_action;
+                v = gt * (1.f - th * th);
+            }
+            dz[r * 20 + c] = v;
+            A.dZ[m * 16 + c] = v;
+        }
+    }
+    __syncthreads();
+    // actor layer 4 backward: reduction over the 16 (padded) head outputs -> one super-step
+    slab_layer(dz, 20, 16, A.online.wd + la.w4, H >> 4, SE_MASK, A.APh3 + row0 * H, H, bufB, SL_LD);
+    __syncthreads();
+    slab_store(bufB, SL_LD, H, A.dK3 + row0 * H, H);
+    slab_layer(bufB, SL_LD, H, A.online.wd + la.w3, H >> 4, SE_MASK, A.APh2 + row0 * H, H, bufA, SL_LD);
+    __syncthreads();
+    slab_store(bufA, SL_LD, H, A.dK2 + row0 * H, H);
+    slab_layer(bufA, SL_LD, H, A.online.wd + la.w2, H >> 4, SE_MASK, A.APh1 + row0 * H, H, bufB, SL_LD);
+    __syncthreads();
+    slab_store(bufB, SL_LD, H, A.dK1 + row0 * H, H);
+}
