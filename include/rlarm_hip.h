@@ -206,6 +206,9 @@ int hp_agent_train_cycle(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm 
  * hipGraph (kind: 0 loss, 1 actor head, 2 forward hidden level, 3 forward first level, 4 q heads,
  * 5 backward hidden level, 6 adam, 8 polyak) -- the per-stage numbers quoted in DESIGN.md */
 int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_launch);
+/* diagnostic: stage-boundary time stamps (100 MHz ticks) of the slab kernels; only a build with
+ * -DSLAB_TIMELINE writes them (tools/ubench/), a production build returns zeros */
+int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);
 int hp_agent_profile(hp_agent *ag, int32_t enable);
 int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
 

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
                                        f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
+    "hp_agent_debug_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "hp_agent_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_profile_read": (C.c_int, [C.c_void_p, f64p, C.c_int32]),
     "hp_agent_destroy": (None, [C.c_void_p]),
@@ -111,7 +112,7 @@ def load(path: str | None = None):
     with _lock:
         if _lib is not None:
             return _lib
-        p = path or LIB_PATH
+        p = path or os.environ.get("RLARM_LIB") or LIB_PATH    # RLARM_LIB: A/B builds of the same ABI
         if not os.path.exists(p):
             raise HpError(
                 f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

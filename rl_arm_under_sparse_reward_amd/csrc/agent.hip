@@ -111,6 +111,7 @@ struct hp_agent {
     AgentDevState *d_state = nullptr;
     // row-slab engine: fragment-ordered weight copies (online forward / online dX / target forward), loss partials
     float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
+    unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;
     DevBuf plan, norm_plan;
     int plan_batches = 0;
@@ -784,6 +785,7 @@ static int enqueue_forward_backward_slab(hp_agent *a) {
     {
         ProfScope ps(a, PROF_GEMM_FWD);
         FwdSlabArgs A;
+        A.tl = a->timeline;
         A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
         A.target = SlabNetPtrs{a->fragFT, nullptr, a->targets};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim; A.Mp = Mp;
@@ -799,6 +801,7 @@ static int enqueue_forward_backward_slab(hp_agent *a) {
     {
         ProfScope ps(a, PROF_GEMM_BWD);
         BwdSlabArgs A;
+        A.tl = a->timeline + 96;
         A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim;
         A.B = a->B; A.Mp = Mp;
@@ -1007,6 +1010,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
+    if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
     if (st == HP_OK && hipEventCreate(&a->ev0) != hipSuccess) st = HP_ERR_HIP;
     if (st == HP_OK && hipEventCreate(&a->ev1) != hipSuccess) st = HP_ERR_HIP;
     if (st == HP_OK) st = ensure_plan(a, 1);
@@ -1335,6 +1339,15 @@ int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_la
     *us_per_launch = 1e3 * ms / n;
     (void)hipGraphExecDestroy(ge);
     (void)hipGraphDestroy(g);
+    return HP_OK;
+}
+
+// diagnostic: stage-boundary time stamps (100 MHz ticks) written by a -DSLAB_TIMELINE build of the slab
+// kernels: out[chain * 32 + k] for the forward kernel, out[96 + chain * 32 + k] for the backward kernel
+int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
+    HP_REQUIRE(a && out192, HP_ERR_INVALID, "hp_agent_debug_timeline: bad argument");
+    HP_CHECK_HIP(hipMemcpyAsync(out192, a->timeline, 192 * 8, hipMemcpyDeviceToHost, a->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
     return HP_OK;
 }
 

@@ -26,11 +26,24 @@
 // floats, one ds_read_b128 per lane per super-step (conflict free, see gemm_lds.h).
 #pragma once
 
-#define SL_THREADS 512
-#define SL_WAVES 8
+#ifndef SL_WAVES
+#define SL_WAVES 8         // wavefronts per slab workgroup: 8 -> two output fragments per wave, 256-VGPR budget
+#endif
+#define SL_THREADS (64 * SL_WAVES)
+#define SL_FR (16 / SL_WAVES)   // output fragments per wave in a 256-wide layer (1 or 2)
 #define SL_ROWS 16
 #define SL_LD 260  // LDS row stride of a 256-wide activation slab (floats)
 #define SL_LDX 52  // LDS row stride of the 48-wide network-input slab
+
+// Workgroup barrier that does NOT drain outstanding global loads.  __syncthreads() makes hipcc emit
+// s_waitcnt vmcnt(0) first, which would stall on the weight prefetch of the NEXT layer at every layer
+// boundary; LDS traffic only needs lgkmcnt(0) (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void slab_sync() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 __host__ __device__ __forceinline__ int frag_fwd_index(int n, int k, int K) {
     return (((n >> 4) * (K >> 4) + (k >> 4)) << 8) + (((n & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3);
@@ -80,6 +93,13 @@ __global__ void k_relayout(const float *__restrict__ canon, float *fragF, float 
 enum { SE_BIAS_RELU = 0, SE_MASK = 1 };
 
 __device__ __forceinline__ void slab_mma8(f32x4 &c0, f32x4 &c1, const float4 a, const float4 b0, const float4 b1) {
+#ifdef SLAB_ABLATE_MFMA   // ablation build: keep every operand live, skip the matrix pipe
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x),
+                 "v"(b1.y), "v"(b1.z), "v"(b1.w));
+    c0[0] += a.x;
+    c1[0] += b0.x + b1.x;
+    return;
+#endif
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, c0, 0, 0, 0);
@@ -127,8 +147,7 @@ __device__ __forceinline__ void slab_layer(const float *lin, int ld_in, int K, c
         const float4 *w1 = reinterpret_cast<const float4 *>(wf) + (size_t)(two ? nf1 : nf0) * nS * 64 + lane;
         f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
         const float *ap = lin + i * ld_in + 4 * q;
-        switch (nS) {   // compile-time trip counts: every weight load of the layer is in flight before the first MFMA
-            case 16: slab_mma<16>(c0, c1, w0, w1, ap); break;
+        switch (nS) {   // small layers only (K = 16 / 32 / 48); the 256-wide ones go through big_layer
             case 3: slab_mma<3>(c0, c1, w0, w1, ap); break;
             case 2: slab_mma<2>(c0, c1, w0, w1, ap); break;
             case 1: slab_mma<1>(c0, c1, w0, w1, ap); break;
@@ -160,6 +179,116 @@ __device__ __forceinline__ void slab_layer(const float *lin, int ld_in, int K, c
     }
 }
 
+// ---- software-pipelined 256 -> 256 layer ---------------------------------------------------------
+// A wavefront needs 32 KiB of weights per layer (2 fragments x 16 super-steps x 1 KiB).  They are
+// fetched as two halves of 8 super-steps (64 VGPRs each): while the MFMAs of one half run (2048
+// cycles), the other half -- possibly the first half of the NEXT layer, whose weights do not depend
+// on this layer's result -- is in flight, so the L2 / cold-miss latency is paid once per chain.
+struct WHalf {
+    float4 b[SL_FR][8];
+};
+
+__device__ __forceinline__ const float4 *wave_wptr(const float *wlayer, int f) {
+    // the wave index is uniform: say so, and the block base stays in SGPRs (32-bit lane offset only)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    return reinterpret_cast<const float4 *>(wlayer) + (size_t)(wave + f * SL_WAVES) * 16 * 64 + lane;
+}
+
+__device__ __forceinline__ void whalf_load(WHalf &h, const float *wlayer, int Sbase) {
+#ifdef SLAB_ABLATE_LOAD   // ablation build: no weight traffic
+    const float4 z = make_float4((float)Sbase, 1.f, 2.f, (float)threadIdx.x);
+#pragma unroll
+    for (int f = 0; f < SL_FR; ++f)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h.b[f][j] = z;
+    return;
+#endif
+#pragma unroll
+    for (int f = 0; f < SL_FR; ++f) {
+        const float4 *w = wave_wptr(wlayer, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#ifdef SLAB_NT_WEIGHTS
+            {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(&w[(Sbase + j) * 64]));
+                h.b[f][j] = make_float4(t.x, t.y, t.z, t.w);
+            }
+#else
+            h.b[f][j] = w[(Sbase + j) * 64];
+#endif
+        }
+    }
+}
+
+__device__ __forceinline__ void mma4(f32x4 &c, const float4 a, const float4 b) {
+#ifdef SLAB_ABLATE_MFMA
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+    c[0] += a.x + b.x;
+    return;
+#endif
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void whalf_mma(f32x4 (&c)[SL_FR], const WHalf &h, const float *ap, int Sbase) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * (Sbase + j));
+#if SL_FR == 2
+        // interleave the two accumulators (dependent-accumulator latency 40 cycles > 32-cycle issue)
+        slab_mma8(c[0], c[1], a, h.b[0][j], h.b[1][j]);
+#else
+        mma4(c[0], a, h.b[0][j]);
+#endif
+    }
+}
+
+// out[16][256] = epi(in[16][256] . W) with a THREE-buffer weight pipeline (prefetch distance = one whole
+// layer: measured, a half-layer burst of 128 KiB needs ~2.3 us to land while half a layer of MFMAs is
+// only ~1.7 us, so a two-buffer scheme stalls ~0.9 us per half):
+//   on entry   ha, hb hold super-steps 0..7 / 8..15 of THIS layer (in flight or landed), hc is free
+//   during     hc <- first half of `nxt`, then (once ha is consumed) ha <- second half of `nxt`
+//   on exit    the next layer's (first, second, free) buffers are (hc, ha, hb): the caller rotates.
+__device__ __forceinline__ void big_layer(const float *lin, int ld_in, WHalf &ha, WHalf &hb, WHalf &hc,
+                                          const float *__restrict__ nxt, int epi, const float *__restrict__ aux,
+                                          int ldaux, float *lout, int ld_out) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    float e[SL_FR][4];
+#pragma unroll
+    for (int f = 0; f < SL_FR; ++f) {   // epilogue operands first: older than the prefetch, ready by the end
+        const int col = 16 * (wave + f * SL_WAVES) + i;
+        if (epi == SE_BIAS_RELU) {
+            e[f][0] = aux[col];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[f][r] = aux[(size_t)(4 * q + r) * ldaux + col];
+        }
+    }
+    if (nxt) whalf_load(hc, nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 c[SL_FR];
+#pragma unroll
+    for (int f = 0; f < SL_FR; ++f) c[f] = f32x4{0, 0, 0, 0};
+    const float *ap = lin + i * ld_in + 4 * q;
+    whalf_mma(c, ha, ap, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt) whalf_load(ha, nxt, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    whalf_mma(c, hb, ap, 8);
+#pragma unroll
+    for (int f = 0; f < SL_FR; ++f) {
+        const int col = 16 * (wave + f * SL_WAVES) + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = (epi == SE_BIAS_RELU) ? fmaxf(c[f][r] + e[f][0], 0.f) : ((e[f][r] > 0.f) ? c[f][r] : 0.f);
+            lout[(4 * q + r) * ld_out + col] = v;
+        }
+    }
+}
+
 // 16-output head on a 16-row slab: the 8 wavefronts split the reduction, partials meet in LDS.
 // Returns (to threads 0..255: row = tid >> 4, col = tid & 15) the raw sum; caller adds bias etc.
 __device__ __forceinline__ float slab_head(const float *lin, int ld_in, int K, const float *__restrict__ wf,
@@ -179,7 +308,7 @@ __device__ __forceinline__ float slab_head(const float *lin, int ld_in, int K, c
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * q + r) * 16 + i] = c0[r];
-    __syncthreads();
+    slab_sync();
     float s = 0.f;
     if (tid < 256) {
 #pragma unroll
@@ -211,7 +340,14 @@ struct SlabNetPtrs {
     const float *canon;  // canonical arena (biases, head rows)
 };
 
+#ifdef SLAB_TIMELINE   // debug build: wave 0 of slab 0 stamps the 100 MHz wall clock at stage boundaries
+#define SLAB_STAMP(tl, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) (tl)[blockIdx.y * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define SLAB_STAMP(tl, k) do { } while (0)
+#endif
+
 struct FwdSlabArgs {
+    unsigned long long *tl;
     SlabNetPtrs online, target;   // arenas: [actor | critic]
     NetLayout la, lc;
     int H, ldx, act_off, act_dim, Mp;
@@ -223,22 +359,30 @@ struct FwdSlabArgs {
     float *QT, *QA, *QP;          // [Mp][16], column 0
 };
 
-// trunk of one network on the slab: xin (K1 wide) -> h1 -> h2 -> h3, optionally keeping copies in global
+// trunk of one network on the slab: xin (K1 wide) -> h1 -> h2 -> h3, optionally keeping copies in global.
+// On entry (p0, p1) hold / are fetching both halves of this net's layer-2 weights and p2 is free; on exit
+// (p1, p2) hold both halves of `nxt` (the next 256x256 layer of the chain) and p0 is free -- when nxt == nullptr
+// nothing is in flight.
 __device__ __forceinline__ void slab_trunk(const float *xin, const NetLayout &l, const float *wf, const float *canon,
                                            int H, float *bufA, float *bufB, float *g1, float *g2, float *g3,
-                                           size_t row0) {
+                                           size_t row0, WHalf &p0, WHalf &p1, WHalf &p2, const float *nxt,
+                                           unsigned long long *tl, int tbase) {
+    SLAB_STAMP(tl, tbase);
     slab_layer(xin, SL_LDX, l.K1, wf + l.w1, H >> 4, SE_BIAS_RELU, canon + l.b1, 0, bufA, SL_LD);
-    __syncthreads();
+    slab_sync();
+    SLAB_STAMP(tl, tbase + 1);
     if (g1) slab_store(bufA, SL_LD, H, g1 + row0 * H, H);
-    slab_layer(bufA, SL_LD, H, wf + l.w2, H >> 4, SE_BIAS_RELU, canon + l.b2, 0, bufB, SL_LD);
-    __syncthreads();
+    big_layer(bufA, SL_LD, p0, p1, p2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, bufB, SL_LD);   // layer 3 now in (p2, p0)
+    slab_sync();
+    SLAB_STAMP(tl, tbase + 2);
     if (g2) slab_store(bufB, SL_LD, H, g2 + row0 * H, H);
-    slab_layer(bufB, SL_LD, H, wf + l.w3, H >> 4, SE_BIAS_RELU, canon + l.b3, 0, bufA, SL_LD);
-    __syncthreads();
+    big_layer(bufB, SL_LD, p2, p0, p1, nxt, SE_BIAS_RELU, canon + l.b3, 0, bufA, SL_LD);         // nxt now in (p1, p2)
+    slab_sync();
+    SLAB_STAMP(tl, tbase + 3);
     if (g3) slab_store(bufA, SL_LD, H, g3 + row0 * H, H);
 }
 
-__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fwd_slab(const FwdSlabArgs A) {
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_WAVES / 4, SL_WAVES / 4))) void k_fwd_slab(const FwdSlabArgs A) {
     __shared__ __attribute__((aligned(16))) float xin[SL_ROWS * SL_LDX];
     __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
     __shared__ __attribute__((aligned(16))) float bufB[SL_ROWS * SL_LD];
@@ -247,25 +391,34 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const size_t row0 = (size_t)slab * SL_ROWS;
     const int tid = threadIdx.x;
     const int H = A.H;
+    SLAB_STAMP(A.tl, 0);
     const NetLayout &la = A.la, &lc = A.lc;
     const int ca = la.total;  // critic segment offset inside an arena
     if (chain == 1) {
         // critic(x, a)
-        slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
-        __syncthreads();
-        slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0);
+        WHalf h0, h1, h2;
+        slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);   // before the prefetch: vmcnt retires in order
+        whalf_load(h0, A.online.wf + ca + lc.w2, 0);
+        whalf_load(h1, A.online.wf + ca + lc.w2, 8);
+        slab_sync();
+        slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0, h0, h1,
+                   h2, nullptr, A.tl, 1);
         const float s = slab_head(bufA, SL_LD, H, A.online.wf + ca + lc.w4, scratch);
         if (tid < 256 && (tid & 15) == 0) A.QA[(row0 + (tid >> 4)) * 16] = s + A.online.canon[ca + lc.b4];
         return;
     }
+    WHalf h0, h1, h2;
     const bool tgt = (chain == 0);
     const SlabNetPtrs &net = tgt ? A.target : A.online;
     float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
     slab_load(xin, SL_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
-    __syncthreads();
-    // actor
+    whalf_load(h0, net.wf + la.w2, 0);
+    whalf_load(h1, net.wf + la.w2, 8);
+    slab_sync();
+    // actor (its last layer prefetches the critic's first 256x256 layer)
     slab_trunk(xin, la, net.wf, net.canon, H, bufA, bufB, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
-               tgt ? nullptr : A.APh3, row0);
+               tgt ? nullptr : A.APh3, row0, h0, h1, h2, net.wf + ca + lc.w2, A.tl, 1);   // critic layer 2 now in (h1, h2)
+    SLAB_STAMP(A.tl, 5);
     {
         const float s = slab_head(bufA, SL_LD, H, net.wf + la.w4, scratch);
         if (tid < 256) {
@@ -279,18 +432,21 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
     }
-    __syncthreads();
+    slab_sync();
+    SLAB_STAMP(A.tl, 7);
     // critic on (x, pi(x))
     slab_trunk(xin, lc, net.wf + ca, net.canon + ca, H, bufA, bufB, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
-               tgt ? nullptr : A.CPh3, row0);
+               tgt ? nullptr : A.CPh3, row0, h1, h2, h0, nullptr, A.tl, 8);
     {
         const float s = slab_head(bufA, SL_LD, H, net.wf + ca + lc.w4, scratch);
         float *Q = tgt ? A.QT : A.QP;
         if (tid < 256 && (tid & 15) == 0) Q[(row0 + (tid >> 4)) * 16] = s + net.canon[ca + lc.b4];
     }
+    SLAB_STAMP(A.tl, 13);
 }
 
 struct BwdSlabArgs {
+    unsigned long long *tl;
     SlabNetPtrs online;
     NetLayout la, lc;
     int H, ldx, act_off, act_dim, B, Mp;
@@ -314,7 +470,7 @@ __device__ __forceinline__ void slab_head_bwd(const float *dq_rows /*LDS [16]*/,
     }
 }
 
-__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bwd_slab(const BwdSlabArgs A) {
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_WAVES / 4, SL_WAVES / 4))) void k_bwd_slab(const BwdSlabArgs A) {
     __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
     __shared__ __attribute__((aligned(16))) float bufB[SL_ROWS * SL_LD];
     __shared__ float scratch[SL_WAVES * 256];
@@ -332,6 +488,9 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     if (chain == 0) {
         // ---- critic loss: y = clamp(r + gamma q', -1/(1-gamma), 0); L = mean((y - q)^2)   (ddpg_agent.py:255-263)
+        WHalf h0, h1, h2;   // declared per chain: shared live ranges across the branch made hipcc spill 130 VGPRs
+        whalf_load(h0, A.online.wd + ca + lc.w3, 0);
+        whalf_load(h1, A.online.wd + ca + lc.w3, 8);
         if (tid < SL_ROWS) {
             const size_t m = row0 + tid;
             float g = 0.f, sq = 0.f;
@@ -347,19 +506,22 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int o = 8; o > 0; o >>= 1) sq += __shfl_down(sq, o, 16);
             if (tid == 0) A.part[slab] = sq;
         }
-        __syncthreads();
+        slab_sync();
         slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CAh3 + row0 * H, H, bufA);
-        __syncthreads();
+        slab_sync();
         slab_store(bufA, SL_LD, H, A.dA3 + row0 * H, H);
-        slab_layer(bufA, SL_LD, H, A.online.wd + ca + lc.w3, H >> 4, SE_MASK, A.CAh2 + row0 * H, H, bufB, SL_LD);
-        __syncthreads();
+        big_layer(bufA, SL_LD, h0, h1, h2, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H, bufB, SL_LD);
+        slab_sync();
         slab_store(bufB, SL_LD, H, A.dA2 + row0 * H, H);
-        slab_layer(bufB, SL_LD, H, A.online.wd + ca + lc.w2, H >> 4, SE_MASK, A.CAh1 + row0 * H, H, bufA, SL_LD);
-        __syncthreads();
+        big_layer(bufB, SL_LD, h2, h0, h1, nullptr, SE_MASK, A.CAh1 + row0 * H, H, bufA, SL_LD);
+        slab_sync();
         slab_store(bufA, SL_LD, H, A.dA1 + row0 * H, H);
         return;
     }
     // ---- actor loss: L = -mean(Q(x, pi(x))) + action_l2 * mean((pi/max_action)^2)   (ddpg_agent.py:265-267)
+    WHalf h0, h1, h2;
+    whalf_load(h0, A.online.wd + ca + lc.w3, 0);
+    whalf_load(h1, A.online.wd + ca + lc.w3, 8);
     if (tid < SL_ROWS) {
         const size_t m = row0 + tid;
         const bool live = (int)m < A.B;
@@ -379,13 +541,14 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             A.part[2 * nslab + slab] = su;
         }
     }
-    __syncthreads();
+    slab_sync();
     slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CPh3 + row0 * H, H, bufA);
-    __syncthreads();
-    slab_layer(bufA, SL_LD, H, A.online.wd + ca + lc.w3, H >> 4, SE_MASK, A.CPh2 + row0 * H, H, bufB, SL_LD);
-    __syncthreads();
-    slab_layer(bufB, SL_LD, H, A.online.wd + ca + lc.w2, H >> 4, SE_MASK, A.CPh1 + row0 * H, H, bufA, SL_LD);
-    __syncthreads();
+    slab_sync();
+    big_layer(bufA, SL_LD, h0, h1, h2, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, bufB, SL_LD);
+    slab_sync();
+    // its second half prefetches the actor's layer-3 dX, which stays in flight across the small stages below
+    big_layer(bufB, SL_LD, h2, h0, h1, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, bufA, SL_LD);   // actor L3 in (h1, h2)
+    slab_sync();
     {
         // dL/d(input) of the critic, action block only: fragment kf = act_off/16 of the dX copy of W1
         const int nSred = H >> 4;
@@ -405,15 +568,15 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             A.dZ[m * 16 + c] = v;
         }
     }
-    __syncthreads();
+    slab_sync();
     // actor layer 4 backward: reduction over the 16 (padded) head outputs -> one super-step
     slab_layer(dz, 20, 16, A.online.wd + la.w4, H >> 4, SE_MASK, A.APh3 + row0 * H, H, bufB, SL_LD);
-    __syncthreads();
+    slab_sync();
     slab_store(bufB, SL_LD, H, A.dK3 + row0 * H, H);
-    slab_layer(bufB, SL_LD, H, A.online.wd + la.w3, H >> 4, SE_MASK, A.APh2 + row0 * H, H, bufA, SL_LD);
-    __syncthreads();
+    big_layer(bufB, SL_LD, h1, h2, h0, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, bufA, SL_LD);   // actor L2 in (h0, h1)
+    slab_sync();
     slab_store(bufA, SL_LD, H, A.dK2 + row0 * H, H);
-    slab_layer(bufA, SL_LD, H, A.online.wd + la.w2, H >> 4, SE_MASK, A.APh1 + row0 * H, H, bufB, SL_LD);
-    __syncthreads();
+    big_layer(bufA, SL_LD, h0, h1, h2, nullptr, SE_MASK, A.APh1 + row0 * H, H, bufB, SL_LD);
+    slab_sync();
     slab_store(bufB, SL_LD, H, A.dK1 + row0 * H, H);
 }

@@ -55,6 +55,11 @@ for nb in (40,):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     print(f"n_batches={nb}: {1e6*dt/(reps*nb):.1f} us/step  ({1e6*dt/reps:.0f} us/cycle)")
+tl = (C.c_uint64 * 192)(); _lib.check(lib.hp_agent_debug_timeline(h, tl))
+for ch, nm in ((0, "fwd T"), (1, "fwd A"), (2, "fwd P")):
+    v = [tl[ch * 32 + k] for k in range(16)]
+    if v[0]:
+        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(16) if v[k]))
 floor("after cycles")
 # eager path
 _lib.check(lib.hp_agent_sample_and_update(h, buf.h, on.h, gn.h, rng.h, 0.8, squared_threshold(0.05), 40)); ctx.synchronize()
