@@ -140,10 +140,10 @@ def profile_kernels(r: Runner, cycles=3):
         r.cycle += 1
         steps += N_BATCHES
     r.sync()
-    out = (C.c_double * 12)()
-    _lib.check(ag.lib.hp_agent_profile_read(ag.h, out, 12))
+    out = (C.c_double * 14)()
+    _lib.check(ag.lib.hp_agent_profile_read(ag.h, out, 14))
     _lib.check(ag.lib.hp_agent_profile(ag.h, 0))
-    names = ("sample", "gemm_fwd", "gemm_bwd", "loss_head", "adam_polyak", "index_plan")
+    names = ("sample", "forward", "backward_dx", "loss_head", "adam_polyak", "index_plan", "weight_grad")
     prof = {}
     for i, nm in enumerate(names):
         ms, cnt = out[2 * i], out[2 * i + 1]
@@ -260,19 +260,31 @@ def main():
                    "final_losses": [float(losses[0]), float(losses[1])]},
     }
     if prof:
-        gemm_ms = prof["gemm_fwd"]["ms_per_step"] + prof["gemm_bwd"]["ms_per_step"]
-        gemm_launches = prof["gemm_fwd"]["launches_per_step"] + prof["gemm_bwd"]["launches_per_step"]
-        flops_step = FLOP_PER_TRANSITION * a.batch
-        achieved = flops_step / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "k_gemm_group (grouped FP32 v_mfma_f32_16x16x4_f32, all 16 launches of a step)",
-            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
-            "flop_per_launch": round(flops_step / gemm_launches, 1) if gemm_launches else None,
-            "avg_launch_us": round(1e3 * gemm_ms / gemm_launches, 3) if gemm_launches else None,
-            "note": "launch/dependency-latency bound at batch 256: 0.71 GFLOP per step over 16 dependent grouped "
-                    "launches; durations from HIP events around each eager launch",
-        }
+        # algorithmic MACs per transition (minimal algorithm): 5 forward passes 699,648;
+        # backward 683,264 = 395,776 (dX chains) + 287,488 (weight gradients)
+        macs = {"forward": 699_648, "backward_dx": 395_776, "weight_grad": 287_488}
+        kern = {"forward": "k_fwd_slab", "backward_dx": "k_bwd_slab", "weight_grad": "k_gemm_lds (8 dW problems)"}
+        per = {}
+        for k, m in macs.items():
+            ms = prof[k]["ms_per_step"]
+            n = prof[k]["launches_per_step"]
+            if ms > 0 and n > 0:
+                tf = 2.0 * m * a.batch / (ms * 1e-3) / 1e12
+                per[k] = {"kernel": kern[k], "avg_launch_us": round(1e3 * ms / n, 3), "launches_per_step": round(n, 2),
+                          "flop_per_launch": round(2.0 * m * a.batch / n, 1), "achieved_tflops": round(tf, 3),
+                          "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5)}
+        dom = max(per, key=lambda k: prof[k]["ms_per_step"]) if per else None
+        if dom:
+            out["roofline"] = {
+                "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": None,
+                "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
+                "note": "dominant kernel by time; FP32 v_mfma_f32_16x16x4_f32.  At batch 256 only 16 slabs x 2-3 chains "
+                        "(32-48 of 256 CUs) have work and each workgroup is bound by streaming the layer weights "
+                        "through its CU (~38 GB/s per CU measured, tools/ubench/stream_bw.hip), not by the matrix pipe; "
+                        "durations are HIP-event pairs around each eager launch on the launch stream",
+                "all_matrix_kernels": per,
+            }
         s_ms = prof["sample"]["ms_per_step"]
         s_gbps = SAMPLE_BYTES_PER_TRANSITION * a.batch / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
         out["roofline_sample_kernel"] = {"bound": "hbm", "kernel": "k_gather_fused", "achieved": round(s_gbps, 2),

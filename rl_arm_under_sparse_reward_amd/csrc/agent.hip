@@ -91,7 +91,7 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 
 #include "slab.h"
 
-enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_N = 6 };
+enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
 struct hp_agent {
     hp_ctx *ctx = nullptr;
@@ -828,7 +828,7 @@ static int enqueue_forward_backward_slab(hp_agent *a) {
         add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
         add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
         add_dw(L, a->dK1, H, H, a->XP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
-        HP_TRY(launch_group(a, L, PROF_GEMM_BWD));
+        HP_TRY(launch_group(a, L, PROF_DW));
     }
     return HP_OK;
 }
@@ -1361,7 +1361,8 @@ int hp_agent_profile(hp_agent *a, int32_t enable) {
     return HP_OK;
 }
 
-// out[2*k] = total ms, out[2*k+1] = launches, k = sample, gemm_fwd, gemm_bwd, loss(+head), adam(+polyak), plan
+// out[2*k] = total ms, out[2*k+1] = launches, k = sample, forward, backward(dX), loss(+head, layer engine),
+// adam(+polyak), index plan, weight-gradient GEMM (slab engine)
 int hp_agent_profile_read(hp_agent *a, double *ms_out, int32_t n) {
     HP_REQUIRE(a && ms_out, HP_ERR_INVALID, "hp_agent_profile_read: null argument");
     for (int i = 0; i < PROF_N && 2 * i + 1 < n; ++i) {

@@ -115,7 +115,7 @@ class ddpg_agent:
         return m, v, step.value
 
     def _broadcast_params(self, comm):
-        if comm.world_size == 1:
+        if not comm.active:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_param_buffer(self.h, C.byref(p), C.byref(n)))
@@ -123,7 +123,7 @@ class ddpg_agent:
         comm.broadcast_device(p.value, n.value, 0)
 
     def _allreduce_grads(self, comm):
-        if comm.world_size == 1:
+        if not comm.active:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_grad_buffer(self.h, C.byref(p), C.byref(n)))
@@ -144,7 +144,7 @@ class ddpg_agent:
     def _update_network(self, n_updates=1):
         """ddpg_agent.py:225-277, `n_updates` times back to back (the reference's inner loop :145-147)."""
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
-        if self.comm.world_size == 1:
+        if not self.comm.active:
             _lib.check(self.lib.hp_agent_sample_and_update(*self._handles(), fp, sq, int(n_updates)))
             return
         for _ in range(int(n_updates)):          # data-parallel ranks: grads are SUMmed between backward and Adam
@@ -197,7 +197,7 @@ class ddpg_agent:
         """ddpg_agent.py:143-150 as one hipGraph: store_episode, _update_normalizer, n_batches x
         _update_network, soft update of both targets.  Asynchronous; single rank only."""
         n_batches = int(n_batches or self.args.n_batches)
-        if self.comm.world_size != 1:
+        if self.comm.active:
             self.buffer.store_episode(episode_batch)
             self._update_normalizer(episode_batch)
             self._update_network(n_batches)

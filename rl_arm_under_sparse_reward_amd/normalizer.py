@@ -47,7 +47,7 @@ class normalizer:
         _lib.check(self.lib.hp_norm_update(self.h, _lib.ptr(v, C.c_double), v.shape[0]))
 
     def recompute_stats(self):
-        if self.comm is None or self.comm.world_size == 1:
+        if self.comm is None or not self.comm.active:
             _lib.check(self.lib.hp_norm_recompute(self.h))
             return
         p, n = C.c_void_p(), C.c_int64()

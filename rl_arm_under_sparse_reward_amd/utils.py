@@ -19,11 +19,17 @@ from . import _lib
 class Communicator:
     """Thin view of the default torch.distributed process group (or a single rank)."""
 
-    def __init__(self, device_id=None):
+    def __init__(self, device_id=None, force=False):
         import torch.distributed as dist
 
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.device_id = device_id
+        self.force = bool(force) and self._dist is not None   # run the collectives even in a 1-rank group (tests)
+
+    @property
+    def active(self):
+        """True when the data-parallel exchange steps must run (more than one rank, or forced)."""
+        return self.world_size > 1 or self.force
 
     @property
     def world_size(self):
@@ -57,15 +63,15 @@ class Communicator:
         return torch.as_tensor(_lib.DevicePointer(address, n), device=f"cuda:{dev}")
 
     def allreduce_sum_device(self, address, n):
-        if self.world_size > 1:
+        if self.active:
             self.allreduce_sum_(self._view(address, n))
 
     def allreduce_mean_device(self, address, n):
-        if self.world_size > 1:
+        if self.active:
             self.allreduce_mean_(self._view(address, n))
 
     def broadcast_device(self, address, n, root=0):
-        if self.world_size > 1:
+        if self.active:
             self.broadcast_(self._view(address, n), root)
 
 
