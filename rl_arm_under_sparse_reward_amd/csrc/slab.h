@@ -179,14 +179,19 @@ __device__ __forceinline__ void slab_layer(const float *lin, int ld_in, int K, c
     }
 }
 
-// ---- software-pipelined 256 -> 256 layer ---------------------------------------------------------
-// A wavefront needs 32 KiB of weights per layer (2 fragments x 16 super-steps x 1 KiB).  They are
-// fetched as two halves of 8 super-steps (64 VGPRs each): while the MFMAs of one half run (2048
-// cycles), the other half -- possibly the first half of the NEXT layer, whose weights do not depend
-// on this layer's result -- is in flight, so the L2 / cold-miss latency is paid once per chain.
-struct WHalf {
-    float4 b[SL_FR][8];
-};
+// ---- 256 -> 256 layer fed by an LDS-DMA weight ring ----------------------------------------------
+// Measured (tools/ubench/stream_bw2.hip): a CU pulls only ~38 GB/s through global_load_dwordx4 -> VGPR, but
+// ~141 GB/s through LDS-DMA (global_load_lds_dwordx4).  A wavefront needs 32 KiB of weights per layer
+// (2 fragments x 16 super-steps x 1 KiB blocks, already lane-linear in the fragment-ordered copy, which is
+// exactly the image LDS-DMA writes: wave-uniform base + lane * 16).  Each wavefront owns a private ring of
+// SL_RING 1-KiB slots: block t lives in slot t % SL_RING, SL_RING blocks are always in flight, a block is
+// consumed with one ds_read_b128 per lane after a COUNTED s_waitcnt vmcnt (the DMA is ordered for the
+// issuing wave by vmcnt alone; the ring is wave-private, so no workgroup barrier is involved), and the freed
+// slot is refilled at once.  After the last block of a layer the first SL_RING blocks of the NEXT 256x256
+// layer of the chain are issued, so they fly during the epilogue, the barrier and any small stage in between.
+#define SL_RING 12
+#define SL_BLOCKS (16 * SL_FR)     // 1-KiB weight blocks a wavefront consumes per 256x256 layer
+typedef float4 RingSlot[64];
 
 __device__ __forceinline__ const float4 *wave_wptr(const float *wlayer, int f) {
     // the wave index is uniform: say so, and the block base stays in SGPRs (32-bit lane offset only)
@@ -194,31 +199,17 @@ __device__ __forceinline__ const float4 *wave_wptr(const float *wlayer, int f) {
     return reinterpret_cast<const float4 *>(wlayer) + (size_t)(wave + f * SL_WAVES) * 16 * 64 + lane;
 }
 
-__device__ __forceinline__ void whalf_load(WHalf &h, const float *wlayer, int Sbase) {
-#ifdef SLAB_ABLATE_LOAD   // ablation build: no weight traffic
-    const float4 z = make_float4((float)Sbase, 1.f, 2.f, (float)threadIdx.x);
-#pragma unroll
-    for (int f = 0; f < SL_FR; ++f)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h.b[f][j] = z;
-    return;
+// block t of a layer = (super-step S = t / SL_FR, fragment f = t % SL_FR)
+__device__ __forceinline__ void ring_issue(RingSlot *ring, const float *wlayer, int t) {
+#ifndef SLAB_ABLATE_LOAD
+    const float4 *src = wave_wptr(wlayer, t % SL_FR) + (t / SL_FR) * 64;
+    __builtin_amdgcn_global_load_lds(src, &ring[t % SL_RING][0], 16, 0, 0);
 #endif
+}
+
+__device__ __forceinline__ void ring_prologue(RingSlot *ring, const float *wlayer) {
 #pragma unroll
-    for (int f = 0; f < SL_FR; ++f) {
-        const float4 *w = wave_wptr(wlayer, f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#ifdef SLAB_NT_WEIGHTS
-            {
-                typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(&w[(Sbase + j) * 64]));
-                h.b[f][j] = make_float4(t.x, t.y, t.z, t.w);
-            }
-#else
-            h.b[f][j] = w[(Sbase + j) * 64];
-#endif
-        }
-    }
+    for (int t = 0; t < SL_RING; ++t) ring_issue(ring, wlayer, t);
 }
 
 __device__ __forceinline__ void mma4(f32x4 &c, const float4 a, const float4 b) {
@@ -233,32 +224,46 @@ __device__ __forceinline__ void mma4(f32x4 &c, const float4 a, const float4 b) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void whalf_mma(f32x4 (&c)[SL_FR], const WHalf &h, const float *ap, int Sbase) {
+template <int S>
+__device__ __forceinline__ void ring_step(f32x4 (&c)[SL_FR], RingSlot *ring, const float *wlayer, const float *ap) {
+    constexpr int t0 = S * SL_FR;                               // first block of this super-step
+    constexpr int left = SL_BLOCKS - t0;                        // blocks not yet consumed
+    constexpr int inflight = left < SL_RING ? left : SL_RING;   // of those, issued and possibly still flying
+    // vmcnt retires in order and the blocks needed now are the oldest outstanding operations
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight - SL_FR) : "memory");
+    const int lane = threadIdx.x & 63;
+    float4 b[SL_FR];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * (Sbase + j));
-#if SL_FR == 2
-        // interleave the two accumulators (dependent-accumulator latency 40 cycles > 32-cycle issue)
-        slab_mma8(c[0], c[1], a, h.b[0][j], h.b[1][j]);
+    for (int f = 0; f < SL_FR; ++f) {
+#ifdef SLAB_ABLATE_LOAD
+        b[f] = make_float4((float)S, 1.f, 2.f, (float)lane);
 #else
-        mma4(c[0], a, h.b[0][j]);
+        b[f] = ring[(t0 + f) % SL_RING][lane];
 #endif
     }
+    const float4 a = *reinterpret_cast<const float4 *>(ap + 16 * S);
+    if constexpr (t0 + SL_RING < SL_BLOCKS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot reads done before the DMA refills them
+#pragma unroll
+        for (int f = 0; f < SL_FR; ++f) ring_issue(ring, wlayer, t0 + SL_RING + f);
+    }
+#if SL_FR == 2
+    slab_mma8(c[0], c[1], a, b[0], b[1]);   // interleaved accumulators (dependent latency 40 > 32-cycle issue)
+#else
+    mma4(c[0], a, b[0]);
+#endif
+    if constexpr (S + 1 < 16) ring_step<S + 1>(c, ring, wlayer, ap);
 }
 
-// out[16][256] = epi(in[16][256] . W) with a THREE-buffer weight pipeline (prefetch distance = one whole
-// layer: measured, a half-layer burst of 128 KiB needs ~2.3 us to land while half a layer of MFMAs is
-// only ~1.7 us, so a two-buffer scheme stalls ~0.9 us per half):
-//   on entry   ha, hb hold super-steps 0..7 / 8..15 of THIS layer (in flight or landed), hc is free
-//   during     hc <- first half of `nxt`, then (once ha is consumed) ha <- second half of `nxt`
-//   on exit    the next layer's (first, second, free) buffers are (hc, ha, hb): the caller rotates.
-__device__ __forceinline__ void big_layer(const float *lin, int ld_in, WHalf &ha, WHalf &hb, WHalf &hc,
+// out[16][256] = epi(in[16][256] . W).  The first SL_RING blocks of `wlayer` must already be in flight
+// (ring_prologue or the previous big_layer's `nxt`); on return the first SL_RING blocks of `nxt` are.
+__device__ __forceinline__ void big_layer(const float *lin, int ld_in, RingSlot *ring, const float *__restrict__ wlayer,
                                           const float *__restrict__ nxt, int epi, const float *__restrict__ aux,
                                           int ldaux, float *lout, int ld_out) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
     float e[SL_FR][4];
 #pragma unroll
-    for (int f = 0; f < SL_FR; ++f) {   // epilogue operands first: older than the prefetch, ready by the end
+    for (int f = 0; f < SL_FR; ++f) {   // epilogue operands first: their latency hides behind the products
         const int col = 16 * (wave + f * SL_WAVES) + i;
         if (epi == SE_BIAS_RELU) {
             e[f][0] = aux[col];
@@ -267,17 +272,15 @@ __device__ __forceinline__ void big_layer(const float *lin, int ld_in, WHalf &ha
             for (int r = 0; r < 4; ++r) e[f][r] = aux[(size_t)(4 * q + r) * ldaux + col];
         }
     }
-    if (nxt) whalf_load(hc, nxt, 0);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 c[SL_FR];
 #pragma unroll
     for (int f = 0; f < SL_FR; ++f) c[f] = f32x4{0, 0, 0, 0};
     const float *ap = lin + i * ld_in + 4 * q;
-    whalf_mma(c, ha, ap, 0);
+    ring_step<0>(c, ring, wlayer, ap);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nxt) ring_prologue(ring, nxt);
     __builtin_amdgcn_sched_barrier(0);
-    if (nxt) whalf_load(ha, nxt, 8);
-    __builtin_amdgcn_sched_barrier(0);
-    whalf_mma(c, hb, ap, 8);
 #pragma unroll
     for (int f = 0; f < SL_FR; ++f) {
         const int col = 16 * (wave + f * SL_WAVES) + i;
@@ -360,23 +363,22 @@ struct FwdSlabArgs {
 };
 
 // trunk of one network on the slab: xin (K1 wide) -> h1 -> h2 -> h3, optionally keeping copies in global.
-// On entry (p0, p1) hold / are fetching both halves of this net's layer-2 weights and p2 is free; on exit
-// (p1, p2) hold both halves of `nxt` (the next 256x256 layer of the chain) and p0 is free -- when nxt == nullptr
-// nothing is in flight.
+// On entry the ring holds (in flight) the first blocks of this net's layer 2; on exit those of `nxt`
+// (the next 256x256 layer of the chain), or nothing when nxt == nullptr.
 __device__ __forceinline__ void slab_trunk(const float *xin, const NetLayout &l, const float *wf, const float *canon,
                                            int H, float *bufA, float *bufB, float *g1, float *g2, float *g3,
-                                           size_t row0, WHalf &p0, WHalf &p1, WHalf &p2, const float *nxt,
-                                           unsigned long long *tl, int tbase) {
+                                           size_t row0, RingSlot *ring, const float *nxt, unsigned long long *tl,
+                                           int tbase) {
     SLAB_STAMP(tl, tbase);
     slab_layer(xin, SL_LDX, l.K1, wf + l.w1, H >> 4, SE_BIAS_RELU, canon + l.b1, 0, bufA, SL_LD);
     slab_sync();
     SLAB_STAMP(tl, tbase + 1);
     if (g1) slab_store(bufA, SL_LD, H, g1 + row0 * H, H);
-    big_layer(bufA, SL_LD, p0, p1, p2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, bufB, SL_LD);   // layer 3 now in (p2, p0)
+    big_layer(bufA, SL_LD, ring, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, bufB, SL_LD);
     slab_sync();
     SLAB_STAMP(tl, tbase + 2);
     if (g2) slab_store(bufB, SL_LD, H, g2 + row0 * H, H);
-    big_layer(bufB, SL_LD, p2, p0, p1, nxt, SE_BIAS_RELU, canon + l.b3, 0, bufA, SL_LD);         // nxt now in (p1, p2)
+    big_layer(bufB, SL_LD, ring, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, bufA, SL_LD);
     slab_sync();
     SLAB_STAMP(tl, tbase + 3);
     if (g3) slab_store(bufA, SL_LD, H, g3 + row0 * H, H);
@@ -387,37 +389,35 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
     __shared__ __attribute__((aligned(16))) float bufB[SL_ROWS * SL_LD];
     __shared__ float scratch[SL_WAVES * 256];
+    __shared__ __attribute__((aligned(16))) RingSlot wring[SL_WAVES][SL_RING];
     const int slab = blockIdx.x, chain = blockIdx.y;
     const size_t row0 = (size_t)slab * SL_ROWS;
     const int tid = threadIdx.x;
     const int H = A.H;
+    RingSlot *ring = wring[__builtin_amdgcn_readfirstlane(tid >> 6)];
     SLAB_STAMP(A.tl, 0);
     const NetLayout &la = A.la, &lc = A.lc;
     const int ca = la.total;  // critic segment offset inside an arena
     if (chain == 1) {
         // critic(x, a)
-        WHalf h0, h1, h2;
         slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);   // before the prefetch: vmcnt retires in order
-        whalf_load(h0, A.online.wf + ca + lc.w2, 0);
-        whalf_load(h1, A.online.wf + ca + lc.w2, 8);
+        ring_prologue(ring, A.online.wf + ca + lc.w2);
         slab_sync();
-        slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0, h0, h1,
-                   h2, nullptr, A.tl, 1);
+        slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0, ring,
+                   nullptr, A.tl, 1);
         const float s = slab_head(bufA, SL_LD, H, A.online.wf + ca + lc.w4, scratch);
         if (tid < 256 && (tid & 15) == 0) A.QA[(row0 + (tid >> 4)) * 16] = s + A.online.canon[ca + lc.b4];
         return;
     }
-    WHalf h0, h1, h2;
     const bool tgt = (chain == 0);
     const SlabNetPtrs &net = tgt ? A.target : A.online;
     float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
     slab_load(xin, SL_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
-    whalf_load(h0, net.wf + la.w2, 0);
-    whalf_load(h1, net.wf + la.w2, 8);
+    ring_prologue(ring, net.wf + la.w2);
     slab_sync();
     // actor (its last layer prefetches the critic's first 256x256 layer)
     slab_trunk(xin, la, net.wf, net.canon, H, bufA, bufB, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
-               tgt ? nullptr : A.APh3, row0, h0, h1, h2, net.wf + ca + lc.w2, A.tl, 1);   // critic layer 2 now in (h1, h2)
+               tgt ? nullptr : A.APh3, row0, ring, net.wf + ca + lc.w2, A.tl, 1);   // critic layer 2 now in flight
     SLAB_STAMP(A.tl, 5);
     {
         const float s = slab_head(bufA, SL_LD, H, net.wf + la.w4, scratch);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     SLAB_STAMP(A.tl, 7);
     // critic on (x, pi(x))
     slab_trunk(xin, lc, net.wf + ca, net.canon + ca, H, bufA, bufB, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
-               tgt ? nullptr : A.CPh3, row0, h1, h2, h0, nullptr, A.tl, 8);
+               tgt ? nullptr : A.CPh3, row0, ring, nullptr, A.tl, 8);
     {
         const float s = slab_head(bufA, SL_LD, H, net.wf + ca + lc.w4, scratch);
         float *Q = tgt ? A.QT : A.QP;
@@ -476,21 +476,21 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     __shared__ float scratch[SL_WAVES * 256];
     __shared__ float dq[SL_ROWS];
     __shared__ __attribute__((aligned(16))) float dz[SL_ROWS * 20];
+    __shared__ __attribute__((aligned(16))) RingSlot wring[SL_WAVES][SL_RING];
     const int slab = blockIdx.x, chain = blockIdx.y, nslab = gridDim.x;
     const size_t row0 = (size_t)slab * SL_ROWS;
     const int tid = threadIdx.x, H = A.H;
     const NetLayout &la = A.la, &lc = A.lc;
     const int ca = la.total;
     const float invB = 1.0f / (float)A.B;
+    RingSlot *ring = wring[__builtin_amdgcn_readfirstlane(tid >> 6)];
     if (slab == 0 && chain == 0 && tid == 0) {  // bookkeeping for the optimizer step that follows
         A.st->step += 1;
         adam_prepare(A.st, A.adam);
     }
     if (chain == 0) {
         // ---- critic loss: y = clamp(r + gamma q', -1/(1-gamma), 0); L = mean((y - q)^2)   (ddpg_agent.py:255-263)
-        WHalf h0, h1, h2;   // declared per chain: shared live ranges across the branch made hipcc spill 130 VGPRs
-        whalf_load(h0, A.online.wd + ca + lc.w3, 0);
-        whalf_load(h1, A.online.wd + ca + lc.w3, 8);
+        ring_prologue(ring, A.online.wd + ca + lc.w3);
         if (tid < SL_ROWS) {
             const size_t m = row0 + tid;
             float g = 0.f, sq = 0.f;
@@ -510,18 +510,17 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
         slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CAh3 + row0 * H, H, bufA);
         slab_sync();
         slab_store(bufA, SL_LD, H, A.dA3 + row0 * H, H);
-        big_layer(bufA, SL_LD, h0, h1, h2, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H, bufB, SL_LD);
+        big_layer(bufA, SL_LD, ring, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H,
+                  bufB, SL_LD);
         slab_sync();
         slab_store(bufB, SL_LD, H, A.dA2 + row0 * H, H);
-        big_layer(bufB, SL_LD, h2, h0, h1, nullptr, SE_MASK, A.CAh1 + row0 * H, H, bufA, SL_LD);
+        big_layer(bufB, SL_LD, ring, A.online.wd + ca + lc.w2, nullptr, SE_MASK, A.CAh1 + row0 * H, H, bufA, SL_LD);
         slab_sync();
         slab_store(bufA, SL_LD, H, A.dA1 + row0 * H, H);
         return;
     }
     // ---- actor loss: L = -mean(Q(x, pi(x))) + action_l2 * mean((pi/max_action)^2)   (ddpg_agent.py:265-267)
-    WHalf h0, h1, h2;
-    whalf_load(h0, A.online.wd + ca + lc.w3, 0);
-    whalf_load(h1, A.online.wd + ca + lc.w3, 8);
+    ring_prologue(ring, A.online.wd + ca + lc.w3);
     if (tid < SL_ROWS) {
         const size_t m = row0 + tid;
         const bool live = (int)m < A.B;
@@ -544,10 +543,13 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     slab_sync();
     slab_head_bwd(dq, A.online.canon + ca + lc.w4, A.CPh3 + row0 * H, H, bufA);
     slab_sync();
-    big_layer(bufA, SL_LD, h0, h1, h2, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, bufB, SL_LD);
+    big_layer(bufA, SL_LD, ring, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, bufB,
+              SL_LD);
     slab_sync();
     // its second half prefetches the actor's layer-3 dX, which stays in flight across the small stages below
-    big_layer(bufB, SL_LD, h2, h0, h1, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, bufA, SL_LD);   // actor L3 in (h1, h2)
+    // its tail issues the actor's layer-3 dX blocks, which stay in flight across the small stages below
+    big_layer(bufB, SL_LD, ring, A.online.wd + ca + lc.w2, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, bufA,
+              SL_LD);
     slab_sync();
     {
         // dL/d(input) of the critic, action block only: fragment kf = act_off/16 of the dX copy of W1
@@ -573,10 +575,10 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     slab_layer(dz, 20, 16, A.online.wd + la.w4, H >> 4, SE_MASK, A.APh3 + row0 * H, H, bufB, SL_LD);
     slab_sync();
     slab_store(bufB, SL_LD, H, A.dK3 + row0 * H, H);
-    big_layer(bufB, SL_LD, h1, h2, h0, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, bufA, SL_LD);   // actor L2 in (h0, h1)
+    big_layer(bufB, SL_LD, ring, A.online.wd + la.w3, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, bufA, SL_LD);
     slab_sync();
     slab_store(bufA, SL_LD, H, A.dK2 + row0 * H, H);
-    big_layer(bufA, SL_LD, h0, h1, h2, nullptr, SE_MASK, A.APh1 + row0 * H, H, bufB, SL_LD);
+    big_layer(bufA, SL_LD, ring, A.online.wd + la.w2, nullptr, SE_MASK, A.APh1 + row0 * H, H, bufB, SL_LD);
     slab_sync();
     slab_store(bufB, SL_LD, H, A.dK1 + row0 * H, H);
 }
