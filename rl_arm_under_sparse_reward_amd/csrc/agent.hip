@@ -446,18 +446,28 @@ __global__ __launch_bounds__(256) void k_adam_frag(float *__restrict__ p, const 
                                                    const float *__restrict__ part, int nslab, int B, int act_dim,
                                                    float action_l2, float *loss_log) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) {  // mean over slabs in slab order: deterministic
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic);
+        // a single thread walking the partials serialised ~16 cold loads behind the whole kernel
+        const int lane = threadIdx.x;
         float tc = 0.f, tq = 0.f, tl = 0.f;
-        for (int s = 0; s < nslab; ++s) {
+        for (int s = lane; s < nslab; s += 64) {
             tc += part[s];
             tq += part[nslab + s];
             tl += part[2 * nslab + s];
         }
-        const float invB = 1.0f / (float)B;
-        const long long k = st->n_logged;
-        loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + action_l2 * (tl / (float)(B * act_dim));
-        loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
-        st->n_logged = k + 1;
+        for (int o = 32; o > 0; o >>= 1) {
+            tc += __shfl_down(tc, o);
+            tq += __shfl_down(tq, o);
+            tl += __shfl_down(tl, o);
+        }
+        if (lane == 0) {
+            const float invB = 1.0f / (float)B;
+            const long long k = st->n_logged;
+            loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + action_l2 * (tl / (float)(B * act_dim));
+            loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
+            st->n_logged = k + 1;
+        }
     }
     if (idx >= n) return;
     const float neg_step_size = (idx < n_actor) ? st->neg_step_actor : st->neg_step_critic;
@@ -622,7 +632,18 @@ static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, c
     return HP_OK;
 }
 
-static int enqueue_forward_backward_slab(hp_agent *a);
+struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs already staged in XA/XP/XT/R)
+    hp_buffer *b;
+    hp_norm *on, *gn;
+    const PlanRec *plan;
+    double sq;
+    // slab engine: draw the NEXT update's index plan in a spare workgroup of the backward kernel
+    hp_rng *rng = nullptr;
+    PlanRec *next_plan = nullptr;
+    double future_p = 0.0;
+};
+
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc);
 
 // layer-per-launch engine: forwards + losses + backwards of one update, inputs in XA/XP/XT/R (18 launches)
 static int enqueue_forward_backward_layers(hp_agent *a) {
@@ -755,8 +776,13 @@ static int enqueue_forward_backward_layers(hp_agent *a) {
     return HP_OK;
 }
 
-static int enqueue_forward_backward(hp_agent *a) {
-    return a->slab ? enqueue_forward_backward_slab(a) : enqueue_forward_backward_layers(a);
+static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq);
+
+// one update's forwards + backwards.  gc == nullptr: the minibatch is already staged in XA/XP/XT/R.
+static int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr) {
+    if (a->slab) return enqueue_forward_backward_slab(a, gc);   // gather fused into the forward kernel
+    if (gc) HP_TRY(enqueue_gather(a, gc->b, gc->on, gc->gn, gc->plan, gc->sq));
+    return enqueue_forward_backward_layers(a);
 }
 
 static ArenaMap arena_map(const hp_agent *a) {
@@ -777,7 +803,7 @@ static int enqueue_relayout(hp_agent *a, bool targets) {
 }
 
 // slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
-static int enqueue_forward_backward_slab(hp_agent *a) {
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
@@ -786,6 +812,15 @@ static int enqueue_forward_backward_slab(hp_agent *a) {
         ProfScope ps(a, PROF_GEMM_FWD);
         FwdSlabArgs A;
         A.tl = a->timeline;
+        memset(&A.gs, 0, sizeof(A.gs));
+        if (gc) {
+            hp_buffer *b = gc->b;
+            A.gs.obs = b->d_obs; A.gs.ag = b->d_ag; A.gs.g = b->d_g; A.gs.act = b->d_act;
+            A.gs.plan = gc->plan; A.gs.onz = gc->on->d; A.gs.gnz = gc->gn->d;
+            A.gs.sq_threshold = gc->sq; A.gs.clip_obs = a->cfg.clip_obs; A.gs.clip_range = a->cfg.clip_range;
+            A.gs.T = b->T; A.gs.obs_dim = b->obs_dim; A.gs.goal_dim = b->goal_dim; A.gs.B = a->B;
+            A.gs.R = a->R;
+        }
         A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
         A.target = SlabNetPtrs{a->fragFT, nullptr, a->targets};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim; A.Mp = Mp;
@@ -814,7 +849,15 @@ static int enqueue_forward_backward_slab(hp_agent *a) {
         A.dQA = a->dQA; A.dA3 = a->dA3; A.dA2 = a->dA2; A.dA1 = a->dA1;
         A.dZ = a->dZ; A.dK3 = a->dK3; A.dK2 = a->dK2; A.dK1 = a->dK1;
         A.part = a->part; A.st = a->d_state; A.adam = adam_cfg(a);
-        hipLaunchKernelGGL(k_bwd_slab, dim3(nslab, 2), dim3(SL_THREADS), 0, s, A);
+        A.nslab = nslab;
+        const bool ride = gc && gc->next_plan && gc->rng;
+        A.rng = ride ? gc->rng->d_state : nullptr;
+        A.meta = ride ? gc->b->d_meta : nullptr;
+        A.next_plan = ride ? gc->next_plan : nullptr;
+        A.future_p = ride ? gc->future_p : 0.0;
+        A.T = ride ? gc->b->T : 0;
+        A.plan_batch = a->B;
+        hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, A);
         HP_CHECK_HIP(hipGetLastError());
     }
     {   // all weight gradients: the only products that reduce over the batch
@@ -889,13 +932,22 @@ static int check_handles(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
 // (nothing else consumes the stream in between, exactly like the reference's inner loop).
 static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq,
                            int n_updates, bool with_adam) {
+    // slab engine: only the first minibatch's indices are drawn up front; update u draws the plan of update u+1 in
+    // a spare workgroup of its backward kernel (same stream order of draws, so the same indices).  Layer engine:
+    // one kernel draws all of them (nothing else consumes the stream in between, like the reference's inner loop).
+    const bool ride = a->slab && with_adam;
     {
         ProfScope ps(a, PROF_PLAN);
-        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, n_updates, future_p, a->plan.as<PlanRec>()));
+        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? 1 : n_updates, future_p, a->plan.as<PlanRec>()));
     }
     for (int u = 0; u < n_updates; ++u) {
-        HP_TRY(enqueue_gather(a, b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq));
-        HP_TRY(enqueue_forward_backward(a));
+        GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
+        if (ride && u + 1 < n_updates) {
+            gc.rng = rng;
+            gc.next_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
+            gc.future_p = future_p;
+        }
+        HP_TRY(enqueue_forward_backward(a, &gc));
         if (with_adam) HP_TRY(enqueue_adam(a));
     }
     return HP_OK;

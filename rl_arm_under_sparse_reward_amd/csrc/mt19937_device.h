@@ -164,3 +164,27 @@ __device__ __forceinline__ void mt_draw_double(MtWg &g, long long count, Emit em
         produced += n;
     }
 }
+
+// her.py:24-33 for `n_batches` consecutive minibatches (shared by k_draw_plan and the plan workgroup that rides
+// along with the backward slab kernel): plan[b*batch + i] = (e, t, future_t, her).  Must be executed by exactly
+// MT_THREADS threads of one workgroup (threadIdx.x < MT_THREADS); `ring` = uint32[4][624], `ibuf` = int[8] in LDS.
+__device__ __forceinline__ void mt_her_plan(MtState *st, long long n_eps, int T, long long batch, int n_batches,
+                                            double future_p, PlanRec *plan, uint32_t (*ring)[MT_N], int *ibuf) {
+    MtWg g;
+    mt_load(g, st, ring, ibuf);
+    if (n_eps <= 0 || T <= 0) return;  // host refuses this case (ValueError: high <= 0)
+    for (int b = 0; b < n_batches; ++b) {
+        PlanRec *p = plan + (long long)b * batch;
+        mt_draw_bounded(g, (uint32_t)(n_eps - 1), batch, [&](long long i, uint32_t v) { p[i].e = (int)v; });
+        mt_draw_bounded(g, (uint32_t)(T - 1), batch, [&](long long i, uint32_t v) { p[i].t = (int)v; });
+        mt_draw_double(g, batch, [&](long long i, double u) { p[i].her = (u < future_p) ? 1 : 0; });
+        __syncthreads();  // p[i].t may have been written by another thread
+        mt_draw_double(g, batch, [&](long long i, double u) {
+            int t = p[i].t;
+            double off = u * (double)(T - t);  // her.py:31 (float64 * int64)
+            p[i].fut = t + 1 + (int)off;       // her.py:32-33 (astype(int) truncates)
+        });
+        __syncthreads();
+    }
+    mt_store(g, st);
+}

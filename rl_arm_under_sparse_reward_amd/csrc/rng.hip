@@ -10,24 +10,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_plan(MtState *st, const Buf
                                                          PlanRec *plan) {
     __shared__ uint32_t ring[4][MT_N];
     __shared__ int ibuf[8];
-    MtWg g;
-    mt_load(g, st, ring, ibuf);
     const long long n_eps = meta ? meta->current_size : n_eps_fixed;
-    if (n_eps <= 0 || T <= 0) return;  // host refuses this case (ValueError: high <= 0)
-    for (int b = 0; b < n_batches; ++b) {
-        PlanRec *p = plan + (long long)b * batch;
-        mt_draw_bounded(g, (uint32_t)(n_eps - 1), batch, [&](long long i, uint32_t v) { p[i].e = (int)v; });
-        mt_draw_bounded(g, (uint32_t)(T - 1), batch, [&](long long i, uint32_t v) { p[i].t = (int)v; });
-        mt_draw_double(g, batch, [&](long long i, double u) { p[i].her = (u < future_p) ? 1 : 0; });
-        __syncthreads();  // p[i].t may have been written by another thread
-        mt_draw_double(g, batch, [&](long long i, double u) {
-            int t = p[i].t;
-            double off = u * (double)(T - t);  // her.py:31 (float64 * int64)
-            p[i].fut = t + 1 + (int)off;       // her.py:32-33 (astype(int) truncates)
-        });
-        __syncthreads();
-    }
-    mt_store(g, st);
+    mt_her_plan(st, n_eps, T, batch, n_batches, future_p, plan, ring, ibuf);
 }
 
 // replay_buffer._get_storage_idx (replay_buffer.py:57-71); updates the device counters.

@@ -25,6 +25,7 @@
 // the canonical row-major parameters.  A operands (activations, dY) are read from LDS rows of 260
 // floats, one ds_read_b128 per lane per super-step (conflict free, see gemm_lds.h).
 #pragma once
+#include "mt19937_device.h"
 
 #ifndef SL_WAVES
 #define SL_WAVES 8         // wavefronts per slab workgroup: 8 -> two output fragments per wave, 256-VGPR budget
@@ -349,8 +350,18 @@ struct SlabNetPtrs {
 #define SLAB_STAMP(tl, k) do { } while (0)
 #endif
 
+struct GatherSrc {   // replay buffer + index plan + normalizer statistics: everything k_gather_fused takes
+    const double *obs, *ag, *g, *act;
+    const PlanRec *plan;              // nullptr: the network inputs are already in XA / XP / XT (minibatch API)
+    const NormDev *onz, *gnz;
+    double sq_threshold, clip_obs, clip_range;
+    int T, obs_dim, goal_dim, B;
+    float *R;
+};
+
 struct FwdSlabArgs {
     unsigned long long *tl;
+    GatherSrc gs;
     SlabNetPtrs online, target;   // arenas: [actor | critic]
     NetLayout la, lc;
     int H, ldx, act_off, act_dim, Mp;
@@ -384,6 +395,56 @@ __device__ __forceinline__ void slab_trunk(const float *xin, const NetLayout &l,
     if (g3) slab_store(bufA, SL_LD, H, g3 + row0 * H, H);
 }
 
+// HER gather + relabel + reward + clip + normalise for the 16 rows of this slab, straight into the LDS input
+// slab (and to the global copies the backward pass / weight-gradient GEMM read later).  Same arithmetic as
+// k_gather_fused (her.py:26-38, ddpg_agent.py:228-243, normalizer.py:67-70): float64 in, float32 out.
+//   which = 0: x' (obs_next, g)   1: (x, a / max_action) + reward   2: x
+__device__ __forceinline__ void slab_gather(float *xin, const GatherSrc &G, int which, size_t row0, int ldx, int act_off,
+                                            int act_dim, float max_action, float *Xout) {
+    const int tid = threadIdx.x, r = tid / (SL_THREADS / SL_ROWS), l = tid % (SL_THREADS / SL_ROWS);
+    const size_t m = row0 + r;
+    const bool live = (int)m < G.B;
+    PlanRec rec = {0, 0, 1, 0};
+    if (live) rec = G.plan[m];
+    const long long e = rec.e;
+    const int t = rec.t, od = G.obs_dim, gd = G.goal_dim;
+    const double *obs_row = G.obs + (e * (G.T + 1) + t + (which == 0 ? 1 : 0)) * od;
+    const double *g_src = rec.her ? G.ag + (e * (G.T + 1) + rec.fut) * gd : G.g + (e * G.T + t) * gd;
+    for (int c = l; c < ldx; c += SL_THREADS / SL_ROWS) {
+        float x = 0.f;
+        if (live) {
+            if (c < od) {
+                double v = fmin(fmax(obs_row[c], -G.clip_obs), G.clip_obs);
+                v = __ddiv_rn(__dsub_rn(v, (double)G.onz->mean[c]), G.onz->std[c]);
+                x = (float)fmin(fmax(v, -G.clip_range), G.clip_range);
+            } else if (c < od + gd) {
+                const int j = c - od;
+                double v = fmin(fmax(g_src[j], -G.clip_obs), G.clip_obs);
+                v = __ddiv_rn(__dsub_rn(v, (double)G.gnz->mean[j]), G.gnz->std[j]);
+                x = (float)fmin(fmax(v, -G.clip_range), G.clip_range);
+            } else if (which == 1 && c >= act_off && c < act_off + act_dim) {
+                x = (float)G.act[(e * G.T + t) * act_dim + (c - act_off)] / max_action;
+            }
+        }
+        xin[r * SL_LDX + c] = x;
+        if (Xout && (which == 1 || c < act_off)) Xout[m * ldx + c] = x;   // chain P: the action block is written by the head
+    }
+    if (which == 1 && l == 0) {
+        float rew = 0.f;
+        if (live) {
+            const double *ag_next = G.ag + (e * (G.T + 1) + t + 1) * gd;
+            double s = 0.0;
+            for (int c = 0; c < gd; ++c) {
+                const double d = __dsub_rn(ag_next[c], g_src[c]);
+                const double sq = __dmul_rn(d, d);
+                s = (c == 0) ? sq : __dadd_rn(s, sq);
+            }
+            rew = (s >= G.sq_threshold) ? -1.0f : -0.0f;
+        }
+        G.R[m] = rew;
+    }
+}
+
 __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_WAVES / 4, SL_WAVES / 4))) void k_fwd_slab(const FwdSlabArgs A) {
     __shared__ __attribute__((aligned(16))) float xin[SL_ROWS * SL_LDX];
     __shared__ __attribute__((aligned(16))) float bufA[SL_ROWS * SL_LD];
@@ -400,7 +461,9 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     const int ca = la.total;  // critic segment offset inside an arena
     if (chain == 1) {
         // critic(x, a)
-        slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);   // before the prefetch: vmcnt retires in order
+        // inputs before the weight prefetch: vmcnt retires in order
+        if (A.gs.plan) slab_gather(xin, A.gs, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
+        else slab_load(xin, SL_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
         ring_prologue(ring, A.online.wf + ca + lc.w2);
         slab_sync();
         slab_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, A.CAh1, A.CAh2, A.CAh3, row0, ring,
@@ -412,7 +475,8 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     const bool tgt = (chain == 0);
     const SlabNetPtrs &net = tgt ? A.target : A.online;
     float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
-    slab_load(xin, SL_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
+    if (A.gs.plan) slab_gather(xin, A.gs, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
+    else slab_load(xin, SL_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
     ring_prologue(ring, net.wf + la.w2);
     slab_sync();
     // actor (its last layer prefetches the critic's first 256x256 layer)
@@ -447,6 +511,13 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
 
 struct BwdSlabArgs {
     unsigned long long *tl;
+    // the index plan of the NEXT update is drawn by one spare workgroup (blockIdx.y == 2) while the backward
+    // pass runs: the sequential MT19937 draw (3.6 us per minibatch) leaves the critical path entirely
+    MtState *rng;
+    const BufMeta *meta;
+    PlanRec *next_plan;               // nullptr: nothing to draw
+    double future_p;
+    int T, plan_batch, nslab;
     SlabNetPtrs online;
     NetLayout la, lc;
     int H, ldx, act_off, act_dim, B, Mp;
@@ -477,13 +548,19 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(SL_W
     __shared__ float dq[SL_ROWS];
     __shared__ __attribute__((aligned(16))) float dz[SL_ROWS * 20];
     __shared__ __attribute__((aligned(16))) RingSlot wring[SL_WAVES][SL_RING];
-    const int slab = blockIdx.x, chain = blockIdx.y, nslab = gridDim.x;
+    const int chain = blockIdx.x / A.nslab, slab = blockIdx.x - chain * A.nslab, nslab = A.nslab;
     const size_t row0 = (size_t)slab * SL_ROWS;
     const int tid = threadIdx.x, H = A.H;
     const NetLayout &la = A.la, &lc = A.lc;
     const int ca = la.total;
     const float invB = 1.0f / (float)A.B;
     RingSlot *ring = wring[__builtin_amdgcn_readfirstlane(tid >> 6)];
+    if (chain == 2) {   // plan workgroup (only launched when next_plan != nullptr)
+        if (tid >= MT_THREADS) return;   // ended waves do not take part in barriers
+        mt_her_plan(A.rng, A.meta->current_size, A.T, A.plan_batch, 1, A.future_p, A.next_plan,
+                    reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(scratch));
+        return;
+    }
     if (slab == 0 && chain == 0 && tid == 0) {  // bookkeeping for the optimizer step that follows
         A.st->step += 1;
         adam_prepare(A.st, A.adam);
