@@ -263,7 +263,7 @@ def main():
         # algorithmic MACs per transition (minimal algorithm): 5 forward passes 699,648;
         # backward 683,264 = 395,776 (dX chains) + 287,488 (weight gradients)
         macs = {"forward": 699_648, "backward_dx": 395_776, "weight_grad": 287_488}
-        kern = {"forward": "k_fwd_slab", "backward_dx": "k_bwd_slab", "weight_grad": "k_gemm_lds (8 dW problems)"}
+        kern = {"forward": "k_fwd_slab8", "backward_dx": "k_bwd_slab8", "weight_grad": "k_gemm_lds (8 dW problems)"}
         per = {}
         for k, m in macs.items():
             ms = prof[k]["ms_per_step"]
@@ -279,17 +279,18 @@ def main():
                 "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": None,
                 "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
-                "note": "dominant kernel by time; FP32 v_mfma_f32_16x16x4_f32.  At batch 256 only 16 slabs x 2-3 chains "
-                        "(32-48 of 256 CUs) have work and each workgroup is bound by streaming the layer weights "
-                        "through its CU (~38 GB/s per CU measured, tools/ubench/stream_bw.hip), not by the matrix pipe; "
-                        "durations are HIP-event pairs around each eager launch on the launch stream",
+                "note": "dominant kernel by time; FP32 v_mfma_f32_4x4x1_16b_f32 (8-row slabs).  At batch 256 only 32 slabs x "
+                        "2-3 chains (64-96 of 256 CUs) have work; a 256x256 layer costs a workgroup ~3.5 us against 1.9 us "
+                        "of MFMA issue and 2.1 us of LDS-DMA weight streaming (DESIGN.md 3.1); durations are HIP-event "
+                        "pairs around each eager launch on the launch stream",
                 "all_matrix_kernels": per,
             }
         s_ms = prof["sample"]["ms_per_step"]
-        s_gbps = SAMPLE_BYTES_PER_TRANSITION * a.batch / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
-        out["roofline_sample_kernel"] = {"bound": "hbm", "kernel": "k_gather_fused", "achieved": round(s_gbps, 2),
-                                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(s_gbps / HBM_PEAK_GBPS, 6),
-                                         "avg_launch_us": round(prof["sample"]["avg_us"], 3), "traffic": None}
+        if s_ms > 0:   # only the layer engine runs the gather as its own kernel; the slab engines fuse it
+            s_gbps = SAMPLE_BYTES_PER_TRANSITION * a.batch / (s_ms * 1e-3) / 1e9
+            out["roofline_sample_kernel"] = {"bound": "hbm", "kernel": "k_gather_fused", "achieved": round(s_gbps, 2),
+                                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(s_gbps / HBM_PEAK_GBPS, 6),
+                                             "avg_launch_us": round(prof["sample"]["avg_us"], 3), "traffic": None}
         out["kernel_time_us_per_step"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)

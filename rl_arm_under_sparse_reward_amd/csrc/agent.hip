@@ -90,6 +90,7 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #define LOSS_LOG 4096
 
 #include "slab.h"
+#include "slab8.h"
 
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
@@ -112,7 +113,8 @@ struct hp_agent {
     // row-slab engine: fragment-ordered weight copies (online forward / online dX / target forward), loss partials
     float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
-    bool slab = true;
+    bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
+    bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
@@ -483,11 +485,9 @@ __global__ __launch_bounds__(256) void k_adam_frag(float *__restrict__ p, const 
     m[idx] = mi;
     v[idx] = vi;
     int of, od;
-    frag_offsets(am, idx, of, od);
-    if (of >= 0) {
-        fragF[of] = pn;
-        fragD[od] = pn;
-    }
+    frag_offsets_any(am, idx, of, od);
+    if (of >= 0) fragF[of] = pn;
+    if (od >= 0) fragD[od] = pn;
 }
 
 __global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__ src, float *fragFT, int n,
@@ -497,7 +497,7 @@ __global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__
     const float t = __fadd_rn(__fmul_rn(one_minus, src[idx]), __fmul_rn(polyak, tgt[idx]));
     tgt[idx] = t;
     int of, od;
-    frag_offsets(am, idx, of, od);
+    frag_offsets_any(am, idx, of, od);
     if (of >= 0) fragFT[of] = t;
 }
 
@@ -790,6 +790,7 @@ static ArenaMap arena_map(const hp_agent *a) {
     am.la = a->la;
     am.lc = a->lc;
     am.H = a->H;
+    am.mode = a->slab8 ? 1 : 0;
     return am;
 }
 
@@ -807,7 +808,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
-    const int nslab = Mp / SL_ROWS;
+    const int nslab = Mp / (a->slab8 ? S8_ROWS : SL_ROWS);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
         FwdSlabArgs A;
@@ -830,7 +831,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
         A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
         A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
         A.QT = a->QT; A.QA = a->QA; A.QP = a->QP;
-        hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, A);
+        if (a->slab8) hipLaunchKernelGGL(k_fwd_slab8, dim3(3 * nslab), dim3(S8_THREADS), 0, s, A);
+        else hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, A);
         HP_CHECK_HIP(hipGetLastError());
     }
     {
@@ -857,7 +859,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
         A.future_p = ride ? gc->future_p : 0.0;
         A.T = ride ? gc->b->T : 0;
         A.plan_batch = a->B;
-        hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, A);
+        if (a->slab8) hipLaunchKernelGGL(k_bwd_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, A);
+        else hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, A);
         HP_CHECK_HIP(hipGetLastError());
     }
     {   // all weight gradients: the only products that reduce over the batch
@@ -884,7 +887,8 @@ static int enqueue_adam(hp_agent *a) {
                            a->adam_m, a->adam_v, a->fragF, a->fragD, n, a->la.total,
                            (float)(1.0 - a->cfg.adam_beta1), (float)a->cfg.adam_beta2,
                            (float)(1.0 - a->cfg.adam_beta2), (float)a->cfg.adam_eps, a->d_state, arena_map(a), a->part,
-                           a->Mp / SL_ROWS, a->B, (int)a->cfg.act_dim, (float)a->cfg.action_l2, a->loss_log);
+                           a->Mp / (a->slab8 ? S8_ROWS : SL_ROWS), a->B, (int)a->cfg.act_dim, (float)a->cfg.action_l2,
+                           a->loss_log);
         HP_CHECK_HIP(hipGetLastError());
         return HP_OK;
     }
@@ -1056,10 +1060,12 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
     A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
     A(&a->loss_log, LOSS_LOG * 2);
-    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / SL_ROWS));
+    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / S8_ROWS));
     {
-        const char *e = getenv("RLARM_ENGINE");   // "layers" selects the layer-per-launch engine (A/B and debugging)
+        // RLARM_ENGINE = slab8 (default) | slab16 | layers: the alternatives stay for A/B runs and debugging
+        const char *e = getenv("RLARM_ENGINE");
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
+        a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);

@@ -56,6 +56,7 @@ __host__ __device__ __forceinline__ int frag_dx_index(int n, int k, int N) {
 struct ArenaMap {  // enough of the arena geometry to find (layer, n, k) of a flat index on the device
     NetLayout la, lc;
     int H;
+    int mode;      // 0: 16-row slab fragment order (slab.h), 1: 8-row slab order (slab8.h)
 };
 
 // canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases
@@ -78,16 +79,21 @@ __host__ __device__ __forceinline__ void frag_offsets(const ArenaMap &am, int id
     off_d = base + w0 + frag_dx_index(n, k, N);
 }
 
+__host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
+
+__host__ __device__ __forceinline__ void frag_offsets_any(const ArenaMap &am, int idx, int &off_f, int &off_d) {
+    if (am.mode == 1) frag8_offsets(am, idx, off_f, off_d);
+    else frag_offsets(am, idx, off_f, off_d);
+}
+
 __global__ void k_relayout(const float *__restrict__ canon, float *fragF, float *fragD, int n, const ArenaMap am) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     int of, od;
-    frag_offsets(am, idx, of, od);
-    if (of >= 0) {
-        const float v = canon[idx];
-        fragF[of] = v;
-        if (fragD) fragD[od] = v;
-    }
+    frag_offsets_any(am, idx, of, od);
+    const float v = canon[idx];
+    if (of >= 0) fragF[of] = v;
+    if (od >= 0 && fragD) fragD[od] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,7 +351,9 @@ struct SlabNetPtrs {
 };
 
 #ifdef SLAB_TIMELINE   // debug build: wave 0 of slab 0 stamps the 100 MHz wall clock at stage boundaries
-#define SLAB_STAMP(tl, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) (tl)[blockIdx.y * 32 + (k)] = wall_clock64(); } while (0)
+#define SLAB_STAMP(tl, k) do { if (slab_stamp_slab() == 0 && threadIdx.x == 0) (tl)[slab_stamp_chain() * 32 + (k)] = wall_clock64(); } while (0)
+__device__ __forceinline__ int slab_stamp_chain() { return gridDim.y > 1 ? blockIdx.y : blockIdx.x / (gridDim.x / 3); }
+__device__ __forceinline__ int slab_stamp_slab() { return gridDim.y > 1 ? blockIdx.x : blockIdx.x % (gridDim.x / 3); }
 #else
 #define SLAB_STAMP(tl, k) do { } while (0)
 #endif

@@ -1,0 +1,526 @@
+// slab8.h -- row-slab engine, 8 batch rows per workgroup on v_mfma_f32_4x4x1_16b_f32 (included by agent.hip).
+//
+// Why a second slab kernel family: with 16-row slabs on the 16x16x4 MFMA (slab.h) a 256x256 layer costs a
+// workgroup 1024 MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The
+// 4x4x1 instruction (16 independent 4x4 outer products per issue, measured 8.7 cycles = 92 % of the 16x16x4
+// FLOP rate, tools/ubench/mfma4x4.hip) lets a slab be 8 rows: lane l of a wavefront owns output column
+// 64*cg + l, accumulator register r owns row r of a 4-row group, the A operand is the 4 activations of that
+// row group at one reduction index (the same for all 16 blocks: an LDS broadcast read), the B operand is ONE
+// weight per lane.  Half the MFMA time per layer, twice the workgroups (96 at batch 256), same weight stream.
+//   wave w of 8:  column group cg = w & 3 (64 output columns),  reduction half kh = w >> 2
+//   per super-step (4 reduction indices): B = float4 per lane (1 KiB block, LDS-DMA ring as in slab.h),
+//   A = two ds_read_b128 (row group 0 / 1), 8 MFMAs (2 row groups x 4 indices, alternating accumulators)
+//   the two reduction halves meet in LDS (8 KiB), the kh == 0 waves run the epilogue.
+// Fragment-ordered copies for this engine (same arena offsets as the canonical layout):
+//   forward  Wf8[((n >> 6) * K/4 + (k >> 2)) * 256 + (n & 63) * 4 + (k & 3)] = W[n][k]     (layers 1-3)
+//   dX       Wd8[((k >> 6) * N/4 + (n >> 2)) * 256 + (k & 63) * 4 + (n & 3)] = W[n][k]     (layers 2-4)
+// The 4- and 1-wide heads and the 4 action columns of the critic's input gradient are 8 x 4 dot products of
+// length 256: one wavefront per row, float4 per lane, shuffle tree -- no matrix pipe, canonical weights.
+#pragma once
+
+#define S8_THREADS 512
+#define S8_WAVES 8
+#define S8_ROWS 8
+#define S8_LD 260
+#define S8_LDX 52
+#define S8_RING 12
+
+__host__ __device__ __forceinline__ int frag8_fwd_index(int n, int k, int K) {
+    return (((n >> 6) * (K >> 2) + (k >> 2)) << 8) + ((n & 63) << 2) + (k & 3);
+}
+__host__ __device__ __forceinline__ int frag8_dx_index(int n, int k, int N) {
+    return (((k >> 6) * (N >> 2) + (n >> 2)) << 8) + ((k & 63) << 2) + (n & 3);
+}
+
+// canonical arena index -> offsets of the slab8 fragment copies (-1: this tensor has none)
+__host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d) {
+    const bool critic = idx >= am.la.total;
+    const NetLayout &l = critic ? am.lc : am.la;
+    const int base = critic ? am.la.total : 0;
+    const int r = idx - base;
+    off_f = off_d = -1;
+    int w0, N, K, layer;
+    if (r < l.b1) { w0 = l.w1; N = am.H; K = l.K1; layer = 1; }
+    else if (r < l.w2) return;
+    else if (r < l.b2) { w0 = l.w2; N = am.H; K = am.H; layer = 2; }
+    else if (r < l.w3) return;
+    else if (r < l.b3) { w0 = l.w3; N = am.H; K = am.H; layer = 3; }
+    else if (r < l.w4) return;
+    else if (r < l.b4) { w0 = l.w4; N = 16; K = am.H; layer = 4; }
+    else return;
+    const int e = r - w0, n = e / K, k = e - n * K;
+    if (layer <= 3) off_f = base + w0 + frag8_fwd_index(n, k, K);
+    if (layer >= 2) off_d = base + w0 + frag8_dx_index(n, k, N);
+}
+
+__device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (see slab.h)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// weight block b (4 reduction indices) of column group cg in a layer with nb4 blocks per column group
+__device__ __forceinline__ const float4 *s8_wblock(const float *wlayer, int cg, int nb4, int b) {
+    return reinterpret_cast<const float4 *>(wlayer) + ((size_t)cg * nb4 + b) * 64 + (threadIdx.x & 63);
+}
+
+// A operand through the MFMA's block broadcast (cbsz = 4: all 16 blocks use the A values of block `abid`):
+// lane l = 4*blk + i keeps x[row group * 4 + i][k0 + 16 j + blk] in register j, so ONE register per lane serves
+// 16 reduction indices and a wavefront loads its whole A operand for a layer once (16 ds_read_b32) instead of
+// two ds_read_b128 per super-step -- the LDS pipe, shared with the weight DMA, was the limiter.
+// TB = (block index within the wave's half) % 4 selects which quarter of register j the 4 indices of a block hit.
+template <int TB>
+__device__ __forceinline__ void s8_mma8(f32x4 &c0, f32x4 &c1, const float a0, const float a1, const float4 b) {
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.x, c0, 4, 4 * TB + 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.x, c1, 4, 4 * TB + 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.y, c0, 4, 4 * TB + 1, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.y, c1, 4, 4 * TB + 1, 0);
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.z, c0, 4, 4 * TB + 2, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.z, c1, 4, 4 * TB + 2, 0);
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.w, c0, 4, 4 * TB + 3, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.w, c1, 4, 4 * TB + 3, 0);
+}
+
+// load this wave's A operand for NJ groups of 16 reduction indices starting at index k0
+template <int NJ>
+__device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, float (&a0)[8], float (&a1)[8]) {
+    const int i = threadIdx.x & 3, blk = (threadIdx.x & 63) >> 2;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        a0[j] = lin[i * ld_in + k0 + 16 * j + blk];
+        a1[j] = lin[(4 + i) * ld_in + k0 + 16 * j + blk];
+    }
+}
+
+// The ring is CONTINUOUS across the 256x256 layers of a chain: block t of the current layer lives in slot
+// (rbase + t) % S8_RING, and as soon as the current layer has no block left to issue the freed slots take the
+// first blocks of the next layer (slot arithmetic stays consistent with rbase' = rbase + 32).  The DMA queue
+// therefore never drains at a layer boundary.
+__device__ __forceinline__ void s8_ring_issue(RingSlot *ring, int rbase, const float *wlayer, int cg, int b0, int t) {
+    __builtin_amdgcn_global_load_lds(s8_wblock(wlayer, cg, 64, b0 + t), &ring[(rbase + t) % S8_RING][0], 16, 0, 0);
+}
+
+// first S8_RING blocks of this wave's half of a 256-reduction layer (start of a chain)
+__device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, const float *wlayer) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
+#pragma unroll
+    for (int t = 0; t < S8_RING; ++t) s8_ring_issue(ring, rbase, wlayer, cg, b0, t);
+}
+
+template <int T, bool HAS_NEXT>   // block T of the 32 this wave consumes
+__device__ __forceinline__ void s8_ring_step(f32x4 &c0, f32x4 &c1, RingSlot *ring, int rbase, const float *wlayer,
+                                             const float *nxt, int cg, int b0, const float (&a0)[8],
+                                             const float (&a1)[8]) {
+    constexpr int left = 32 - T;
+    constexpr int inflight = HAS_NEXT ? S8_RING : (left < S8_RING ? left : S8_RING);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight - 1) : "memory");
+    const float4 b = ring[(rbase + T) % S8_RING][threadIdx.x & 63];
+    if constexpr (T + S8_RING < 32) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot read done before the DMA refills it
+        s8_ring_issue(ring, rbase, wlayer, cg, b0, T + S8_RING);
+    } else if constexpr (HAS_NEXT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        s8_ring_issue(ring, rbase + 32, nxt, cg, b0, T + S8_RING - 32);
+    }
+    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b);
+    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
+}
+
+// combine the two reduction halves and run the epilogue.  c0/c1: this wave's partial [row group][row][col = lane]
+__device__ __forceinline__ void s8_finish(f32x4 c0, f32x4 c1, int epi, const float *e, float *pbuf, float *lout,
+                                          int ld_out) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
+    const int col = 64 * cg + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pbuf[r * 256 + col] = c0[r];
+            pbuf[(4 + r) * 256 + col] = c1[r];
+        }
+    }
+    s8_sync();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = c0[r] + pbuf[r * 256 + col], v1 = c1[r] + pbuf[(4 + r) * 256 + col];
+            if (epi == SE_BIAS_RELU) {
+                lout[r * ld_out + col] = fmaxf(v0 + e[0], 0.f);
+                lout[(4 + r) * ld_out + col] = fmaxf(v1 + e[0], 0.f);
+            } else {
+                lout[r * ld_out + col] = (e[r] > 0.f) ? v0 : 0.f;
+                lout[(4 + r) * ld_out + col] = (e[4 + r] > 0.f) ? v1 : 0.f;
+            }
+        }
+    }
+}
+
+// epilogue operands of this wave's column (only the kh == 0 waves use them): bias, or the 8 gate values
+__device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float *__restrict__ aux, int ldaux) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = 64 * (wave & 3) + (threadIdx.x & 63);
+    if ((wave >> 2) != 0) return;
+    if (epi == SE_BIAS_RELU) {
+        e[0] = aux[col];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = aux[(size_t)r * ldaux + col];
+    }
+}
+
+// out[8][256] = epi(in[8][256] . W): DMA-ring fed.  The first S8_RING blocks of `wlayer` must be in flight at
+// ring base `rbase`; on return the first S8_RING blocks of `nxt` are (if nxt != nullptr) and rbase has advanced.
+__device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSlot *ring, int &rbase,
+                                             const float *__restrict__ wlayer, const float *__restrict__ nxt, int epi,
+                                             const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
+                                             int ld_out) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
+    float e[8];
+    s8_epi_load(e, epi, aux, ldaux);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    float a0[8], a1[8];
+    s8_aload<8>(lin, ld_in, 4 * b0, a0, a1);
+    if (nxt) s8_ring_step<0, true>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
+    else s8_ring_step<0, false>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
+    rbase = (rbase + 32) % S8_RING;
+    __builtin_amdgcn_sched_barrier(0);
+    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
+}
+
+template <int T, int HALF>
+__device__ __forceinline__ void s8_small_steps(f32x4 &c0, f32x4 &c1, const float *wlayer, int cg, int nb4, int b0,
+                                               const float (&a0)[8], const float (&a1)[8]) {
+    const float4 b = *s8_wblock(wlayer, cg, nb4, b0 + T);
+    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b);
+    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, c1, wlayer, cg, nb4, b0, a0, a1);
+}
+
+// small layer (reduction length Kred = 16 / 32 / 48): weights straight from global, no ring
+__device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float *__restrict__ wlayer,
+                                               int epi, const float *__restrict__ aux, int ldaux, float *pbuf,
+                                               float *lout, int ld_out) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, kh = wave >> 2;
+    const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
+    float e[8];
+    s8_epi_load(e, epi, aux, ldaux);
+    f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    float a0[8], a1[8];
+    s8_aload<2>(lin, ld_in, 4 * b0, a0, a1);   // at most 24 indices per half; lanes past the row end read unused padding
+    switch (half) {
+        case 2: s8_small_steps<0, 2>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
+        case 4: s8_small_steps<0, 4>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
+        case 6: s8_small_steps<0, 6>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
+        default: break;   // other input widths are rejected on the host
+    }
+    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
+}
+
+// 8 x nout dot products of length 256 (nout <= 4): wave r owns row r, lane p the reduction indices 4p..4p+3.
+// w(j) must return the float4 of weights for output j at those indices.  Result valid in lane 0.
+template <class WF>
+__device__ __forceinline__ void s8_rowdots(const float *lin, int ld_in, int nout, WF w, float (&out)[4]) {
+    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = threadIdx.x & 63;
+    const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+        if (j < nout) {
+            const float4 wv = w(j, p);
+            s = (h.x * wv.x + h.y * wv.y) + (h.z * wv.z + h.w * wv.w);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        }
+        out[j] = s;
+    }
+}
+
+__device__ __forceinline__ void s8_store(const float *l, int ld, int width, float *g, int ldg) {
+    const int per_row = width >> 2;
+    for (int f = threadIdx.x; f < S8_ROWS * per_row; f += S8_THREADS) {
+        const int r = f / per_row, c4 = f - r * per_row;
+        *reinterpret_cast<float4 *>(g + (size_t)r * ldg + 4 * c4) = *reinterpret_cast<const float4 *>(l + r * ld + 4 * c4);
+    }
+}
+
+__device__ __forceinline__ void s8_load(float *l, int ld, int width, const float *g, int ldg) {
+    const int per_row = width >> 2;
+    for (int f = threadIdx.x; f < S8_ROWS * per_row; f += S8_THREADS) {
+        const int r = f / per_row, c4 = f - r * per_row;
+        *reinterpret_cast<float4 *>(l + r * ld + 4 * c4) = *reinterpret_cast<const float4 *>(g + (size_t)r * ldg + 4 * c4);
+    }
+}
+
+// HER gather for the 8 rows of a slab (same arithmetic as slab_gather / k_gather_fused); 64 threads per row
+__device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, int which, size_t row0, int ldx, int act_off,
+                                          int act_dim, float max_action, float *Xout) {
+    const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const size_t m = row0 + r;
+    const bool live = (int)m < G.B;
+    PlanRec rec = {0, 0, 1, 0};
+    if (live) rec = G.plan[m];
+    const long long e = rec.e;
+    const int t = rec.t, od = G.obs_dim, gd = G.goal_dim;
+    const double *obs_row = G.obs + (e * (G.T + 1) + t + (which == 0 ? 1 : 0)) * od;
+    const double *g_src = rec.her ? G.ag + (e * (G.T + 1) + rec.fut) * gd : G.g + (e * G.T + t) * gd;
+    if (l < ldx) {
+        const int c = l;
+        float x = 0.f;
+        if (live) {
+            if (c < od) {
+                double v = fmin(fmax(obs_row[c], -G.clip_obs), G.clip_obs);
+                v = __ddiv_rn(__dsub_rn(v, (double)G.onz->mean[c]), G.onz->std[c]);
+                x = (float)fmin(fmax(v, -G.clip_range), G.clip_range);
+            } else if (c < od + gd) {
+                const int j = c - od;
+                double v = fmin(fmax(g_src[j], -G.clip_obs), G.clip_obs);
+                v = __ddiv_rn(__dsub_rn(v, (double)G.gnz->mean[j]), G.gnz->std[j]);
+                x = (float)fmin(fmax(v, -G.clip_range), G.clip_range);
+            } else if (which == 1 && c >= act_off && c < act_off + act_dim) {
+                x = (float)G.act[(e * G.T + t) * act_dim + (c - act_off)] / max_action;
+            }
+        }
+        xin[r * S8_LDX + c] = x;
+        if (Xout && (which == 1 || c < act_off)) Xout[m * ldx + c] = x;
+    }
+    if (which == 1 && l == 63) {
+        float rew = 0.f;
+        if (live) {
+            const double *ag_next = G.ag + (e * (G.T + 1) + t + 1) * gd;
+            double s = 0.0;
+            for (int c = 0; c < gd; ++c) {
+                const double d = __dsub_rn(ag_next[c], g_src[c]);
+                const double sq = __dmul_rn(d, d);
+                s = (c == 0) ? sq : __dadd_rn(s, sq);
+            }
+            rew = (s >= G.sq_threshold) ? -1.0f : -0.0f;
+        }
+        G.R[m] = rew;
+    }
+}
+
+// xin (K1 wide) -> h1 -> h2 -> h3.  Ring: layer 2 in flight on entry, `nxt` on exit.
+__device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, const float *wf, const float *canon, int H,
+                                         float *bufA, float *bufB, float *pbuf, float *g1, float *g2, float *g3,
+                                         size_t row0, RingSlot *ring, int &rbase, const float *nxt,
+                                         unsigned long long *tl, int tbase) {
+    SLAB_STAMP(tl, tbase);
+    s8_small_layer(xin, S8_LDX, l.K1, wf + l.w1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD);
+    s8_sync();
+    SLAB_STAMP(tl, tbase + 1);
+    if (g1) s8_store(bufA, S8_LD, H, g1 + row0 * H, H);
+    s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD);
+    s8_sync();
+    SLAB_STAMP(tl, tbase + 2);
+    if (g2) s8_store(bufB, S8_LD, H, g2 + row0 * H, H);
+    s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD);
+    s8_sync();
+    SLAB_STAMP(tl, tbase + 3);
+    if (g3) s8_store(bufA, S8_LD, H, g3 + row0 * H, H);
+}
+
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fwd_slab8(const FwdSlabArgs A) {
+    __shared__ __attribute__((aligned(16))) float xin[S8_ROWS * S8_LDX];
+    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
+    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
+    const int nslab = A.Mp / S8_ROWS;
+    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
+    const size_t row0 = (size_t)slab * S8_ROWS;
+    const int tid = threadIdx.x, H = A.H;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    RingSlot *ring = wring[wave];
+    int rbase = 0;
+    const NetLayout &la = A.la, &lc = A.lc;
+    const int ca = la.total;
+#ifdef SLAB_TIMELINE
+    if (slab == 0 && tid == 0) A.tl[chain * 32] = wall_clock64();
+#endif
+    if (chain == 1) {   // critic(x, a)
+        if (A.gs.plan) s8_gather(xin, A.gs, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
+        else s8_load(xin, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
+        s8_ring_prologue(ring, rbase, A.online.wf + ca + lc.w2);
+        s8_sync();
+        s8_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0, ring,
+                 rbase, nullptr, A.tl, 1);
+        float q[4];
+        const float *w4 = A.online.canon + ca + lc.w4;
+        s8_rowdots(bufA, S8_LD, 1, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, q);
+        if (lane == 0) A.QA[(row0 + wave) * 16] = q[0] + A.online.canon[ca + lc.b4];
+        return;
+    }
+    const bool tgt = (chain == 0);
+    const SlabNetPtrs &net = tgt ? A.target : A.online;
+    float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
+    if (A.gs.plan) s8_gather(xin, A.gs, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
+    else s8_load(xin, S8_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
+    s8_ring_prologue(ring, rbase, net.wf + la.w2);
+    s8_sync();
+    s8_trunk(xin, la, net.wf, net.canon, H, bufA, bufB, pbuf, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
+             tgt ? nullptr : A.APh3, row0, ring, rbase, net.wf + ca + lc.w2, A.tl, 1);
+    SLAB_STAMP(A.tl, 5);
+    {   // actor head: tanh -> action block of the critic input (models.py:24, :38)
+        float z[4];
+        const float *w4 = net.canon + la.w4;
+        s8_rowdots(bufA, S8_LD, A.act_dim, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, z);
+        if (lane == 0) {
+            for (int j = 0; j < A.act_dim; ++j) {
+                const float th = tanhf(z[j] + net.canon[la.b4 + j]);
+                const float u = (A.max_action * th) / A.max_action;
+                xin[wave * S8_LDX + A.act_off + j] = u;
+                X[(row0 + wave) * A.ldx + A.act_off + j] = u;
+                if (!tgt) A.TP[(row0 + wave) * 16 + j] = th;
+            }
+        }
+    }
+    s8_sync();
+    SLAB_STAMP(A.tl, 7);
+    s8_trunk(xin, lc, net.wf + ca, net.canon + ca, H, bufA, bufB, pbuf, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
+             tgt ? nullptr : A.CPh3, row0, ring, rbase, nullptr, A.tl, 8);
+    {
+        float q[4];
+        const float *w4 = net.canon + ca + lc.w4;
+        s8_rowdots(bufA, S8_LD, 1, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, q);
+        float *Q = tgt ? A.QT : A.QP;
+        if (lane == 0) Q[(row0 + wave) * 16] = q[0] + net.canon[ca + lc.b4];
+    }
+    SLAB_STAMP(A.tl, 13);
+}
+
+// dY of the top hidden layer from a per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0)
+__device__ __forceinline__ void s8_head_bwd(const float *dq_rows, const float *__restrict__ w4row,
+                                            const float *__restrict__ h3, int H, float *lout) {
+    for (int f = threadIdx.x; f < S8_ROWS * H; f += S8_THREADS) {
+        const int r = f / H, c = f - r * H;
+        lout[r * S8_LD + c] = (h3[(size_t)r * H + c] > 0.f) ? dq_rows[r] * w4row[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bwd_slab8(const BwdSlabArgs A) {
+    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
+    __shared__ float dq[S8_ROWS];
+    __shared__ __attribute__((aligned(16))) float dz[S8_ROWS * 20];
+    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
+    const int nslab = A.nslab;
+    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
+    const size_t row0 = (size_t)slab * S8_ROWS;
+    const int tid = threadIdx.x, H = A.H;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const NetLayout &la = A.la, &lc = A.lc;
+    const int ca = la.total;
+    const float invB = 1.0f / (float)A.B;
+    RingSlot *ring = wring[wave];
+    int rbase = 0;
+    if (chain == 2) {   // plan workgroup: draws the next update's indices (see BwdSlabArgs)
+        if (tid >= MT_THREADS) return;
+        mt_her_plan(A.rng, A.meta->current_size, A.T, A.plan_batch, 1, A.future_p, A.next_plan,
+                    reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+        return;
+    }
+    if (slab == 0 && chain == 0 && tid == 0) {
+        A.st->step += 1;
+        adam_prepare(A.st, A.adam);
+    }
+    if (chain == 0) {
+        // ---- critic loss (ddpg_agent.py:255-263)
+        s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
+        if (tid < S8_ROWS) {
+            const size_t m = row0 + tid;
+            float g = 0.f, sq = 0.f;
+            if ((int)m < A.B) {
+                float y = A.R[m] + A.gamma * A.QT[m * 16];
+                y = fminf(fmaxf(y, -A.clip_ret), 0.f);
+                const float d = y - A.QA[m * 16];
+                sq = d * d;
+                g = -2.f * d * invB;
+            }
+            dq[tid] = g;
+            A.dQA[m * 16] = g;
+            for (int o = 4; o > 0; o >>= 1) sq += __shfl_down(sq, o, 8);
+            if (tid == 0) A.part[slab] = sq;
+        }
+        s8_sync();
+        s8_head_bwd(dq, A.online.canon + ca + lc.w4, A.CAh3 + row0 * H, H, bufA);
+        s8_sync();
+        s8_store(bufA, S8_LD, H, A.dA3 + row0 * H, H);
+        s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H,
+                     pbuf, bufB, S8_LD);
+        s8_sync();
+        s8_store(bufB, S8_LD, H, A.dA2 + row0 * H, H);
+        s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, nullptr, SE_MASK, A.CAh1 + row0 * H, H, pbuf, bufA,
+                     S8_LD);
+        s8_sync();
+        s8_store(bufA, S8_LD, H, A.dA1 + row0 * H, H);
+        return;
+    }
+    // ---- actor loss (ddpg_agent.py:265-267)
+    s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
+    if (tid < S8_ROWS) {
+        const size_t m = row0 + tid;
+        const bool live = (int)m < A.B;
+        dq[tid] = live ? -invB : 0.f;
+        float sq = live ? A.QP[m * 16] : 0.f, su = 0.f;
+        if (live)
+            for (int j = 0; j < A.act_dim; ++j) {
+                const float u = A.XP[m * A.ldx + A.act_off + j];
+                su += u * u;
+            }
+        for (int o = 4; o > 0; o >>= 1) {
+            sq += __shfl_down(sq, o, 8);
+            su += __shfl_down(su, o, 8);
+        }
+        if (tid == 0) {
+            A.part[nslab + slab] = sq;
+            A.part[2 * nslab + slab] = su;
+        }
+    }
+    s8_sync();
+    s8_head_bwd(dq, A.online.canon + ca + lc.w4, A.CPh3 + row0 * H, H, bufA);
+    s8_sync();
+    s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, pbuf,
+                 bufB, S8_LD);
+    s8_sync();
+    s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, pbuf, bufA,
+                 S8_LD);
+    s8_sync();
+    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh
+        float s[4];
+        const float *w1 = A.online.canon + ca + lc.w1 + A.act_off;   // W1c[n][act_off + j], row stride K1
+        const int K1 = lc.K1, ad = A.act_dim;
+        // lane p covers n = 4p..4p+3; for output j gather the 4 weights W1c[4p + c][act_off + j]
+        s8_rowdots(bufA, S8_LD, ad, [&](int j, int p) {
+            return make_float4(w1[(size_t)(4 * p) * K1 + j], w1[(size_t)(4 * p + 1) * K1 + j],
+                               w1[(size_t)(4 * p + 2) * K1 + j], w1[(size_t)(4 * p + 3) * K1 + j]); }, s);
+        if (lane < 16) {
+            const size_t m = row0 + wave;
+            float v = 0.f, sj = 0.f;   // s[] is only valid in lane 0: hand s[lane] to lane `lane`
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float b = __shfl(s[j], 0);
+                if (lane == j) sj = b;
+            }
+            if (lane < ad && (int)m < A.B) {
+                const float u = A.XP[m * A.ldx + A.act_off + lane];
+                const float th = A.TP[m * 16 + lane];
+                const float gu = A.action_l2 * (2.f * u / (float)(A.B * ad)) + sj;
+                const float gt = (gu / A.max_action) * A.max_action;
+                v = gt * (1.f - th * th);
+            }
+            dz[wave * 20 + lane] = v;
+            A.dZ[m * 16 + lane] = v;
+        }
+    }
+    s8_sync();
+    // actor layer 4 backward: reduction over the 16 padded head outputs
+    s8_small_layer(dz, 20, 16, A.online.wd + la.w4, SE_MASK, A.APh3 + row0 * H, H, pbuf, bufB, S8_LD);
+    s8_sync();
+    s8_store(bufB, S8_LD, H, A.dK3 + row0 * H, H);
+    s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + la.w3, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, pbuf, bufA,
+                 S8_LD);
+    s8_sync();
+    s8_store(bufA, S8_LD, H, A.dK2 + row0 * H, H);
+    s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + la.w2, nullptr, SE_MASK, A.APh1 + row0 * H, H, pbuf, bufB, S8_LD);
+    s8_sync();
+    s8_store(bufB, S8_LD, H, A.dK1 + row0 * H, H);
+}

@@ -58,8 +58,9 @@ def test_one_update_on_identical_minibatch_golden():
     # relative check on the well-conditioned entries as well
     big = np.abs(g["critic_grads_step1"]) > 1e-3 * np.abs(g["critic_grads_step1"]).max()
     assert np.allclose(gc[big], g["critic_grads_step1"][big], rtol=2e-3, atol=0)
-    assert close(agent._get_flat(NET_ACTOR), g["actor_after_step1"], 2e-6)
-    assert close(agent._get_flat(NET_CRITIC), g["critic_after_step1"], 2e-6)
+    # lr = 1e-3: 5e-6 is half a percent of one Adam step
+    assert close(agent._get_flat(NET_ACTOR), g["actor_after_step1"], 5e-6)
+    assert close(agent._get_flat(NET_CRITIC), g["critic_after_step1"], 5e-6)
     m, v, step = agent.get_adam_state(NET_CRITIC)
     assert step == 1
     assert np.allclose(m, 0.1 * g["critic_grads_step1"], rtol=1e-3, atol=1e-9)
