@@ -92,6 +92,65 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #include "slab.h"
 #include "slab8.h"
 
+// Adam (torch.optim.Adam, _single_tensor_adam, no weight decay / amsgrad) on one arena element, plus the
+// fragment-ordered copies of the slab engines.  Shared by k_adam_frag and the weight-gradient GEMM epilogue
+// (single-rank runs fuse the optimizer into the GEMM; data-parallel runs all-reduce the gradients in between).
+struct AdamFuse {
+    float *p, *m, *v, *fragF, *fragD;
+    const float *grads_base;          // arena origin of the gradient buffer the GEMM writes
+    AgentDevState *st;
+    ArenaMap am;
+    int n_actor;
+    float w, b2, omb2, eps;
+    const float *part;                // per-slab loss partials
+    int nslab, B, act_dim;
+    float action_l2;
+    float *loss_log;
+};
+
+__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
+    const float neg_step_size = (idx < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
+    const float bc2_sqrt = F.st->bc2_sqrt;
+    float mi = F.m[idx], vi = F.v[idx];
+    mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
+    vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float sq = (float)__dsqrt_rn((double)vi);                             // correctly rounded float32 sqrt
+    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), F.eps);
+    const float pn = __fadd_rn(F.p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
+    F.p[idx] = pn;
+    F.m[idx] = mi;
+    F.v[idx] = vi;
+    int of, od;
+    frag_offsets_any(F.am, idx, of, od);
+    if (of >= 0) F.fragF[of] = pn;
+    if (od >= 0) F.fragD[od] = pn;
+}
+
+// loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic)
+__device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
+    const int lane = threadIdx.x;
+    float tc = 0.f, tq = 0.f, tl = 0.f;
+    for (int s = lane; s < F.nslab; s += 64) {
+        tc += F.part[s];
+        tq += F.part[F.nslab + s];
+        tl += F.part[2 * F.nslab + s];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        tc += __shfl_down(tc, o);
+        tq += __shfl_down(tq, o);
+        tl += __shfl_down(tl, o);
+    }
+    if (lane == 0) {
+        const float invB = 1.0f / (float)F.B;
+        const long long k = F.st->n_logged;
+        F.loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + F.action_l2 * (tl / (float)(F.B * F.act_dim));
+        F.loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
+        F.st->n_logged = k + 1;
+    }
+}
+
+#include "gemm_lds.h"
+
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
 struct hp_agent {
@@ -144,8 +203,6 @@ struct hp_agent {
 //                         dW = dY^T X                 (A = dY, a_si = 1, a_sk = ldy;  B = X, b_sj = 1, b_sk = ldx)
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l & 15][k = l >> 4] and
 // B[k = l >> 4][j = l & 15]; accumulator register r holds D[row = 4 * (l >> 4) + r][col = l & 15].
-#include "gemm_lds.h"
-
 struct Acc {
     f32x4 c00, c01, c10, c11;
     float as0, as1;
@@ -441,53 +498,11 @@ __global__ void k_polyak(float *__restrict__ tgt, const float *__restrict__ src,
 }
 
 // slab engine: Adam that also refreshes the fragment-ordered copies and finishes the loss log
-__global__ __launch_bounds__(256) void k_adam_frag(float *__restrict__ p, const float *__restrict__ g,
-                                                   float *__restrict__ m, float *__restrict__ v, float *fragF,
-                                                   float *fragD, int n, int n_actor, float w, float b2, float omb2,
-                                                   float epsf, AgentDevState *st, const ArenaMap am,
-                                                   const float *__restrict__ part, int nslab, int B, int act_dim,
-                                                   float action_l2, float *loss_log) {
+__global__ __launch_bounds__(256) void k_adam_frag(const AdamFuse F, const float *__restrict__ g, int n) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic);
-        // a single thread walking the partials serialised ~16 cold loads behind the whole kernel
-        const int lane = threadIdx.x;
-        float tc = 0.f, tq = 0.f, tl = 0.f;
-        for (int s = lane; s < nslab; s += 64) {
-            tc += part[s];
-            tq += part[nslab + s];
-            tl += part[2 * nslab + s];
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            tc += __shfl_down(tc, o);
-            tq += __shfl_down(tq, o);
-            tl += __shfl_down(tl, o);
-        }
-        if (lane == 0) {
-            const float invB = 1.0f / (float)B;
-            const long long k = st->n_logged;
-            loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + action_l2 * (tl / (float)(B * act_dim));
-            loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
-            st->n_logged = k + 1;
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     if (idx >= n) return;
-    const float neg_step_size = (idx < n_actor) ? st->neg_step_actor : st->neg_step_critic;
-    const float bc2_sqrt = st->bc2_sqrt;
-    const float gi = g[idx];
-    float mi = m[idx], vi = v[idx];
-    mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));
-    vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
-    const float sq = (float)__dsqrt_rn((double)vi);
-    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), epsf);
-    const float pn = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
-    p[idx] = pn;
-    m[idx] = mi;
-    v[idx] = vi;
-    int of, od;
-    frag_offsets_any(am, idx, of, od);
-    if (of >= 0) fragF[of] = pn;
-    if (od >= 0) fragD[od] = pn;
+    adam_apply(F, idx, g[idx]);
 }
 
 __global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__ src, float *fragFT, int n,
@@ -643,7 +658,8 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     double future_p = 0.0;
 };
 
-static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc);
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam);
+static AdamFuse adam_fuse(hp_agent *a);
 
 // layer-per-launch engine: forwards + losses + backwards of one update, inputs in XA/XP/XT/R (18 launches)
 static int enqueue_forward_backward_layers(hp_agent *a) {
@@ -779,8 +795,17 @@ static int enqueue_forward_backward_layers(hp_agent *a) {
 static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq);
 
 // one update's forwards + backwards.  gc == nullptr: the minibatch is already staged in XA/XP/XT/R.
-static int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr) {
-    if (a->slab) return enqueue_forward_backward_slab(a, gc);   // gather fused into the forward kernel
+// fuse_adam: the optimizer step follows immediately on this rank (no gradient exchange): the slab engines then apply
+// it in the weight-gradient GEMM's epilogue and the caller must NOT enqueue Adam again (returns that via *fused).
+static int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fuse_adam = false,
+                                    bool *fused = nullptr) {
+    // Measured: applying Adam in the weight-gradient GEMM's epilogue (k_gemm_lds_adam) is SLOWER than the separate
+    // elementwise kernel, 92.9 vs 67.5 us per update: the optimizer's cold reads of p/m/v and its float64 sqrt/divide
+    // chains run at the GEMM's low occupancy (2 workgroups per CU, 256 epilogue threads each).  Kept for A/B only.
+    static const bool kFuseAdam = [] { const char *e = getenv("RLARM_FUSE_ADAM"); return e && e[0] == '1'; }();
+    fuse_adam = fuse_adam && kFuseAdam;
+    if (fused) *fused = a->slab && fuse_adam;
+    if (a->slab) return enqueue_forward_backward_slab(a, gc, fuse_adam);   // gather fused into the forward kernel
     if (gc) HP_TRY(enqueue_gather(a, gc->b, gc->on, gc->gn, gc->plan, gc->sq));
     return enqueue_forward_backward_layers(a);
 }
@@ -804,7 +829,7 @@ static int enqueue_relayout(hp_agent *a, bool targets) {
 }
 
 // slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
-static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
@@ -874,21 +899,33 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc) {
         add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
         add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
         add_dw(L, a->dK1, H, H, a->XP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
-        HP_TRY(launch_group(a, L, PROF_DW));
+        if (fuse_adam) {
+            ProfScope ps(a, PROF_DW);
+            hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, adam_fuse(a));
+            HP_CHECK_HIP(hipGetLastError());
+        } else {
+            HP_TRY(launch_group(a, L, PROF_DW));
+        }
     }
     return HP_OK;
+}
+
+static AdamFuse adam_fuse(hp_agent *a) {
+    AdamFuse F;
+    F.p = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
+    F.grads_base = a->grads; F.st = a->d_state; F.am = arena_map(a); F.n_actor = a->la.total;
+    F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
+    F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
+    F.part = a->part; F.nslab = a->Mp / (a->slab8 ? S8_ROWS : SL_ROWS); F.B = a->B; F.act_dim = a->cfg.act_dim;
+    F.action_l2 = (float)a->cfg.action_l2; F.loss_log = a->loss_log;
+    return F;
 }
 
 static int enqueue_adam(hp_agent *a) {
     ProfScope ps(a, PROF_ADAM);
     const int n = a->n_arena;
     if (a->slab) {
-        hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->params, a->grads,
-                           a->adam_m, a->adam_v, a->fragF, a->fragD, n, a->la.total,
-                           (float)(1.0 - a->cfg.adam_beta1), (float)a->cfg.adam_beta2,
-                           (float)(1.0 - a->cfg.adam_beta2), (float)a->cfg.adam_eps, a->d_state, arena_map(a), a->part,
-                           a->Mp / (a->slab8 ? S8_ROWS : SL_ROWS), a->B, (int)a->cfg.act_dim, (float)a->cfg.action_l2,
-                           a->loss_log);
+        hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n);
         HP_CHECK_HIP(hipGetLastError());
         return HP_OK;
     }
@@ -951,8 +988,9 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             gc.next_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
             gc.future_p = future_p;
         }
-        HP_TRY(enqueue_forward_backward(a, &gc));
-        if (with_adam) HP_TRY(enqueue_adam(a));
+        bool fused = false;
+        HP_TRY(enqueue_forward_backward(a, &gc, with_adam, &fused));
+        if (with_adam && !fused) HP_TRY(enqueue_adam(a));
     }
     return HP_OK;
 }
@@ -1156,8 +1194,9 @@ int hp_agent_update_minibatch(hp_agent *a, const float *x, const float *x_next, 
     HP_CHECK_HIP(hipMemcpyAsync(a->XT, hxt.data(), hxt.size() * 4, hipMemcpyHostToDevice, s));
     HP_CHECK_HIP(hipMemcpyAsync(a->R, hr.data(), hr.size() * 4, hipMemcpyHostToDevice, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
-    HP_TRY(enqueue_forward_backward(a));
-    HP_TRY(enqueue_adam(a));
+    bool fused = false;
+    HP_TRY(enqueue_forward_backward(a, nullptr, true, &fused));
+    if (!fused) HP_TRY(enqueue_adam(a));
     a->host_steps += 1;
     if (losses_host) HP_TRY(hp_agent_get_losses(a, losses_host, 1));
     else HP_CHECK_HIP(hipStreamSynchronize(s));

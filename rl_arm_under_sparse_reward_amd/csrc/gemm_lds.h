@@ -57,7 +57,12 @@ __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag,
     return make_float4(p[0], p[GL_KMAJ_LD], p[2 * GL_KMAJ_LD], p[3 * GL_KMAJ_LD]);
 }
 
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) {
+// ADAM = true (single-rank weight-gradient launch of the slab engines): the epilogue applies the optimizer step to
+// the tile it just produced (gradient still written out for inspection), and workgroup 0 finishes the loss log --
+// one launch and one cold pass over p/m/v less per update.  Data-parallel runs use ADAM = false + k_adam_frag so the
+// gradients can be all-reduced in between.
+template <bool ADAM>
+__device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
     __shared__ __attribute__((aligned(16))) float lds[2 * GL_OPERAND_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
     int pi = 0;
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) {
     const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    if (ADAM && blockIdx.x == 0 && tid < 64) loss_finalize(*F);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
     float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) {
 #pragma unroll
         for (int w = 0; w < GL_WAVES; ++w) s += bsum[w][tid];
         p.bias_grad[m0 + tid] = s;
+        if (ADAM) adam_apply(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, s);
     }
     if (!etile) return;
     float v[4];
@@ -184,4 +191,16 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) {
         for (int j = 0; j < 4; ++j)
             if (en + j < p.n_store) p.C[(long long)em * p.ldc + en + j] = v[j];
     }
+    if (ADAM) {
+        const int base = (int)(p.C - F->grads_base) + em * p.ldc + en;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (en + j < p.n_store) adam_apply(*F, base + j, v[j]);
+    }
+}
+
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }
+
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam(const GemmGroup grp, const AdamFuse F) {
+    gemm_lds_body<true>(grp, &F);
 }
