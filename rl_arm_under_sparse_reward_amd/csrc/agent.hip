@@ -114,9 +114,9 @@ __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi)
     float mi = F.m[idx], vi = F.v[idx];
     mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float sq = (float)__dsqrt_rn((double)vi);                             // correctly rounded float32 sqrt
-    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), F.eps);
-    const float pn = __fadd_rn(F.p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
+    const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
+    const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
+    const float pn = __fadd_rn(F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
     F.p[idx] = pn;
     F.m[idx] = mi;
     F.v[idx] = vi;
@@ -124,6 +124,36 @@ __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi)
     frag_offsets_any(F.am, idx, of, od);
     if (of >= 0) F.fragF[of] = pn;
     if (od >= 0) F.fragD[od] = pn;
+}
+
+// four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
+// latency of p / m / v is paid once, not once per element (scalar version: the store to p[idx] may alias the next
+// element's load, which serialises them)
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
+    const float neg_step_size = (idx0 < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
+    const float bc2_sqrt = F.st->bc2_sqrt;
+    const float4 p4 = *reinterpret_cast<const float4 *>(F.p + idx0);
+    const float4 m4 = *reinterpret_cast<const float4 *>(F.m + idx0);
+    const float4 v4 = *reinterpret_cast<const float4 *>(F.v + idx0);
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mm[j] = __fadd_rn(mm[j], __fmul_rn(F.w, __fsub_rn(g[j], mm[j])));
+        vv[j] = __fadd_rn(__fmul_rn(vv[j], F.b2), __fmul_rn(__fmul_rn(F.omb2, g[j]), g[j]));
+        const float sq = __fsqrt_rn(vv[j]);
+        const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
+        pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(neg_step_size, mm[j]), denom));
+    }
+    *reinterpret_cast<float4 *>(F.p + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int of, od;
+        frag_offsets_any(F.am, idx0 + j, of, od);
+        if (of >= 0) F.fragF[of] = pp[j];
+        if (od >= 0) F.fragD[od] = pp[j];
+    }
 }
 
 // loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic)
@@ -483,9 +513,9 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
     float mi = m[idx], vi = v[idx];
     mi = __fadd_rn(mi, __fmul_rn(w, __fsub_rn(gi, mi)));                 // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float sq = (float)__dsqrt_rn((double)vi);                     // correctly rounded float32 sqrt
-    const float denom = __fadd_rn((float)__ddiv_rn((double)sq, (double)bc2_sqrt), epsf);
-    p[idx] = __fadd_rn(p[idx], (float)__ddiv_rn((double)__fmul_rn(neg_step_size, mi), (double)denom));
+    const float sq = __fsqrt_rn(vi);                     // correctly rounded float32 sqrt
+    const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), epsf);
+    p[idx] = __fadd_rn(p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
     m[idx] = mi;
     v[idx] = vi;
 }

@@ -193,9 +193,13 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
     }
     if (ADAM) {
         const int base = (int)(p.C - F->grads_base) + em * p.ldc + en;
+        if (en + 3 < p.n_store) {
+            adam_apply4(*F, base, v);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (en + j < p.n_store) adam_apply(*F, base + j, v[j]);
+            for (int j = 0; j < 4; ++j)
+                if (en + j < p.n_store) adam_apply(*F, base + j, v[j]);
+        }
     }
 }
 
