@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--replay-k", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
@@ -148,6 +148,15 @@ def profile_kernels(r: Runner, cycles=3):
     for i, nm in enumerate(names):
         ms, cnt = out[2 * i], out[2 * i + 1]
         prof[nm] = {"ms_per_step": ms / steps, "launches_per_step": cnt / steps, "avg_us": (1e3 * ms / cnt) if cnt else 0.0}
+    # calibration: what an event pair around ONE eager launch of a trivial kernel reads on this stream (the
+    # bracketing overhead contained in every avg_us above; rocprofv3 kernel durations do not contain it)
+    ctx = ag.ctx if hasattr(ag, "ctx") else _lib.Context.default()
+    us = C.c_double()
+    tot = 0.0
+    for _ in range(20):
+        _lib.check(ctx.lib.hp_ctx_launch_floor(ctx.h, 1, 0, C.byref(us)))
+        tot += us.value
+    prof["_event_pair_trivial_us"] = tot / 20
     return prof
 
 
@@ -171,14 +180,15 @@ def cpu_baseline(a, seconds):
     update_normalizers(on, gn, [x[:2] for x in eps], fp, rs)
     res = {}
     cores = os.cpu_count() or 1
-    for threads in sorted({1, cores}):
+    tried = sorted({1, min(8, cores), min(32, cores), cores})   # torch intra-op threads; best one is reported
+    for threads in tried:
         torch.set_num_threads(threads)
         learner = oupd.DDPGLearner(oupd.init_actor(27, 3, 4, 0), oupd.init_critic(27, 3, 4, 1))
         for _ in range(5):
             tr, _ = st.sample(a.batch, fp, rs)
             learner.update(*oupd.minibatch_tensors(tr, on, gn))
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds / 2:
+        while time.perf_counter() - t0 < seconds / len(tried):
             tr, _ = st.sample(a.batch, fp, rs)
             learner.update(*oupd.minibatch_tensors(tr, on, gn))
             n += 1
@@ -200,7 +210,7 @@ def cpu_baseline(a, seconds):
         "value": round(res[best][0], 1), "unit": "transitions/s", "cores": best, "kind": "port",
         "sample": f"{res[best][1]} sample+update steps at batch {a.batch} on a {n_eps}-episode buffer "
                   f"({res[best][2]:.1f} s), oracle = numpy legacy-RNG sampler + torch-CPU update",
-        "value_1_thread": round(res[1][0], 1), "host_cpu": model, "host_cores": cores,
+        "value_by_threads": {str(k): round(v[0], 1) for k, v in res.items()}, "host_cpu": model, "host_cores": cores,
     }
 
 
@@ -273,16 +283,29 @@ def main():
                 per[k] = {"kernel": kern[k], "avg_launch_us": round(1e3 * ms / n, 3), "launches_per_step": round(n, 2),
                           "flop_per_launch": round(2.0 * m * a.batch / n, 1), "achieved_tflops": round(tf, 3),
                           "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5)}
+        ev_floor = prof.pop("_event_pair_trivial_us", None)
         dom = max(per, key=lambda k: prof[k]["ms_per_step"]) if per else None
+        # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE
+        # runs of this same command at batch 256, gfx950 FETCH x2 correction); null for any other configuration
+        pmc = {}
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if a.batch == 256 and os.environ.get("RLARM_ENGINE", "slab8") == "slab8" and os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
+        for k in per:
+            per[k]["traffic_hbm_bytes_per_launch"] = pmc.get(per[k]["kernel"].split()[0])
         if dom:
             out["roofline"] = {
                 "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": None,
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
+                "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
                 "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
+                "event_pair_trivial_kernel_us": None if ev_floor is None else round(ev_floor, 3),
                 "note": "dominant kernel by time; FP32 v_mfma_f32_4x4x1_16b_f32 (8-row slabs).  At batch 256 only 32 slabs x "
                         "2-3 chains (64-96 of 256 CUs) have work; a 256x256 layer costs a workgroup ~3.5 us against 1.9 us "
                         "of MFMA issue and 2.1 us of LDS-DMA weight streaming (DESIGN.md 3.1); durations are HIP-event "
-                        "pairs around each eager launch on the launch stream",
+                        "pairs around each eager launch on the launch stream and include the bracketing overhead reported as "
+                        "event_pair_trivial_kernel_us (rocprofv3 kernel durations in profiles/ are shorter by about that much)",
                 "all_matrix_kernels": per,
             }
         s_ms = prof["sample"]["ms_per_step"]

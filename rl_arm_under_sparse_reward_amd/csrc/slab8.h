@@ -24,6 +24,11 @@
 #define S8_LD 260
 #define S8_LDX 52
 #define S8_RING 12
+#ifdef SLAB_TIMELINE
+#define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define S8_STAMP(k) do { } while (0)
+#endif
 
 __host__ __device__ __forceinline__ int frag8_fwd_index(int n, int k, int K) {
     return (((n >> 6) * (K >> 2) + (k >> 2)) << 8) + ((n & 63) << 2) + (k & 3);
@@ -108,23 +113,29 @@ __device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, cons
     for (int t = 0; t < S8_RING; ++t) s8_ring_issue(ring, rbase, wlayer, cg, b0, t);
 }
 
-template <int T, bool HAS_NEXT>   // block T of the 32 this wave consumes
+// Block T of the 32 this wave consumes.  The weight operand is software-pipelined through registers: the LDS read of
+// block T+1 is issued BEFORE the 8 MFMAs of block T, so its latency hides under this wave's own matrix work instead
+// of being exposed once per block (with two waves per SIMD the other wave covered only part of it).
+template <int T, bool HAS_NEXT>
 __device__ __forceinline__ void s8_ring_step(f32x4 &c0, f32x4 &c1, RingSlot *ring, int rbase, const float *wlayer,
                                              const float *nxt, int cg, int b0, const float (&a0)[8],
-                                             const float (&a1)[8]) {
-    constexpr int left = 32 - T;
-    constexpr int inflight = HAS_NEXT ? S8_RING : (left < S8_RING ? left : S8_RING);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight - 1) : "memory");
-    const float4 b = ring[(rbase + T) % S8_RING][threadIdx.x & 63];
-    if constexpr (T + S8_RING < 32) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot read done before the DMA refills it
-        s8_ring_issue(ring, rbase, wlayer, cg, b0, T + S8_RING);
-    } else if constexpr (HAS_NEXT) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        s8_ring_issue(ring, rbase + 32, nxt, cg, b0, T + S8_RING - 32);
+                                             const float (&a1)[8], const float4 bcur) {
+    float4 bnext = bcur;
+    if constexpr (T + 1 < 32) {
+        // DMA blocks possibly outstanding here: T+1 .. T+R-1 (fewer at the tail of a chain's last layer)
+        constexpr int out = HAS_NEXT ? S8_RING - 1 : ((31 - T) < S8_RING - 1 ? (31 - T) : S8_RING - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(out - 1) : "memory");
+        bnext = ring[(rbase + T + 1) % S8_RING][threadIdx.x & 63];
     }
-    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b);
-    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
+    if constexpr (T + S8_RING < 32 || HAS_NEXT) {
+        // slot of block T is free once ITS read (one LDS op older than bnext's) has returned
+        if constexpr (T + 1 < 32) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (T + S8_RING < 32) s8_ring_issue(ring, rbase, wlayer, cg, b0, T + S8_RING);
+        else s8_ring_issue(ring, rbase + 32, nxt, cg, b0, T + S8_RING - 32);
+    }
+    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], bcur);
+    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bnext);
 }
 
 // combine the two reduction halves and run the epilogue.  c0/c1: this wave's partial [row group][row][col = lane]
@@ -180,26 +191,38 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     float a0[8], a1[8];
     s8_aload<8>(lin, ld_in, 4 * b0, a0, a1);
-    if (nxt) s8_ring_step<0, true>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
-    else s8_ring_step<0, false>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S8_RING - 1) : "memory");   // block 0 has landed
+    const float4 bfirst = ring[rbase % S8_RING][threadIdx.x & 63];
+    if (nxt) s8_ring_step<0, true>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bfirst);
+    else s8_ring_step<0, false>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bfirst);
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
     s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
 }
 
 template <int T, int HALF>
-__device__ __forceinline__ void s8_small_steps(f32x4 &c0, f32x4 &c1, const float *wlayer, int cg, int nb4, int b0,
-                                               const float (&a0)[8], const float (&a1)[8]) {
-    const float4 b = *s8_wblock(wlayer, cg, nb4, b0 + T);
-    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b);
-    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, c1, wlayer, cg, nb4, b0, a0, a1);
+__device__ __forceinline__ void s8_small_steps(f32x4 &c0, f32x4 &c1, const float4 (&b)[6], const float (&a0)[8],
+                                               const float (&a1)[8]) {
+    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b[T]);
+    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, c1, b, a0, a1);
 }
 
-// small layer (reduction length Kred = 16 / 32 / 48): weights straight from global, no ring
-__device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float *__restrict__ wlayer,
-                                               int epi, const float *__restrict__ aux, int ldaux, float *pbuf,
-                                               float *lout, int ld_out) {
+// All weight blocks of a small layer (reduction length Kred = 16 / 32 / 48 -> 2 / 4 / 6 blocks per reduction half) in
+// ONE batch of loads, issued by the caller as early as it can (kernel entry): the loads are cold, and left to the
+// compiler they end up as load -> wait -> MFMA once per block with one destination register.
+__device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlayer, int Kred, float4 (&b)[6]) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, kh = wave >> 2;
+    const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+        if (t < half) b[t] = *s8_wblock(wlayer, cg, nb4, b0 + t);
+}
+
+// small layer: weights already in registers (s8_small_prefetch), no ring
+__device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
+                                               const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
+                                               int ld_out) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
     s8_epi_load(e, epi, aux, ldaux);
@@ -207,30 +230,31 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
     float a0[8], a1[8];
     s8_aload<2>(lin, ld_in, 4 * b0, a0, a1);   // at most 24 indices per half; lanes past the row end read unused padding
     switch (half) {
-        case 2: s8_small_steps<0, 2>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
-        case 4: s8_small_steps<0, 4>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
-        case 6: s8_small_steps<0, 6>(c0, c1, wlayer, cg, nb4, b0, a0, a1); break;
+        case 2: s8_small_steps<0, 2>(c0, c1, b, a0, a1); break;
+        case 4: s8_small_steps<0, 4>(c0, c1, b, a0, a1); break;
+        case 6: s8_small_steps<0, 6>(c0, c1, b, a0, a1); break;
         default: break;   // other input widths are rejected on the host
     }
     s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
 }
 
-// 8 x nout dot products of length 256 (nout <= 4): wave r owns row r, lane p the reduction indices 4p..4p+3.
-// w(j) must return the float4 of weights for output j at those indices.  Result valid in lane 0.
-template <class WF>
-__device__ __forceinline__ void s8_rowdots(const float *lin, int ld_in, int nout, WF w, float (&out)[4]) {
+// 8 x nout dot products of length 256 (nout <= 4): wave r owns row r, lane p the reduction indices 4p..4p+3;
+// wv[j] = this lane's float4 of weights for output j (loaded by the caller well ahead of time).  On return lane j
+// (j < nout) holds output j of the wave's row (other lanes: unspecified).
+__device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int nout, const float4 (&wv)[4]) {
     const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = threadIdx.x & 63;
     const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
+    float mine = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float s = 0.f;
         if (j < nout) {
-            const float4 wv = w(j, p);
-            s = (h.x * wv.x + h.y * wv.y) + (h.z * wv.z + h.w * wv.w);
+            float s = (h.x * wv[j].x + h.y * wv[j].y) + (h.z * wv[j].z + h.w * wv[j].w);
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            const float tot = __shfl(s, 0);
+            if (p == j) mine = tot;
         }
-        out[j] = s;
     }
+    return mine;
 }
 
 __device__ __forceinline__ void s8_store(const float *l, int ld, int width, float *g, int ldg) {
@@ -298,12 +322,13 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, int wh
 }
 
 // xin (K1 wide) -> h1 -> h2 -> h3.  Ring: layer 2 in flight on entry, `nxt` on exit.
-__device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, const float *wf, const float *canon, int H,
+__device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, const float4 (&wb1)[6], const float *wf,
+                                         const float *canon, int H,
                                          float *bufA, float *bufB, float *pbuf, float *g1, float *g2, float *g3,
                                          size_t row0, RingSlot *ring, int &rbase, const float *nxt,
                                          unsigned long long *tl, int tbase) {
     SLAB_STAMP(tl, tbase);
-    s8_small_layer(xin, S8_LDX, l.K1, wf + l.w1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD);
+    s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD);
     s8_sync();
     SLAB_STAMP(tl, tbase + 1);
     if (g1) s8_store(bufA, S8_LD, H, g1 + row0 * H, H);
@@ -336,63 +361,79 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (slab == 0 && tid == 0) A.tl[chain * 32] = wall_clock64();
 #endif
     if (chain == 1) {   // critic(x, a)
+        float4 wb[6], wq[4];
+        s8_small_prefetch(A.online.wf + ca + lc.w1, lc.K1, wb);
+        wq[0] = *reinterpret_cast<const float4 *>(A.online.canon + ca + lc.w4 + 4 * lane);
+        const float bq = A.online.canon[ca + lc.b4];
+        __builtin_amdgcn_sched_barrier(0);
         if (A.gs.plan) s8_gather(xin, A.gs, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
         else s8_load(xin, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
         s8_ring_prologue(ring, rbase, A.online.wf + ca + lc.w2);
         s8_sync();
-        s8_trunk(xin, lc, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0, ring,
-                 rbase, nullptr, A.tl, 1);
-        float q[4];
-        const float *w4 = A.online.canon + ca + lc.w4;
-        s8_rowdots(bufA, S8_LD, 1, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, q);
-        if (lane == 0) A.QA[(row0 + wave) * 16] = q[0] + A.online.canon[ca + lc.b4];
+        s8_trunk(xin, lc, wb, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0,
+                 ring, rbase, nullptr, A.tl, 1);
+        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
+        if (lane == 0) A.QA[(row0 + wave) * 16] = q + bq;
         return;
     }
     const bool tgt = (chain == 0);
     const SlabNetPtrs &net = tgt ? A.target : A.online;
     float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
+    // everything that does not depend on the activations is fetched now: first-layer weight blocks of both trunks,
+    // the head rows and biases (cold loads whose latency would otherwise sit on the chain once per use)
+    float4 wba[6], wbc[6], wh[4], wq[4];
+    s8_small_prefetch(net.wf + la.w1, la.K1, wba);
+    s8_small_prefetch(net.wf + ca + lc.w1, lc.K1, wbc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < A.act_dim) wh[j] = *reinterpret_cast<const float4 *>(net.canon + la.w4 + j * H + 4 * lane);
+    wq[0] = *reinterpret_cast<const float4 *>(net.canon + ca + lc.w4 + 4 * lane);
+    const float bh = (lane < A.act_dim) ? net.canon[la.b4 + lane] : 0.f;
+    const float bq = net.canon[ca + lc.b4];
+    __builtin_amdgcn_sched_barrier(0);
     if (A.gs.plan) s8_gather(xin, A.gs, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
     else s8_load(xin, S8_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
     s8_ring_prologue(ring, rbase, net.wf + la.w2);
     s8_sync();
-    s8_trunk(xin, la, net.wf, net.canon, H, bufA, bufB, pbuf, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
+    s8_trunk(xin, la, wba, net.wf, net.canon, H, bufA, bufB, pbuf, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
              tgt ? nullptr : A.APh3, row0, ring, rbase, net.wf + ca + lc.w2, A.tl, 1);
     SLAB_STAMP(A.tl, 5);
-    {   // actor head: tanh -> action block of the critic input (models.py:24, :38)
-        float z[4];
-        const float *w4 = net.canon + la.w4;
-        s8_rowdots(bufA, S8_LD, A.act_dim, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, z);
-        if (lane == 0) {
-            for (int j = 0; j < A.act_dim; ++j) {
-                const float th = tanhf(z[j] + net.canon[la.b4 + j]);
-                const float u = (A.max_action * th) / A.max_action;
-                xin[wave * S8_LDX + A.act_off + j] = u;
-                X[(row0 + wave) * A.ldx + A.act_off + j] = u;
-                if (!tgt) A.TP[(row0 + wave) * 16 + j] = th;
-            }
+    {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
+        const float z = s8_rowdots(bufA, S8_LD, A.act_dim, wh);
+        if (lane < A.act_dim) {
+            const float th = tanhf(z + bh);
+            const float u = (A.max_action * th) / A.max_action;
+            xin[wave * S8_LDX + A.act_off + lane] = u;
+            X[(row0 + wave) * A.ldx + A.act_off + lane] = u;
+            if (!tgt) A.TP[(row0 + wave) * 16 + lane] = th;
         }
     }
     s8_sync();
     SLAB_STAMP(A.tl, 7);
-    s8_trunk(xin, lc, net.wf + ca, net.canon + ca, H, bufA, bufB, pbuf, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
+    s8_trunk(xin, lc, wbc, net.wf + ca, net.canon + ca, H, bufA, bufB, pbuf, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
              tgt ? nullptr : A.CPh3, row0, ring, rbase, nullptr, A.tl, 8);
     {
-        float q[4];
-        const float *w4 = net.canon + ca + lc.w4;
-        s8_rowdots(bufA, S8_LD, 1, [&](int j, int p) { return *reinterpret_cast<const float4 *>(w4 + j * H + 4 * p); }, q);
+        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
         float *Q = tgt ? A.QT : A.QP;
-        if (lane == 0) Q[(row0 + wave) * 16] = q[0] + net.canon[ca + lc.b4];
+        if (lane == 0) Q[(row0 + wave) * 16] = q + bq;
     }
     SLAB_STAMP(A.tl, 13);
 }
 
-// dY of the top hidden layer from a per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0)
-__device__ __forceinline__ void s8_head_bwd(const float *dq_rows, const float *__restrict__ w4row,
-                                            const float *__restrict__ h3, int H, float *lout) {
-    for (int f = threadIdx.x; f < S8_ROWS * H; f += S8_THREADS) {
-        const int r = f / H, c = f - r * H;
-        lout[r * S8_LD + c] = (h3[(size_t)r * H + c] > 0.f) ? dq_rows[r] * w4row[c] : 0.f;
-    }
+// dY of the top hidden layer from a per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0).
+// H == 256 (checked on the host): a thread owns column tid & 255 of rows (tid >> 8) + 2 i, i < 4.  The operands are
+// fetched at kernel entry (s8_head_bwd_fetch) so their latency overlaps the loss prologue.
+struct S8HeadOps { float w; float h[4]; };
+__device__ __forceinline__ void s8_head_bwd_fetch(S8HeadOps &o, const float *__restrict__ w4row, const float *__restrict__ h3) {
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+    o.w = w4row[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.h[i] = h3[(size_t)(r0 + 2 * i) * 256 + c];
+}
+__device__ __forceinline__ void s8_head_bwd(const float *dq_rows, const S8HeadOps &o, float *lout) {
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lout[(r0 + 2 * i) * S8_LD + c] = (o.h[i] > 0.f) ? dq_rows[r0 + 2 * i] * o.w : 0.f;
 }
 
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bwd_slab8(const BwdSlabArgs A) {
@@ -422,6 +463,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         A.st->step += 1;
         adam_prepare(A.st, A.adam);
     }
+    S8_STAMP(0);
+    S8HeadOps hops;
+    s8_head_bwd_fetch(hops, A.online.canon + ca + lc.w4, (chain == 0 ? A.CAh3 : A.CPh3) + row0 * H);
     if (chain == 0) {
         // ---- critic loss (ddpg_agent.py:255-263)
         s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
@@ -441,20 +485,47 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (tid == 0) A.part[slab] = sq;
         }
         s8_sync();
-        s8_head_bwd(dq, A.online.canon + ca + lc.w4, A.CAh3 + row0 * H, H, bufA);
+        S8_STAMP(1);
+        s8_head_bwd(dq, hops, bufA);
         s8_sync();
+        S8_STAMP(2);
         s8_store(bufA, S8_LD, H, A.dA3 + row0 * H, H);
         s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H,
                      pbuf, bufB, S8_LD);
         s8_sync();
+        S8_STAMP(3);
         s8_store(bufB, S8_LD, H, A.dA2 + row0 * H, H);
         s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, nullptr, SE_MASK, A.CAh1 + row0 * H, H, pbuf, bufA,
                      S8_LD);
         s8_sync();
+        S8_STAMP(4);
         s8_store(bufA, S8_LD, H, A.dA1 + row0 * H, H);
+        S8_STAMP(5);
         return;
     }
     // ---- actor loss (ddpg_agent.py:265-267)
+    // operands of the action-gradient stage and of the actor's head layer, fetched now (cold, strided: the 16 first-
+    // layer weights W1c[4p + c][act_off + j] this lane needs, its row's action / tanh values, the 2 head-layer blocks)
+    const int K1c = lc.K1, ad = A.act_dim;
+    float4 w1g[4], wb4[6];
+    {
+        const float *w1 = A.online.canon + ca + lc.w1 + A.act_off;   // W1c[n][act_off + j], row stride K1
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < ad)
+                w1g[j] = make_float4(w1[(size_t)(4 * lane) * K1c + j], w1[(size_t)(4 * lane + 1) * K1c + j],
+                                     w1[(size_t)(4 * lane + 2) * K1c + j], w1[(size_t)(4 * lane + 3) * K1c + j]);
+    }
+    s8_small_prefetch(A.online.wd + la.w4, 16, wb4);
+    float u_mine = 0.f, th_mine = 0.f;
+    {
+        const size_t m = row0 + wave;
+        if (lane < ad && (int)m < A.B) {
+            u_mine = A.XP[m * A.ldx + A.act_off + lane];
+            th_mine = A.TP[m * 16 + lane];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
     if (tid < S8_ROWS) {
         const size_t m = row0 + tid;
@@ -476,51 +547,47 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     s8_sync();
-    s8_head_bwd(dq, A.online.canon + ca + lc.w4, A.CPh3 + row0 * H, H, bufA);
+    S8_STAMP(1);
+    s8_head_bwd(dq, hops, bufA);
     s8_sync();
+    S8_STAMP(2);
     s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, pbuf,
                  bufB, S8_LD);
     s8_sync();
+    S8_STAMP(3);
     s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, pbuf, bufA,
                  S8_LD);
     s8_sync();
-    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh
-        float s[4];
-        const float *w1 = A.online.canon + ca + lc.w1 + A.act_off;   // W1c[n][act_off + j], row stride K1
-        const int K1 = lc.K1, ad = A.act_dim;
-        // lane p covers n = 4p..4p+3; for output j gather the 4 weights W1c[4p + c][act_off + j]
-        s8_rowdots(bufA, S8_LD, ad, [&](int j, int p) {
-            return make_float4(w1[(size_t)(4 * p) * K1 + j], w1[(size_t)(4 * p + 1) * K1 + j],
-                               w1[(size_t)(4 * p + 2) * K1 + j], w1[(size_t)(4 * p + 3) * K1 + j]); }, s);
+    S8_STAMP(4);
+    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh; lane j owns action j
+        const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
         if (lane < 16) {
             const size_t m = row0 + wave;
-            float v = 0.f, sj = 0.f;   // s[] is only valid in lane 0: hand s[lane] to lane `lane`
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float b = __shfl(s[j], 0);
-                if (lane == j) sj = b;
-            }
+            float v = 0.f;
             if (lane < ad && (int)m < A.B) {
-                const float u = A.XP[m * A.ldx + A.act_off + lane];
-                const float th = A.TP[m * 16 + lane];
-                const float gu = A.action_l2 * (2.f * u / (float)(A.B * ad)) + sj;
+                const float gu = A.action_l2 * (2.f * u_mine / (float)(A.B * ad)) + sj;
                 const float gt = (gu / A.max_action) * A.max_action;
-                v = gt * (1.f - th * th);
+                v = gt * (1.f - th_mine * th_mine);
             }
             dz[wave * 20 + lane] = v;
             A.dZ[m * 16 + lane] = v;
         }
     }
     s8_sync();
+    S8_STAMP(5);
     // actor layer 4 backward: reduction over the 16 padded head outputs
-    s8_small_layer(dz, 20, 16, A.online.wd + la.w4, SE_MASK, A.APh3 + row0 * H, H, pbuf, bufB, S8_LD);
+    s8_small_layer(dz, 20, 16, wb4, SE_MASK, A.APh3 + row0 * H, H, pbuf, bufB, S8_LD);
     s8_sync();
+    S8_STAMP(6);
     s8_store(bufB, S8_LD, H, A.dK3 + row0 * H, H);
     s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + la.w3, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, pbuf, bufA,
                  S8_LD);
     s8_sync();
+    S8_STAMP(7);
     s8_store(bufA, S8_LD, H, A.dK2 + row0 * H, H);
     s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + la.w2, nullptr, SE_MASK, A.APh1 + row0 * H, H, pbuf, bufB, S8_LD);
     s8_sync();
+    S8_STAMP(8);
     s8_store(bufB, S8_LD, H, A.dK1 + row0 * H, H);
+    S8_STAMP(9);
 }
