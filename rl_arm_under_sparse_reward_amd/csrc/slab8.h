@@ -274,13 +274,19 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
 }
 
 // HER gather for the 8 rows of a slab (same arithmetic as slab_gather / k_gather_fused); 64 threads per row
-__device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, int which, size_t row0, int ldx, int act_off,
-                                          int act_dim, float max_action, float *Xout) {
+// this thread's row of the index plan (the first load of the kernel: everything else in the gather depends on it)
+__device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0) {
+    const size_t m = row0 + (threadIdx.x >> 6);
+    PlanRec rec = {0, 0, 1, 0};
+    if (G.plan && (int)m < G.B) rec = G.plan[m];
+    return rec;
+}
+
+__device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const PlanRec rec, int which, size_t row0, int ldx,
+                                          int act_off, int act_dim, float max_action, float *Xout) {
     const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t m = row0 + r;
     const bool live = (int)m < G.B;
-    PlanRec rec = {0, 0, 1, 0};
-    if (live) rec = G.plan[m];
     const long long e = rec.e;
     const int t = rec.t, od = G.obs_dim, gd = G.goal_dim;
     const double *obs_row = G.obs + (e * (G.T + 1) + t + (which == 0 ? 1 : 0)) * od;
@@ -360,13 +366,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #ifdef SLAB_TIMELINE
     if (slab == 0 && tid == 0) A.tl[chain * 32] = wall_clock64();
 #endif
+    const PlanRec rec = s8_plan_rec(A.gs, row0);
     if (chain == 1) {   // critic(x, a)
         float4 wb[6], wq[4];
         s8_small_prefetch(A.online.wf + ca + lc.w1, lc.K1, wb);
         wq[0] = *reinterpret_cast<const float4 *>(A.online.canon + ca + lc.w4 + 4 * lane);
         const float bq = A.online.canon[ca + lc.b4];
         __builtin_amdgcn_sched_barrier(0);
-        if (A.gs.plan) s8_gather(xin, A.gs, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
+        if (A.gs.plan) s8_gather(xin, A.gs, rec, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
         else s8_load(xin, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
         s8_ring_prologue(ring, rbase, A.online.wf + ca + lc.w2);
         s8_sync();
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const float bh = (lane < A.act_dim) ? net.canon[la.b4 + lane] : 0.f;
     const float bq = net.canon[ca + lc.b4];
     __builtin_amdgcn_sched_barrier(0);
-    if (A.gs.plan) s8_gather(xin, A.gs, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
+    if (A.gs.plan) s8_gather(xin, A.gs, rec, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
     else s8_load(xin, S8_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
     s8_ring_prologue(ring, rbase, net.wf + la.w2);
     s8_sync();
@@ -442,6 +449,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
     __shared__ float dq[S8_ROWS];
     __shared__ __attribute__((aligned(16))) float dz[S8_ROWS * 20];
+    __shared__ __attribute__((aligned(16))) float w1t[4 * 256];
     __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
     const int nslab = A.nslab;
     const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
@@ -464,18 +472,34 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         adam_prepare(A.st, A.adam);
     }
     S8_STAMP(0);
+    // per-row loss operands first (the loss is the head of the chain and vmcnt retires in order), then the prefetches
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, lu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < S8_ROWS && (int)(row0 + tid) < A.B) {
+        const size_t m = row0 + tid;
+        if (chain == 0) {
+            l0 = A.R[m];
+            l1 = A.QT[m * 16];
+            l2 = A.QA[m * 16];
+        } else {
+            l0 = A.QP[m * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < A.act_dim) lu[j] = A.XP[m * A.ldx + A.act_off + j];
+        }
+    }
     S8HeadOps hops;
     s8_head_bwd_fetch(hops, A.online.canon + ca + lc.w4, (chain == 0 ? A.CAh3 : A.CPh3) + row0 * H);
     if (chain == 0) {
         // ---- critic loss (ddpg_agent.py:255-263)
         s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
+        __builtin_amdgcn_sched_barrier(0);
         if (tid < S8_ROWS) {
             const size_t m = row0 + tid;
             float g = 0.f, sq = 0.f;
             if ((int)m < A.B) {
-                float y = A.R[m] + A.gamma * A.QT[m * 16];
+                float y = l0 + A.gamma * l1;
                 y = fminf(fmaxf(y, -A.clip_ret), 0.f);
-                const float d = y - A.QA[m * 16];
+                const float d = y - l2;
                 sq = d * d;
                 g = -2.f * d * invB;
             }
@@ -507,14 +531,13 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // operands of the action-gradient stage and of the actor's head layer, fetched now (cold, strided: the 16 first-
     // layer weights W1c[4p + c][act_off + j] this lane needs, its row's action / tanh values, the 2 head-layer blocks)
     const int K1c = lc.K1, ad = A.act_dim;
-    float4 w1g[4], wb4[6];
-    {
-        const float *w1 = A.online.canon + ca + lc.w1 + A.act_off;   // W1c[n][act_off + j], row stride K1
+    float4 wb4[6];
+    float w1n[4] = {0.f, 0.f, 0.f, 0.f};   // thread n < 256: W1c[n][act_off + j] (one line per n; staged in LDS as w1t[j][n])
+    if (tid < 256) {
+        const float *w1 = A.online.canon + ca + lc.w1 + (size_t)tid * K1c + A.act_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < ad)
-                w1g[j] = make_float4(w1[(size_t)(4 * lane) * K1c + j], w1[(size_t)(4 * lane + 1) * K1c + j],
-                                     w1[(size_t)(4 * lane + 2) * K1c + j], w1[(size_t)(4 * lane + 3) * K1c + j]);
+            if (j < ad) w1n[j] = w1[j];
     }
     s8_small_prefetch(A.online.wd + la.w4, 16, wb4);
     float u_mine = 0.f, th_mine = 0.f;
@@ -527,16 +550,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __builtin_amdgcn_sched_barrier(0);
     s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
+    __builtin_amdgcn_sched_barrier(0);
     if (tid < S8_ROWS) {
         const size_t m = row0 + tid;
         const bool live = (int)m < A.B;
         dq[tid] = live ? -invB : 0.f;
-        float sq = live ? A.QP[m * 16] : 0.f, su = 0.f;
+        float sq = live ? l0 : 0.f, su = 0.f;
         if (live)
-            for (int j = 0; j < A.act_dim; ++j) {
-                const float u = A.XP[m * A.ldx + A.act_off + j];
-                su += u * u;
-            }
+            for (int j = 0; j < A.act_dim; ++j) su += lu[j] * lu[j];
         for (int o = 4; o > 0; o >>= 1) {
             sq += __shfl_down(sq, o, 8);
             su += __shfl_down(su, o, 8);
@@ -545,6 +566,10 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             A.part[nslab + slab] = sq;
             A.part[2 * nslab + slab] = su;
         }
+    }
+    if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
     }
     s8_sync();
     S8_STAMP(1);
@@ -560,6 +585,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     S8_STAMP(4);
     {   // d L / d(action block of the critic input), then through the L2 penalty and tanh; lane j owns action j
+        float4 w1g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
         const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
         if (lane < 16) {
             const size_t m = row0 + wave;
