@@ -147,12 +147,24 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
     *reinterpret_cast<float4 *>(F.p + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    if (F.am.mode == 1) {
+        // slab8 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's row
+        // length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
         int of, od;
-        frag_offsets_any(F.am, idx0 + j, of, od);
-        if (of >= 0) F.fragF[of] = pp[j];
-        if (od >= 0) F.fragD[od] = pp[j];
+        frag8_offsets(F.am, idx0, of, od);
+        if (of >= 0) *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (od >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) F.fragD[od + 4 * j] = pp[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int of, od;
+            frag_offsets_any(F.am, idx0 + j, of, od);
+            if (of >= 0) F.fragF[of] = pp[j];
+            if (od >= 0) F.fragD[od] = pp[j];
+        }
     }
 }
 
@@ -535,6 +547,16 @@ __global__ __launch_bounds__(256) void k_adam_frag(const AdamFuse F, const float
     adam_apply(F, idx, g[idx]);
 }
 
+// 4 consecutive arena elements per thread (n % 4 == 0)
+__global__ __launch_bounds__(256) void k_adam_frag4(const AdamFuse F, const float *__restrict__ g, int n4) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    if (t >= n4) return;
+    const float4 g4 = *reinterpret_cast<const float4 *>(g + 4 * t);
+    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    adam_apply4(F, 4 * t, gv);
+}
+
 __global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__ src, float *fragFT, int n,
                               float one_minus, float polyak, const ArenaMap am) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -829,10 +851,11 @@ static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, c
 // it in the weight-gradient GEMM's epilogue and the caller must NOT enqueue Adam again (returns that via *fused).
 static int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fuse_adam = false,
                                     bool *fused = nullptr) {
-    // Measured: applying Adam in the weight-gradient GEMM's epilogue (k_gemm_lds_adam) is SLOWER than the separate
-    // elementwise kernel, 92.9 vs 67.5 us per update: the optimizer's cold reads of p/m/v and its float64 sqrt/divide
-    // chains run at the GEMM's low occupancy (2 workgroups per CU, 256 epilogue threads each).  Kept for A/B only.
-    static const bool kFuseAdam = [] { const char *e = getenv("RLARM_FUSE_ADAM"); return e && e[0] == '1'; }();
+    // Adam in the weight-gradient GEMM's epilogue (k_gemm_lds_adam).  The first version (one element at a time: four
+    // serialised cold round trips per thread for p/m/v) measured 92.9 vs 67.5 us per update and was parked; with four
+    // elements per thread (one float4 load per state array, float4 store into the forward fragment copy) it is the
+    // faster path, 57.2 vs 60.5 us, and the default.  RLARM_FUSE_ADAM=0 keeps the separate k_adam_frag4 launch for A/B.
+    static const bool kFuseAdam = [] { const char *e = getenv("RLARM_FUSE_ADAM"); return !(e && e[0] == '0'); }();
     fuse_adam = fuse_adam && kFuseAdam;
     if (fused) *fused = a->slab && fuse_adam;
     if (a->slab) return enqueue_forward_backward_slab(a, gc, fuse_adam);   // gather fused into the forward kernel
@@ -955,7 +978,10 @@ static int enqueue_adam(hp_agent *a) {
     ProfScope ps(a, PROF_ADAM);
     const int n = a->n_arena;
     if (a->slab) {
-        hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n);
+        if (n % 4 == 0 && a->la.total % 4 == 0)
+            hipLaunchKernelGGL(k_adam_frag4, dim3((n / 4 + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n / 4);
+        else
+            hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n);
         HP_CHECK_HIP(hipGetLastError());
         return HP_OK;
     }
@@ -1475,6 +1501,9 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
     HP_REQUIRE(a && out192, HP_ERR_INVALID, "hp_agent_debug_timeline: bad argument");
     HP_CHECK_HIP(hipMemcpyAsync(out192, a->timeline, 192 * 8, hipMemcpyDeviceToHost, a->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+#ifdef SLAB_TIMELINE   // weight-gradient GEMM stamps: first workgroup at [160..175], last at [176..191]
+    HP_CHECK_HIP(hipMemcpyFromSymbol(out192 + 160, HIP_SYMBOL(g_gemm_tl), 32 * 8));
+#endif
     return HP_OK;
 }
 

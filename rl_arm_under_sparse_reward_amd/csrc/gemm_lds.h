@@ -27,6 +27,13 @@
 #define GL_KMAJ_LD 36
 #define GL_OPERAND_FLOATS (GL_KC * GL_KMAJ_LD)  // 9216 floats = larger of the two images (rowK: 32*260 = 8320)
 
+#ifdef SLAB_TIMELINE   // debug build: first and last workgroup stamp the 100 MHz wall clock at stage boundaries
+__device__ unsigned long long g_gemm_tl[32];
+#define GL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_gemm_tl[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+#else
+#define GL_STAMP(k) do { } while (0)
+#endif
+
 // stage one 32 x kc operand chunk into LDS.  `valid` = number of real rows/cols (16 or 32).
 __device__ __forceinline__ void gl_stage(float *lds, const float *base, long long s_idx, long long s_k, int valid,
                                          int kc, bool rowk) {
@@ -74,6 +81,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
     const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    GL_STAMP(0);
     if (ADAM && blockIdx.x == 0 && tid < 64) loss_finalize(*F);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
@@ -102,6 +110,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         gl_stage(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
         gl_stage(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
         __syncthreads();
+        GL_STAMP(1);
         const int nS = kc >> 4;
         for (int S = wave; S < nS; S += GL_WAVES) {
             const float4 a0 = gl_frag(ldsA, a_rowk, 0, S, i, q), a1 = gl_frag(ldsA, a_rowk, 1, S, i, q);
@@ -119,6 +128,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
             }
         }
     }
+    GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
     float *my = lds + wave * (32 * 33);
 #pragma unroll
@@ -141,6 +151,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         }
     }
     __syncthreads();
+    GL_STAMP(3);
     if (want_bias_grad && tid < vm) {
         float s = 0.f;
 #pragma unroll
@@ -184,6 +195,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         }
         default: break;
     }
+    GL_STAMP(4);
     if (en + 3 < p.n_store) {
         *reinterpret_cast<float4 *>(p.C + (long long)em * p.ldc + en) = make_float4(v[0], v[1], v[2], v[3]);
     } else {

@@ -60,6 +60,10 @@ for ch, nm in ((0, "fwd T"), (1, "fwd A"), (2, "fwd P"), (3, "bwd critic"), (4, 
     v = [tl[ch * 32 + k] for k in range(16)]
     if v[0]:
         print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(16) if v[k]))
+for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
+    v = [tl[base + k] for k in range(8)]
+    if v[0]:
+        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-tl[160])/100:.1f}" for k in range(8) if v[k]))
 floor("after cycles")
 # eager path
 _lib.check(lib.hp_agent_sample_and_update(h, buf.h, on.h, gn.h, rng.h, 0.8, squared_threshold(0.05), 40)); ctx.synchronize()
