@@ -71,8 +71,6 @@ class Runner:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         self.ctx = _lib.Context(local)
-        if world > 1:
-            self.ctx.use_torch_stream()      # order our kernels with the RCCL collectives torch enqueues
         args = Args(batch_size=a.batch, buffer_size=a.episodes * 100, replay_k=a.replay_k, seed=125 + rank)
         self.rng = DeviceRandomState(args.seed, ctx=self.ctx)
         torch.manual_seed(0)                 # same initial networks on every rank (plus the broadcast)
@@ -95,7 +93,7 @@ class Runner:
         """Advance exactly k steps, including every cycle boundary crossed."""
         ag = self.agent
         while k > 0:
-            if self.in_cycle == 0 and k >= N_BATCHES and self.world == 1:
+            if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
                 self.cycle += 1
                 k -= N_BATCHES
@@ -265,7 +263,10 @@ def main():
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
                    "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
-                   "parallelism": f"dp{world}" + (" (RCCL grad SUM + normalizer MEAN all-reduce)" if world > 1 else ""),
+                   "parallelism": f"dp{world}" + (
+                       " (RCCL grad SUM all-reduce per update + normalizer MEAN per cycle, " +
+                       ("issued by the library inside the cycle hipGraph)" if r.agent._native_comm is not None
+                        else "issued through torch.distributed, host-driven loop)") if world > 1 else ""),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])]},
     }

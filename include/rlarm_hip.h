@@ -46,6 +46,7 @@ typedef struct hp_rng hp_rng;
 typedef struct hp_buffer hp_buffer;
 typedef struct hp_norm hp_norm;
 typedef struct hp_agent hp_agent;
+typedef struct hp_comm hp_comm;
 
 int hp_abi_version(void);
 const char *hp_last_error(void);
@@ -192,6 +193,29 @@ int hp_agent_grad_buffer(hp_agent *ag, void **dev_grads, int64_t *n_floats);
 int hp_agent_param_buffer(hp_agent *ag, void **dev_params, int64_t *n_floats); /* actor|critic, for Bcast (utils.py:6-15) */
 int hp_agent_apply(hp_agent *ag);
 int hp_agent_sync_targets(hp_agent *ag); /* ddpg_agent.py:33-34: targets := online nets */
+
+/* ---- rank exchange on RCCL (one process per GPU; replaces mpi4py) -------------------------------
+ * The three exchanges of the reference: sync_networks (utils.py:6-15, Bcast from rank 0), sync_grads
+ * (utils.py:43-48, Allreduce SUM of the flat gradients, every update) and the normalizer's
+ * _mpi_average (normalizer.py:60-64, Allreduce SUM / size).  Bootstrap: rank 0 calls
+ * hp_comm_unique_id, the 128 bytes travel to the other ranks by any side channel (the Python mirror
+ * uses torch.distributed), every rank calls hp_comm_create.  Collectives are enqueued on the
+ * context's stream.  RCCL is resolved with dlopen at first use; without it these return HP_ERR_STATE. */
+int hp_comm_unique_id(uint8_t *out128);
+int hp_comm_create(hp_ctx *ctx, const uint8_t *id128, int32_t rank, int32_t world, hp_comm **out);
+int hp_comm_info(hp_comm *comm, int32_t *rank, int32_t *world);
+int hp_comm_allreduce_sum_f32(hp_comm *comm, void *dev, int64_t n);    /* in place, device pointer */
+int hp_comm_allreduce_mean_f32(hp_comm *comm, void *dev, int64_t n);   /* SUM then / world (float32) */
+int hp_comm_broadcast_f32(hp_comm *comm, void *dev, int64_t n, int32_t root);
+void hp_comm_destroy(hp_comm *comm);
+/* Attach (or detach with NULL) a communicator: hp_agent_sample_and_update and hp_agent_train_cycle then
+ * all-reduce the gradients between backward and Adam inside the library (and train_cycle the
+ * normalizer sums), so the data-parallel loop needs no host round trip per update and stays inside
+ * the cycle's hipGraph.  The split-phase calls above keep working for callers with their own transport. */
+int hp_agent_set_comm(hp_agent *ag, hp_comm *comm);
+/* diagnostic: 0 = no cycle built yet, 1 = hp_agent_train_cycle replays a cached hipGraph, 2 = it issues eager
+ * launches because a capture containing collectives was refused by the runtime */
+int hp_agent_cycle_mode(hp_agent *ag, int32_t *mode);
 
 /* One training cycle's learner half (ddpg_agent.py:143-150) as one cached hipGraph:
  *   store n_new episodes -> update normalizers (+recompute) -> n_batches updates -> soft update.

@@ -93,6 +93,15 @@ PROTOTYPES = {
     "hp_agent_param_buffer": (C.c_int, [C.c_void_p, c_void_pp, i64p]),
     "hp_agent_apply": (C.c_int, [C.c_void_p]),
     "hp_agent_sync_targets": (C.c_int, [C.c_void_p]),
+    "hp_comm_unique_id": (C.c_int, [u8p]),
+    "hp_comm_create": (C.c_int, [C.c_void_p, u8p, C.c_int32, C.c_int32, c_void_pp]),
+    "hp_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hp_comm_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "hp_comm_allreduce_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "hp_comm_broadcast_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "hp_comm_destroy": (None, [C.c_void_p]),
+    "hp_agent_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_agent_cycle_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
                                        f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),

@@ -221,6 +221,9 @@ struct hp_agent {
     DevBuf fwd_ws;          // actor_forward scratch
     PinnedBuf pin;
     std::vector<void *> owned;
+    // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
+    hp_comm *comm = nullptr;
+    bool graph_refused = false;   // capturing the cycle with collectives failed once: stay on eager launches
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
     hp_buffer *g_buf = nullptr;
@@ -892,10 +895,12 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         FwdSlabArgs A;
         A.tl = a->timeline;
         memset(&A.gs, 0, sizeof(A.gs));
+        A.gs.plan_any = a->plan.as<PlanRec>();
+        A.gs.B = a->B;
         if (gc) {
             hp_buffer *b = gc->b;
             A.gs.obs = b->d_obs; A.gs.ag = b->d_ag; A.gs.g = b->d_g; A.gs.act = b->d_act;
-            A.gs.plan = gc->plan; A.gs.onz = gc->on->d; A.gs.gnz = gc->gn->d;
+            A.gs.plan = gc->plan; A.gs.plan_any = gc->plan; A.gs.onz = gc->on->d; A.gs.gnz = gc->gn->d;
             A.gs.sq_threshold = gc->sq; A.gs.clip_obs = a->cfg.clip_obs; A.gs.clip_range = a->cfg.clip_range;
             A.gs.T = b->T; A.gs.obs_dim = b->obs_dim; A.gs.goal_dim = b->goal_dim; A.gs.B = a->B;
             A.gs.R = a->R;
@@ -1045,8 +1050,13 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             gc.future_p = future_p;
         }
         bool fused = false;
-        HP_TRY(enqueue_forward_backward(a, &gc, with_adam, &fused));
-        if (with_adam && !fused) HP_TRY(enqueue_adam(a));
+        HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm, &fused));
+        if (with_adam) {
+            // utils.sync_grads (utils.py:43-48): SUM over ranks between backward and the optimizer step; one
+            // all-reduce covers both networks (the reference sends the actor's and the critic's separately)
+            if (a->comm) HP_TRY(comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
+            if (!fused) HP_TRY(enqueue_adam(a));
+        }
     }
     return HP_OK;
 }
@@ -1366,8 +1376,12 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
     HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, b->T, 1, future_p, norm_plan));
     HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs));
     HP_TRY(norm_launch_begin(on));
-    HP_TRY(norm_launch_end(on));
     HP_TRY(norm_launch_begin(gn));
+    if (a->comm) {   // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
+        HP_TRY(comm_allreduce_mean_f32(a->comm, on->d->sync, (size_t)(2 * on->size + 1)));
+        HP_TRY(comm_allreduce_mean_f32(a->comm, gn->d->sync, (size_t)(2 * gn->size + 1)));
+    }
+    HP_TRY(norm_launch_end(on));
     HP_TRY(norm_launch_end(gn));
     // ddpg_agent.py:145-150
     HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq, n_batches, true));
@@ -1376,6 +1390,23 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 }
 
 extern "C" {
+
+// diagnostic: how hp_agent_train_cycle currently runs -- 0 nothing built yet, 1 cached hipGraph, 2 eager launches
+// (a capture containing collectives was refused)
+int hp_agent_cycle_mode(hp_agent *a, int32_t *mode) {
+    HP_REQUIRE(a && mode, HP_ERR_INVALID, "hp_agent_cycle_mode: null argument");
+    *mode = a->graph_refused ? 2 : (a->graph ? 1 : 0);
+    return HP_OK;
+}
+
+int hp_agent_set_comm(hp_agent *a, hp_comm *comm) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_comm: null handle");
+    HP_REQUIRE(!comm || comm->ctx == a->ctx, HP_ERR_INVALID, "hp_agent_set_comm: communicator belongs to another context");
+    drop_graph(a);
+    a->graph_refused = false;
+    a->comm = comm;
+    return HP_OK;
+}
 
 int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, const double *obs,
                          const double *ag_host, const double *g, const double *actions, int64_t n_new,
@@ -1392,23 +1423,46 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
     const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
                       a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&
                       a->g_sq == sq_threshold && a->g_stage == b->st_obs.p;
+    if (a->graph_refused) {   // see below
+        HP_TRY(ensure_plan(a, n_batches));
+        HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
+        HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>()));
+        a->host_steps += n_batches;
+        return HP_OK;
+    }
     if (!same) {
         drop_graph(a);
         HP_TRY(ensure_plan(a, n_batches));
         HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
+        if (a->comm) {
+            // RCCL sets up its channels lazily on the first collective of a given kind: do that outside the capture
+            // (the gradients are recomputed before they are read, the zeroed sync vectors are idle between cycles)
+            HP_TRY(comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
+        }
         HP_CHECK_HIP(hipStreamSynchronize(s));
         hipGraph_t graph = nullptr;
         HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int st = enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>());
         hipError_t e = hipStreamEndCapture(s, &graph);
-        if (st != HP_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return st;
+        if (st == HP_OK && e == hipSuccess) {
+            e = hipGraphInstantiate(&a->graph, graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) a->graph = nullptr;
         }
-        HP_CHECK_HIP(e);
-        e = hipGraphInstantiate(&a->graph, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        HP_CHECK_HIP(e);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (st != HP_OK || e != hipSuccess) {
+            if (!a->comm) {
+                if (st != HP_OK) return st;
+                HP_CHECK_HIP(e);
+            }
+            // A capture that contains collectives was refused (RCCL build without graph support, or a lazy allocation
+            // inside the capture).  Nothing was executed -- a capture only records -- so the same work is issued as
+            // ordinary launches from now on; the other ranks see the same sequence of collectives either way.
+            (void)hipGetLastError();
+            a->graph_refused = true;
+            HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>()));
+            a->host_steps += n_batches;
+            return HP_OK;
+        }
         a->g_buf = b; a->g_on = on; a->g_gn = gn; a->g_rng = rng;
         a->g_n_new = n_new; a->g_n_batches = n_batches; a->g_future_p = future_p; a->g_sq = sq_threshold;
         a->g_stage = b->st_obs.p;

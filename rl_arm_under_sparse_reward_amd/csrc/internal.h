@@ -172,6 +172,15 @@ struct hp_norm {
     bool in_recompute = false;
 };
 
+// rank exchange (comm.hip): one RCCL communicator bound to the context's stream
+struct hp_comm {
+    hp_ctx *ctx = nullptr;
+    void *nccl = nullptr;   // ncclComm_t
+    int rank = 0, world = 1;
+};
+int comm_allreduce_sum_f32(hp_comm *c, float *dev, size_t n);    // utils.py:43-48
+int comm_allreduce_mean_f32(hp_comm *c, float *dev, size_t n);   // normalizer.py:60-64
+
 // launchers implemented in the .hip files -------------------------------------------------
 // rng.hip
 int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,

@@ -361,6 +361,7 @@ __device__ __forceinline__ int slab_stamp_slab() { return gridDim.y > 1 ? blockI
 struct GatherSrc {   // replay buffer + index plan + normalizer statistics: everything k_gather_fused takes
     const double *obs, *ag, *g, *act;
     const PlanRec *plan;              // nullptr: the network inputs are already in XA / XP / XT (minibatch API)
+    const PlanRec *plan_any;          // never null (>= B records): lets the kernels load their record without a branch
     const NormDev *onz, *gnz;
     double sq_threshold, clip_obs, clip_range;
     int T, obs_dim, goal_dim, B;

@@ -102,8 +102,17 @@ __device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, fl
 // (rbase + t) % S8_RING, and as soon as the current layer has no block left to issue the freed slots take the
 // first blocks of the next layer (slot arithmetic stays consistent with rbase' = rbase + 32).  The DMA queue
 // therefore never drains at a layer boundary.
+// LDS-DMA of one 1 KiB block (16 B per lane).  Note for whoever tunes this next: the builtin is a FLAT-encoded
+// instruction that touches memory and LDS, and while one is pending hipcc's wait-count pass turns every wait it
+// inserts into vmcnt(0) / lgkmcnt(0) ("pending flat").  Issuing the transfer from inline assembly (s_mov_b32 m0 +
+// global_load_lds_dwordx4) makes the compiler's counts exact -- verified in the ISA -- but measured no faster
+// (57.1 vs 57.3 us per update) and needs M0 on the clobber list, which hipcc flags as reserved; the builtin stays.
+__device__ __forceinline__ void s8_dma16(const void *gsrc, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds(gsrc, lds_dst, 16, 0, 0);
+}
+
 __device__ __forceinline__ void s8_ring_issue(RingSlot *ring, int rbase, const float *wlayer, int cg, int b0, int t) {
-    __builtin_amdgcn_global_load_lds(s8_wblock(wlayer, cg, 64, b0 + t), &ring[(rbase + t) % S8_RING][0], 16, 0, 0);
+    s8_dma16(s8_wblock(wlayer, cg, 64, b0 + t), &ring[(rbase + t) % S8_RING][0]);
 }
 
 // first S8_RING blocks of this wave's half of a 256-reduction layer (start of a chain)
@@ -213,9 +222,10 @@ __device__ __forceinline__ void s8_small_steps(f32x4 &c0, f32x4 &c1, const float
 __device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlayer, int Kred, float4 (&b)[6]) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
+    // branch free (blocks past `half` reload the last one): with no control flow between the loads the compiler
+    // can count them, and waits for OLDER loads become vmcnt(n) instead of vmcnt(0)
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
-        if (t < half) b[t] = *s8_wblock(wlayer, cg, nb4, b0 + t);
+    for (int t = 0; t < 6; ++t) b[t] = *s8_wblock(wlayer, cg, nb4, b0 + (t < half ? t : half - 1));
 }
 
 // small layer: weights already in registers (s8_small_prefetch), no ring
@@ -274,12 +284,12 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
 }
 
 // HER gather for the 8 rows of a slab (same arithmetic as slab_gather / k_gather_fused); 64 threads per row
-// this thread's row of the index plan (the first load of the kernel: everything else in the gather depends on it)
+// this thread's row of the index plan: the first load of the kernel (everything else in the gather depends on it).
+// Unconditional (rows past the batch re-read the last record, plan_any is never null): a load under a branch is
+// merged with its default through a register copy, which makes the compiler wait for it on the spot.
 __device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0) {
-    const size_t m = row0 + (threadIdx.x >> 6);
-    PlanRec rec = {0, 0, 1, 0};
-    if (G.plan && (int)m < G.B) rec = G.plan[m];
-    return rec;
+    const int m = (int)row0 + (int)(threadIdx.x >> 6);
+    return G.plan_any[m < G.B ? m : G.B - 1];
 }
 
 __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const PlanRec rec, int which, size_t row0, int ldx,
@@ -366,9 +376,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #ifdef SLAB_TIMELINE
     if (slab == 0 && tid == 0) A.tl[chain * 32] = wall_clock64();
 #endif
-    const PlanRec rec = s8_plan_rec(A.gs, row0);
     if (chain == 1) {   // critic(x, a)
-        float4 wb[6], wq[4];
+        const PlanRec rec = s8_plan_rec(A.gs, row0);   // per branch: a value live across the branch gets a register
+        float4 wb[6], wq[4];                           // copy, and the copy waits for the load
         s8_small_prefetch(A.online.wf + ca + lc.w1, lc.K1, wb);
         wq[0] = *reinterpret_cast<const float4 *>(A.online.canon + ca + lc.w4 + 4 * lane);
         const float bq = A.online.canon[ca + lc.b4];
@@ -386,16 +396,17 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const bool tgt = (chain == 0);
     const SlabNetPtrs &net = tgt ? A.target : A.online;
     float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
+    const PlanRec rec = s8_plan_rec(A.gs, row0);
     // everything that does not depend on the activations is fetched now: first-layer weight blocks of both trunks,
     // the head rows and biases (cold loads whose latency would otherwise sit on the chain once per use)
     float4 wba[6], wbc[6], wh[4], wq[4];
     s8_small_prefetch(net.wf + la.w1, la.K1, wba);
     s8_small_prefetch(net.wf + ca + lc.w1, lc.K1, wbc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < A.act_dim) wh[j] = *reinterpret_cast<const float4 *>(net.canon + la.w4 + j * H + 4 * lane);
+    for (int j = 0; j < 4; ++j)   // branch free: rows past act_dim re-read the last one
+        wh[j] = *reinterpret_cast<const float4 *>(net.canon + la.w4 + (j < A.act_dim ? j : A.act_dim - 1) * H + 4 * lane);
     wq[0] = *reinterpret_cast<const float4 *>(net.canon + ca + lc.w4 + 4 * lane);
-    const float bh = (lane < A.act_dim) ? net.canon[la.b4 + lane] : 0.f;
+    const float bh = net.canon[la.b4 + (lane < A.act_dim ? lane : 0)];
     const float bq = net.canon[ca + lc.b4];
     __builtin_amdgcn_sched_barrier(0);
     if (A.gs.plan) s8_gather(xin, A.gs, rec, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
@@ -467,32 +478,34 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
         return;
     }
-    if (slab == 0 && chain == 0 && tid == 0) {
-        A.st->step += 1;
-        adam_prepare(A.st, A.adam);
-    }
+    // NOTE on stores: gfx9 counts stores on vmcnt too, and with a store pending next to loads the compiler can no
+    // longer rely on in-order return -- every wait it inserts becomes vmcnt(0), which drains the weight DMA queue.
+    // All small global stores of this kernel (Adam step scalars, loss partials, dQ) are therefore parked in registers
+    // and written at the very end of the workgroup.
     S8_STAMP(0);
     // per-row loss operands first (the loss is the head of the chain and vmcnt retires in order), then the prefetches
-    float l0 = 0.f, l1 = 0.f, l2 = 0.f, lu[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < S8_ROWS && (int)(row0 + tid) < A.B) {
-        const size_t m = row0 + tid;
-        if (chain == 0) {
-            l0 = A.R[m];
-            l1 = A.QT[m * 16];
-            l2 = A.QA[m * 16];
-        } else {
-            l0 = A.QP[m * 16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < A.act_dim) lu[j] = A.XP[m * A.ldx + A.act_off + j];
-        }
+    // unconditional and merged by ADDRESS, not by value (threads 8.. repeat rows 0..7; padded rows exist): a loaded
+    // value that meets a default or another branch's value in a phi gets a register copy that waits for the load
+    float l0, lu[4];
+    {
+        const size_t m = row0 + (tid & (S8_ROWS - 1));
+        const bool c0 = (chain == 0);
+        const float *xp = A.XP + m * A.ldx + A.act_off;
+        const int ad1 = A.act_dim - 1;
+        l0 = *(c0 ? A.R + m : A.QP + m * 16);
+        lu[0] = *(c0 ? A.QT + m * 16 : xp);
+        lu[1] = *(c0 ? A.QA + m * 16 : xp + (1 < ad1 ? 1 : ad1));
+        lu[2] = *(c0 ? A.QA + m * 16 : xp + (2 < ad1 ? 2 : ad1));
+        lu[3] = *(c0 ? A.QA + m * 16 : xp + (3 < ad1 ? 3 : ad1));
     }
+    const float l1 = lu[0], l2 = lu[1];   // critic chain: Q_target, Q(x, a)
     S8HeadOps hops;
     s8_head_bwd_fetch(hops, A.online.canon + ca + lc.w4, (chain == 0 ? A.CAh3 : A.CPh3) + row0 * H);
     if (chain == 0) {
         // ---- critic loss (ddpg_agent.py:255-263)
         s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
         __builtin_amdgcn_sched_barrier(0);
+        float keep_g = 0.f, keep_a = 0.f;
         if (tid < S8_ROWS) {
             const size_t m = row0 + tid;
             float g = 0.f, sq = 0.f;
@@ -504,9 +517,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 g = -2.f * d * invB;
             }
             dq[tid] = g;
-            A.dQA[m * 16] = g;
             for (int o = 4; o > 0; o >>= 1) sq += __shfl_down(sq, o, 8);
-            if (tid == 0) A.part[slab] = sq;
+            keep_g = g;
+            keep_a = sq;
         }
         s8_sync();
         S8_STAMP(1);
@@ -524,6 +537,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_sync();
         S8_STAMP(4);
         s8_store(bufA, S8_LD, H, A.dA1 + row0 * H, H);
+        if (tid < S8_ROWS) {
+            A.dQA[(row0 + tid) * 16] = keep_g;
+            if (tid == 0) A.part[slab] = keep_a;
+        }
+        if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
+            A.st->step += 1;
+            adam_prepare(A.st, A.adam);
+        }
         S8_STAMP(5);
         return;
     }
@@ -533,43 +554,39 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int K1c = lc.K1, ad = A.act_dim;
     float4 wb4[6];
     float w1n[4] = {0.f, 0.f, 0.f, 0.f};   // thread n < 256: W1c[n][act_off + j] (one line per n; staged in LDS as w1t[j][n])
-    if (tid < 256) {
-        const float *w1 = A.online.canon + ca + lc.w1 + (size_t)tid * K1c + A.act_off;
+    {   // branch free (threads 256.. duplicate 0..255, columns past act_dim re-read the last one)
+        const float *w1 = A.online.canon + ca + lc.w1 + (size_t)(tid & 255) * K1c + A.act_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < ad) w1n[j] = w1[j];
+        for (int j = 0; j < 4; ++j) w1n[j] = w1[j < ad ? j : ad - 1];
     }
     s8_small_prefetch(A.online.wd + la.w4, 16, wb4);
     float u_mine = 0.f, th_mine = 0.f;
     {
-        const size_t m = row0 + wave;
-        if (lane < ad && (int)m < A.B) {
-            u_mine = A.XP[m * A.ldx + A.act_off + lane];
-            th_mine = A.TP[m * 16 + lane];
-        }
+        const size_t m = row0 + wave;   // padded rows exist (Mp rows allocated) and hold zeros
+        const int jl = lane < ad ? lane : 0;
+        u_mine = A.XP[m * A.ldx + A.act_off + jl];
+        th_mine = A.TP[m * 16 + jl];
     }
     __builtin_amdgcn_sched_barrier(0);
     s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
     __builtin_amdgcn_sched_barrier(0);
+    float keep_q = 0.f, keep_u = 0.f;
     if (tid < S8_ROWS) {
         const size_t m = row0 + tid;
         const bool live = (int)m < A.B;
         dq[tid] = live ? -invB : 0.f;
         float sq = live ? l0 : 0.f, su = 0.f;
-        if (live)
-            for (int j = 0; j < A.act_dim; ++j) su += lu[j] * lu[j];
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < A.act_dim) su += lu[j] * lu[j];
+        }
         for (int o = 4; o > 0; o >>= 1) {
             sq += __shfl_down(sq, o, 8);
             su += __shfl_down(su, o, 8);
         }
-        if (tid == 0) {
-            A.part[nslab + slab] = sq;
-            A.part[2 * nslab + slab] = su;
-        }
-    }
-    if (tid < 256) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
+        keep_q = sq;
+        keep_u = su;
     }
     s8_sync();
     S8_STAMP(1);
@@ -578,6 +595,10 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     S8_STAMP(2);
     s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, pbuf,
                  bufB, S8_LD);
+    if (tid < 256) {   // parked until now so that the strided loads had two stages to land
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
+    }
     s8_sync();
     S8_STAMP(3);
     s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, pbuf, bufA,
@@ -617,5 +638,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     S8_STAMP(8);
     s8_store(bufB, S8_LD, H, A.dK1 + row0 * H, H);
+    if (tid == 0) {
+        A.part[nslab + slab] = keep_q;
+        A.part[2 * nslab + slab] = keep_u;
+    }
     S8_STAMP(9);
 }

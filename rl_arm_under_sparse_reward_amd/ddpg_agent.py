@@ -69,6 +69,10 @@ class ddpg_agent:
             net.attach(self, slot)
         self.actor_network.push()
         self.critic_network.push()
+        # data-parallel ranks on GPUs: the library issues the collectives itself (csrc/comm.hip)
+        self._native_comm = self.comm.attach_native(self.ctx)
+        if self._native_comm is not None:
+            _lib.check(self.lib.hp_agent_set_comm(self.h, self._native_comm))
         self._broadcast_params(self.comm)                       # sync_networks x2 (ddpg_agent.py:27-28)
         _lib.check(self.lib.hp_agent_sync_targets(self.h))      # targets := online (ddpg_agent.py:33-34)
         # her sampler + replay buffer (ddpg_agent.py:45-47)
@@ -119,7 +123,8 @@ class ddpg_agent:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_param_buffer(self.h, C.byref(p), C.byref(n)))
-        self.ctx.use_torch_stream()
+        if comm.native is None:
+            self.ctx.use_torch_stream()      # order our kernels with the collectives torch enqueues
         comm.broadcast_device(p.value, n.value, 0)
 
     def _allreduce_grads(self, comm):
@@ -144,7 +149,8 @@ class ddpg_agent:
     def _update_network(self, n_updates=1):
         """ddpg_agent.py:225-277, `n_updates` times back to back (the reference's inner loop :145-147)."""
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
-        if not self.comm.active:
+        if not self.comm.active or self._native_comm is not None:
+            # single rank, or the library all-reduces the gradients itself between backward and Adam
             _lib.check(self.lib.hp_agent_sample_and_update(*self._handles(), fp, sq, int(n_updates)))
             return
         for _ in range(int(n_updates)):          # data-parallel ranks: grads are SUMmed between backward and Adam
@@ -195,9 +201,11 @@ class ddpg_agent:
 
     def train_cycle(self, episode_batch, n_batches=None):
         """ddpg_agent.py:143-150 as one hipGraph: store_episode, _update_normalizer, n_batches x
-        _update_network, soft update of both targets.  Asynchronous; single rank only."""
+        _update_network, soft update of both targets.  Asynchronous.  With data-parallel ranks the graph
+        contains the RCCL all-reduces (gradients every update, normalizer sums once) when the library owns the
+        communicator; otherwise the loop is driven from the host."""
         n_batches = int(n_batches or self.args.n_batches)
-        if self.comm.active:
+        if self.comm.active and self._native_comm is None:      # collectives on torch.distributed: host-driven loop
             self.buffer.store_episode(episode_batch)
             self._update_normalizer(episode_batch)
             self._update_network(n_batches)

@@ -4,11 +4,19 @@ Reference semantics (utils.py:6-69), preserved:
   * sync_networks(net): every rank ends up with rank 0's parameters (MPI Bcast, utils.py:13);
   * sync_grads(net):   gradients are SUMMED over ranks, not averaged (MPI Allreduce SUM,
                        utils.py:47), so the effective learning rate scales with world size.
-The transport is torch.distributed ("nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU
-tests), one process per GPU.  When a network is attached to a `ddpg_agent`, the exchange runs
-directly on the library's device vectors (zero copy); otherwise on the module's host tensors.
+The transport is RCCL over xGMI, one process per GPU.  torch.distributed provides the process group
+(rendezvous, barriers, the "gloo" CPU tests); on GPUs the collectives of the hot path are issued by the
+library itself on its own stream (`hp_comm_*`, csrc/comm.hip) so that a whole training cycle -- including
+the per-update gradient all-reduce -- is one hipGraph with no host round trip per update.  The native
+communicator is bootstrapped from the torch group (rank 0's RCCL id is broadcast through it);
+RLARM_COMM=torch keeps every collective on torch.distributed instead.  When a network is attached to a
+`ddpg_agent`, the exchange runs directly on the library's device vectors (zero copy); otherwise on the
+module's host tensors.
 """
 from __future__ import annotations
+
+import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -25,6 +33,35 @@ class Communicator:
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.device_id = device_id
         self.force = bool(force) and self._dist is not None   # run the collectives even in a 1-rank group (tests)
+        self.native = None        # library-side RCCL communicator (hp_comm *), see attach_native
+        self._native_lib = None
+
+    def attach_native(self, ctx):
+        """Create (once) the library's own RCCL communicator for this rank.  Collective: every rank of the
+        group must call it.  Returns the handle, or None when the group is not on GPUs / RLARM_COMM=torch."""
+        if self.native is not None:
+            return self.native
+        if not self.active or os.environ.get("RLARM_COMM", "native") == "torch":
+            return None
+        if self._dist.get_backend() != "nccl":
+            return None
+        lib = ctx.lib
+        ident = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{ctx.device_id}")
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(lib.hp_comm_unique_id(buf))
+            ident.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        self._dist.broadcast(ident, src=0)
+        raw = (C.c_uint8 * 128)(*ident.cpu().tolist())
+        h = C.c_void_p()
+        _lib.check(lib.hp_comm_create(ctx.h, raw, self.rank, self.world_size, C.byref(h)))
+        self.native, self._native_lib = h, lib
+        return h
+
+    def close(self):
+        if self.native is not None:
+            self._native_lib.hp_comm_destroy(self.native)
+            self.native = None
 
     @property
     def active(self):
@@ -63,15 +100,27 @@ class Communicator:
         return torch.as_tensor(_lib.DevicePointer(address, n), device=f"cuda:{dev}")
 
     def allreduce_sum_device(self, address, n):
-        if self.active:
+        if not self.active:
+            return
+        if self.native is not None:
+            _lib.check(self._native_lib.hp_comm_allreduce_sum_f32(self.native, C.c_void_p(address), int(n)))
+        else:
             self.allreduce_sum_(self._view(address, n))
 
     def allreduce_mean_device(self, address, n):
-        if self.active:
+        if not self.active:
+            return
+        if self.native is not None:
+            _lib.check(self._native_lib.hp_comm_allreduce_mean_f32(self.native, C.c_void_p(address), int(n)))
+        else:
             self.allreduce_mean_(self._view(address, n))
 
     def broadcast_device(self, address, n, root=0):
-        if self.active:
+        if not self.active:
+            return
+        if self.native is not None:
+            _lib.check(self._native_lib.hp_comm_broadcast_f32(self.native, C.c_void_p(address), int(n), int(root)))
+        else:
             self.broadcast_(self._view(address, n), root)
 
 

@@ -220,10 +220,13 @@ def test_demo_npz_preload():
     assert np.all(np.isfinite(agent.last_losses(2)))
 
 
-def _run_cycles(agent, n_cycles=3, n_batches=4):
+def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
     agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
     for cycle in range(n_cycles):
         eps = make_episodes(2, seed=200 + cycle, mode="walk")
+        if graph:
+            agent.train_cycle(eps, n_batches)           # one hipGraph launch (collectives inside, if any)
+            continue
         agent.buffer.store_episode(eps)
         agent._update_normalizer(eps)
         agent._update_network(n_batches)
@@ -232,16 +235,20 @@ def _run_cycles(agent, n_cycles=3, n_batches=4):
             agent.last_losses(n_cycles * n_batches), agent.o_norm.mean, agent.g_norm.std)
 
 
-def test_rccl_path_world1_equals_single_rank_bitwise():
-    """The data-parallel code path (forward_backward -> all-reduce SUM on the library's device vector ->
-    apply; normalizer begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must
-    reproduce the fused single-rank path bit for bit (a 1-rank SUM / MEAN is the identity)."""
+@pytest.mark.parametrize("transport,graph", [("torch", False), ("native", False), ("native", True)])
+def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, monkeypatch):
+    """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
+    begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
+    fused single-rank path bit for bit (a 1-rank SUM / MEAN is the identity).  transport "torch": collectives
+    issued by torch.distributed on views of the library's device vectors, host-driven loop; "native": issued by
+    the library on its own stream (hp_comm_*), also captured inside the training-cycle hipGraph."""
     import os
     import socket
     import torch.distributed as dist
     from rl_arm_under_sparse_reward_amd.utils import Communicator
     from rl_arm_under_sparse_reward_amd import _lib
 
+    monkeypatch.setenv("RLARM_COMM", transport)
     torch.manual_seed(0)
     ref_agent, _ = make_agent(batch=256, n_eps=32, seed=21)
     want = _run_cycles(ref_agent)
@@ -249,18 +256,22 @@ def test_rccl_path_world1_equals_single_rank_bitwise():
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = None
     try:
-        ctx = _lib.Context.default()
-        ctx.use_torch_stream()          # order our kernels with the collectives torch enqueues
         comm = Communicator(0, force=True)
         assert comm.active and comm.world_size == 1
         torch.manual_seed(0)
         args = Args(batch_size=256, buffer_size=32 * 100)
         rng = fresh_rng(21)
         agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=comm, rng=rng)
-        got = _run_cycles(agent)
+        assert (comm.native is not None) == (transport == "native")
+        got = _run_cycles(agent, graph=graph)
+        _lib.Context.default().synchronize()
         torch.cuda.synchronize()
+        del agent
     finally:
+        if comm is not None:
+            comm.close()
         _lib.Context.default().set_stream(None)
         dist.destroy_process_group()
     for a, b in zip(want, got):
