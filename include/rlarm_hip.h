@@ -60,6 +60,9 @@ int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
 /* diagnostic: average microseconds per dependent trivial kernel on the context's stream, measured
  * as an n-node captured hipGraph (graph != 0) or n eager launches (the launch floor in DESIGN.md) */
 int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel);
+/* diagnostic: microseconds a hipEvent pair reads with nothing between the two records (the bracketing overhead
+ * inside every per-launch event measurement of hp_agent_profile; bench.py subtracts it) */
+int hp_ctx_event_pair_us(hp_ctx *ctx, int reps, double *us);
 /* diagnostic: shader clock in MHz observed by a probe kernel enqueued now (DVFS state under this load) */
 int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz);
 void hp_ctx_destroy(hp_ctx *ctx);

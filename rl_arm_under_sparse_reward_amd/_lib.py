@@ -49,6 +49,7 @@ PROTOTYPES = {
     "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "hp_ctx_launch_floor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p]),
+    "hp_ctx_event_pair_us": (C.c_int, [C.c_void_p, C.c_int, f64p]),
     "hp_ctx_clock_mhz": (C.c_int, [C.c_void_p, f64p]),
     "hp_ctx_destroy": (None, [C.c_void_p]),
     "hp_rng_create": (C.c_int, [C.c_void_p, c_void_pp]),

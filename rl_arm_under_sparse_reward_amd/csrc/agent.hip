@@ -223,6 +223,7 @@ struct hp_agent {
     std::vector<void *> owned;
     // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
     hp_comm *comm = nullptr;
+    bool comm_warm = false;       // the collectives of a cycle have each run once outside a capture
     bool graph_refused = false;   // capturing the cycle with collectives failed once: stay on eager launches
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
@@ -1404,6 +1405,7 @@ int hp_agent_set_comm(hp_agent *a, hp_comm *comm) {
     HP_REQUIRE(!comm || comm->ctx == a->ctx, HP_ERR_INVALID, "hp_agent_set_comm: communicator belongs to another context");
     drop_graph(a);
     a->graph_refused = false;
+    a->comm_warm = false;
     a->comm = comm;
     return HP_OK;
 }
@@ -1434,10 +1436,13 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
         drop_graph(a);
         HP_TRY(ensure_plan(a, n_batches));
         HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
-        if (a->comm) {
+        if (a->comm && !a->comm_warm) {
+            a->comm_warm = true;   // once per attach, on the first cycle of every rank: stays symmetric across ranks
             // RCCL sets up its channels lazily on the first collective of a given kind: do that outside the capture
             // (the gradients are recomputed before they are read, the zeroed sync vectors are idle between cycles)
             HP_TRY(comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
+            HP_TRY(comm_allreduce_sum_f32(a->comm, on->d->sync, (size_t)(2 * on->size + 1)));   // overwritten by
+            HP_TRY(comm_allreduce_sum_f32(a->comm, gn->d->sync, (size_t)(2 * gn->size + 1)));   // k_norm_begin
         }
         HP_CHECK_HIP(hipStreamSynchronize(s));
         hipGraph_t graph = nullptr;

@@ -123,6 +123,35 @@ int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel) {
     return HP_OK;
 }
 
+// diagnostic: what a hipEvent pair with NOTHING between the two records reads on the context's stream (average of
+// `reps` pairs, each behind a trivial kernel so that the stream is busy like in the profiling pass).  This is the
+// bracketing overhead contained in every per-launch event measurement; rocprofv3 kernel durations do not have it.
+int hp_ctx_event_pair_us(hp_ctx *ctx, int reps, double *us) {
+    HP_REQUIRE(ctx && us && reps > 0, HP_ERR_INVALID, "hp_ctx_event_pair_us: bad argument");
+    hipStream_t s = ctx->stream;
+    int *d = nullptr;
+    HP_CHECK_HIP(hipMalloc((void **)&d, 4));
+    HP_CHECK_HIP(hipMemsetAsync(d, 0, 4, s));
+    hipEvent_t e0, e1;
+    HP_CHECK_HIP(hipEventCreate(&e0));
+    HP_CHECK_HIP(hipEventCreate(&e1));
+    double tot = 0;
+    for (int r = 0; r < reps; ++r) {
+        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(k_floor_probe, dim3(1), dim3(64), 0, s, d);
+        HP_CHECK_HIP(hipEventRecord(e0, s));
+        HP_CHECK_HIP(hipEventRecord(e1, s));
+        HP_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+    }
+    *us = 1e3 * tot / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return HP_OK;
+}
+
 // diagnostic: shader clock (MHz) seen by a kernel enqueued right now on the context's stream
 int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz) {
     HP_REQUIRE(ctx && mhz, HP_ERR_INVALID, "hp_ctx_clock_mhz: bad argument");

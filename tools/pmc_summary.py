@@ -1,20 +1,57 @@
 #!/usr/bin/env python3
-"""Per-kernel average of a PMC counter from rocprofv3 sqlite outputs (one db per counter pass)."""
+"""Per-kernel average of the FETCH_SIZE / WRITE_SIZE counters from two rocprofv3 sqlite outputs (one db per counter
+pass, tools/gpu_pmc.sh) -> text table on stdout and, with --json PATH, the per-launch HBM traffic file bench.py reads.
+
+  python tools/pmc_summary.py FETCH.db WRITE.db [--json profiles/rNN_pmc_traffic.json] [--note "..."]
+
+MI355X_MICROARCH.md: both counters report KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their
+bytes (x2 correction applied in hbm_bytes_per_launch), WRITE_SIZE is uncalibrated."""
+import json
 import sqlite3
 import sys
 
-for path in sys.argv[1:]:
+
+def per_kernel(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-    view = "counters_collection" if "counters_collection" in tabs else None
-    if not view:
-        print(path, "no counters_collection view; tables:", tabs[:10])
-        continue
-    cols = [d[0] for d in cur.execute(f"select * from {view} limit 1").description]
+    if "counters_collection" not in tabs:
+        raise SystemExit(f"{path}: no counters_collection view; tables: {tabs[:10]}")
+    cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
     name_col = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else cols[0])
-    rows = cur.execute(f"select {name_col}, counter_name, count(*), avg(value), sum(value) from {view} "
+    rows = cur.execute(f"select {name_col}, counter_name, count(*), avg(value), sum(value) from counters_collection "
                        f"group by {name_col}, counter_name order by 5 desc").fetchall()
-    print(path)
-    for r in rows[:12]:
-        print(f"  {str(r[0])[:50]:50s} {r[1]:12s} n={r[2]:6d} avg={r[3]:12.1f}")
+    return rows
+
+
+def main():
+    args = sys.argv[1:]
+    out_json, note = None, ""
+    if "--json" in args:
+        i = args.index("--json"); out_json = args[i + 1]; del args[i:i + 2]
+    if "--note" in args:
+        i = args.index("--note"); note = args[i + 1]; del args[i:i + 2]
+    table = {}
+    for path in args:
+        print(path)
+        for name, counter, n, avg, _ in per_kernel(path)[:14]:
+            print(f"  {str(name)[:50]:50s} {counter:12s} n={n:6d} avg={avg:12.1f} KiB/launch")
+            short = str(name).split("(")[0]
+            table.setdefault(short, {})[counter] = avg
+    if out_json:
+        kernels = {}
+        for k, v in table.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k.startswith("k_"):
+                kernels[k] = {"FETCH_SIZE_KiB": round(v["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(v["WRITE_SIZE"], 1),
+                              "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
+        with open(out_json, "w") as f:
+            json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/gpu_pmc.sh) "
+                                 "-- python bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-profile; " + note,
+                       "units": "KiB per launch as reported; MI355X_MICROARCH.md: FETCH_SIZE counts wide coalesced reads at "
+                                "half their bytes on gfx950 (x2 correction applied in hbm_bytes_per_launch), WRITE_SIZE "
+                                "uncalibrated", "kernels": kernels}, f, indent=1)
+        print("wrote", out_json)
+
+
+if __name__ == "__main__":
+    main()
