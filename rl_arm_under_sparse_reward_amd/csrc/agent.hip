@@ -216,6 +216,7 @@ struct hp_agent {
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
+    bool merged_fb = true; // slab8: forward and backward in ONE launch (RLARM_FB=split: two kernels, for A/B)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
@@ -891,9 +892,9 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
     const int nslab = Mp / (a->slab8 ? S8_ROWS : SL_ROWS);
+    FbSlabArgs P;
     {
-        ProfScope ps(a, PROF_GEMM_FWD);
-        FwdSlabArgs A;
+        FwdSlabArgs &A = P.f;
         A.tl = a->timeline;
         memset(&A.gs, 0, sizeof(A.gs));
         A.gs.plan_any = a->plan.as<PlanRec>();
@@ -915,13 +916,10 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
         A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
         A.QT = a->QT; A.QA = a->QA; A.QP = a->QP;
-        if (a->slab8) hipLaunchKernelGGL(k_fwd_slab8, dim3(3 * nslab), dim3(S8_THREADS), 0, s, A);
-        else hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, A);
-        HP_CHECK_HIP(hipGetLastError());
     }
+    const bool ride = gc && gc->next_plan && gc->rng;
     {
-        ProfScope ps(a, PROF_GEMM_BWD);
-        BwdSlabArgs A;
+        BwdSlabArgs &A = P.b;
         A.tl = a->timeline + 96;
         A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim;
@@ -936,16 +934,31 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.dZ = a->dZ; A.dK3 = a->dK3; A.dK2 = a->dK2; A.dK1 = a->dK1;
         A.part = a->part; A.st = a->d_state; A.adam = adam_cfg(a);
         A.nslab = nslab;
-        const bool ride = gc && gc->next_plan && gc->rng;
         A.rng = ride ? gc->rng->d_state : nullptr;
         A.meta = ride ? gc->b->d_meta : nullptr;
         A.next_plan = ride ? gc->next_plan : nullptr;
         A.future_p = ride ? gc->future_p : 0.0;
         A.T = ride ? gc->b->T : 0;
         A.plan_batch = a->B;
-        if (a->slab8) hipLaunchKernelGGL(k_bwd_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, A);
-        else hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, A);
+    }
+    if (a->slab8 && a->merged_fb) {
+        // one launch: each workgroup carries its rows through forward AND backward (k_fb_slab8)
+        ProfScope ps(a, PROF_GEMM_FWD);
+        hipLaunchKernelGGL(k_fb_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
+    } else {
+        {
+            ProfScope ps(a, PROF_GEMM_FWD);
+            if (a->slab8) hipLaunchKernelGGL(k_fwd_slab8, dim3(3 * nslab), dim3(S8_THREADS), 0, s, P.f);
+            else hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, P.f);
+            HP_CHECK_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps(a, PROF_GEMM_BWD);
+            if (a->slab8) hipLaunchKernelGGL(k_bwd_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, P.b);
+            else hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, P.b);
+            HP_CHECK_HIP(hipGetLastError());
+        }
     }
     {   // all weight gradients: the only products that reduce over the batch
         float *Ga = a->grads, *Gc = a->grads + la.total;
@@ -1171,6 +1184,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         const char *e = getenv("RLARM_ENGINE");
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
+        const char *fb = getenv("RLARM_FB");
+        a->merged_fb = !(fb && strcmp(fb, "split") == 0);
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);

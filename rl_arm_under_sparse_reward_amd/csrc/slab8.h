@@ -26,8 +26,10 @@
 #define S8_RING 12
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
+#define S8_TSTAMP(tl, k) do { if ((tl) && threadIdx.x == 0) (tl)[k] = wall_clock64(); } while (0)
 #else
 #define S8_STAMP(k) do { } while (0)
+#define S8_TSTAMP(tl, k) do { } while (0)
 #endif
 
 __host__ __device__ __forceinline__ int frag8_fwd_index(int n, int k, int K) {
@@ -148,8 +150,12 @@ __device__ __forceinline__ void s8_ring_step(f32x4 &c0, f32x4 &c1, RingSlot *rin
 }
 
 // combine the two reduction halves and run the epilogue.  c0/c1: this wave's partial [row group][row][col = lane]
+// mask_out (SE_BIAS_RELU, may be null): LDS byte per column, bit r = (output row r > 0) -- the ReLU mask the backward
+// stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
+// instead of the 8 gate values in e[].
 __device__ __forceinline__ void s8_finish(f32x4 c0, f32x4 c1, int epi, const float *e, float *pbuf, float *lout,
-                                          int ld_out) {
+                                          int ld_out, const unsigned char *mask_in = nullptr,
+                                          unsigned char *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
@@ -161,17 +167,25 @@ __device__ __forceinline__ void s8_finish(f32x4 c0, f32x4 c1, int epi, const flo
     }
     s8_sync();
     if (kh == 0) {
+        unsigned bits = mask_in ? (unsigned)mask_in[col] : 0u, outbits = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v0 = c0[r] + pbuf[r * 256 + col], v1 = c1[r] + pbuf[(4 + r) * 256 + col];
             if (epi == SE_BIAS_RELU) {
-                lout[r * ld_out + col] = fmaxf(v0 + e[0], 0.f);
-                lout[(4 + r) * ld_out + col] = fmaxf(v1 + e[0], 0.f);
+                const float o0 = fmaxf(v0 + e[0], 0.f), o1 = fmaxf(v1 + e[0], 0.f);
+                lout[r * ld_out + col] = o0;
+                lout[(4 + r) * ld_out + col] = o1;
+                outbits |= (o0 > 0.f ? 1u : 0u) << r;
+                outbits |= (o1 > 0.f ? 1u : 0u) << (4 + r);
+            } else if (mask_in) {
+                lout[r * ld_out + col] = ((bits >> r) & 1u) ? v0 : 0.f;
+                lout[(4 + r) * ld_out + col] = ((bits >> (4 + r)) & 1u) ? v1 : 0.f;
             } else {
                 lout[r * ld_out + col] = (e[r] > 0.f) ? v0 : 0.f;
                 lout[(4 + r) * ld_out + col] = (e[4 + r] > 0.f) ? v1 : 0.f;
             }
         }
+        if (mask_out) mask_out[col] = (unsigned char)outbits;
     }
 }
 
@@ -192,10 +206,11 @@ __device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float 
 __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSlot *ring, int &rbase,
                                              const float *__restrict__ wlayer, const float *__restrict__ nxt, int epi,
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
-                                             int ld_out) {
+                                             int ld_out, const unsigned char *mask_in = nullptr,
+                                             unsigned char *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
-    s8_epi_load(e, epi, aux, ldaux);
+    if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     float a0[8], a1[8];
@@ -206,7 +221,7 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     else s8_ring_step<0, false>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bfirst);
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
-    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
+    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
 template <int T, int HALF>
@@ -231,11 +246,12 @@ __device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlay
 // small layer: weights already in registers (s8_small_prefetch), no ring
 __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
                                                const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
-                                               int ld_out) {
+                                               int ld_out, const unsigned char *mask_in = nullptr,
+                                               unsigned char *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
-    s8_epi_load(e, epi, aux, ldaux);
+    if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     float a0[8], a1[8];
     s8_aload<2>(lin, ld_in, 4 * b0, a0, a1);   // at most 24 indices per half; lanes past the row end read unused padding
@@ -245,7 +261,7 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
         case 6: s8_small_steps<0, 6>(c0, c1, b, a0, a1); break;
         default: break;   // other input widths are rejected on the host
     }
-    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out);
+    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
 // 8 x nout dot products of length 256 (nout <= 4): wave r owns row r, lane p the reduction indices 4p..4p+3;
@@ -293,7 +309,8 @@ __device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0) 
 }
 
 __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const PlanRec rec, int which, size_t row0, int ldx,
-                                          int act_off, int act_dim, float max_action, float *Xout) {
+                                          int act_off, int act_dim, float max_action, float *Xout,
+                                          float *rew_lds = nullptr) {
     const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t m = row0 + r;
     const bool live = (int)m < G.B;
@@ -334,27 +351,30 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const 
             rew = (s >= G.sq_threshold) ? -1.0f : -0.0f;
         }
         G.R[m] = rew;
+        if (rew_lds) rew_lds[r] = rew;
     }
 }
 
-// xin (K1 wide) -> h1 -> h2 -> h3.  Ring: layer 2 in flight on entry, `nxt` on exit.
+// xin (K1 wide) -> h1 -> h2 -> h3.  Ring: layer 2 in flight on entry, `nxt` on exit.  m1..m3 (LDS, may be null):
+// ReLU masks of h1..h3 for the backward stages of a merged kernel.
 __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, const float4 (&wb1)[6], const float *wf,
                                          const float *canon, int H,
                                          float *bufA, float *bufB, float *pbuf, float *g1, float *g2, float *g3,
                                          size_t row0, RingSlot *ring, int &rbase, const float *nxt,
-                                         unsigned long long *tl, int tbase) {
-    SLAB_STAMP(tl, tbase);
-    s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD);
+                                         unsigned long long *tl, int tbase, unsigned char *m1 = nullptr,
+                                         unsigned char *m2 = nullptr, unsigned char *m3 = nullptr) {
+    S8_TSTAMP(tl, tbase);
+    s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1);
     s8_sync();
-    SLAB_STAMP(tl, tbase + 1);
+    S8_TSTAMP(tl, tbase + 1);
     if (g1) s8_store(bufA, S8_LD, H, g1 + row0 * H, H);
-    s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD);
+    s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2);
     s8_sync();
-    SLAB_STAMP(tl, tbase + 2);
+    S8_TSTAMP(tl, tbase + 2);
     if (g2) s8_store(bufB, S8_LD, H, g2 + row0 * H, H);
-    s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD);
+    s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD, nullptr, m3);
     s8_sync();
-    SLAB_STAMP(tl, tbase + 3);
+    S8_TSTAMP(tl, tbase + 3);
     if (g3) s8_store(bufA, S8_LD, H, g3 + row0 * H, H);
 }
 
@@ -388,7 +408,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_ring_prologue(ring, rbase, A.online.wf + ca + lc.w2);
         s8_sync();
         s8_trunk(xin, lc, wb, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0,
-                 ring, rbase, nullptr, A.tl, 1);
+                 ring, rbase, nullptr, slab == 0 ? A.tl + chain * 32 : nullptr, 1);
         const float q = s8_rowdots(bufA, S8_LD, 1, wq);
         if (lane == 0) A.QA[(row0 + wave) * 16] = q + bq;
         return;
@@ -414,8 +434,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_ring_prologue(ring, rbase, net.wf + la.w2);
     s8_sync();
     s8_trunk(xin, la, wba, net.wf, net.canon, H, bufA, bufB, pbuf, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
-             tgt ? nullptr : A.APh3, row0, ring, rbase, net.wf + ca + lc.w2, A.tl, 1);
-    SLAB_STAMP(A.tl, 5);
+             tgt ? nullptr : A.APh3, row0, ring, rbase, net.wf + ca + lc.w2, slab == 0 ? A.tl + chain * 32 : nullptr, 1);
+    S8_STAMP(5);
     {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
         const float z = s8_rowdots(bufA, S8_LD, A.act_dim, wh);
         if (lane < A.act_dim) {
@@ -427,15 +447,15 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     s8_sync();
-    SLAB_STAMP(A.tl, 7);
+    S8_STAMP(7);
     s8_trunk(xin, lc, wbc, net.wf + ca, net.canon + ca, H, bufA, bufB, pbuf, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
-             tgt ? nullptr : A.CPh3, row0, ring, rbase, nullptr, A.tl, 8);
+             tgt ? nullptr : A.CPh3, row0, ring, rbase, nullptr, slab == 0 ? A.tl + chain * 32 : nullptr, 8);
     {
         const float q = s8_rowdots(bufA, S8_LD, 1, wq);
         float *Q = tgt ? A.QT : A.QP;
         if (lane == 0) Q[(row0 + wave) * 16] = q + bq;
     }
-    SLAB_STAMP(A.tl, 13);
+    S8_STAMP(13);
 }
 
 // dY of the top hidden layer from a per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0).
@@ -643,4 +663,294 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         A.part[2 * nslab + slab] = keep_u;
     }
     S8_STAMP(9);
+}
+
+
+// ===================================================================================================================
+// Merged forward + backward: one launch per update instead of two.
+//   chain 0 (critic side):  actor_target -> critic_target -> Q';  critic(x, a) -> Q;  critic loss;  critic dX chain
+//   chain 1 (actor side):   actor -> critic(x, pi(x)) -> Q_pi;  actor loss;  dX through the critic and the actor
+//   chain 2: the workgroup that draws the next update's HER indices (as in k_bwd_slab8)
+// Both chains are 8 256x256 layers long, no workgroup waits for another.  What the split kernels hand over through
+// global memory stays on chip here: Q / Q' / reward / action / tanh in LDS or registers, the top hidden layer in the
+// LDS slab it was computed in, the ReLU masks as one byte per column (s8_finish); the weight ring runs on from the
+// forward fragment copies into the dX copies without draining.  Arithmetic and summation order are those of
+// k_fwd_slab8 + k_bwd_slab8 (same device functions), so the results are bit-identical.
+struct FbSlabArgs {
+    FwdSlabArgs f;
+    BwdSlabArgs b;
+};
+
+__device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 2 * i;
+        const float h = buf[r * S8_LD + c];
+        buf[r * S8_LD + c] = (h > 0.f) ? dq_rows[r] * w4c : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_slab8(const FbSlabArgs P) {
+    const FwdSlabArgs &A = P.f;
+    const BwdSlabArgs &Bk = P.b;
+    __shared__ __attribute__((aligned(16))) float xin[S8_ROWS * S8_LDX];
+    __shared__ __attribute__((aligned(16))) float xin2[S8_ROWS * S8_LDX];
+    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
+    __shared__ float dq[S8_ROWS];
+    __shared__ float rows[3][S8_ROWS];          // per-row scalars: Q' | Q (or Q_pi) | reward
+    __shared__ __attribute__((aligned(16))) float dz[S8_ROWS * 20];
+    __shared__ __attribute__((aligned(16))) float w1t[4 * 256];
+    __shared__ unsigned char msk[5][256];       // ReLU masks: critic h1, h2 | actor h1, h2, h3
+    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
+    const int nslab = A.Mp / S8_ROWS;
+    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
+    const size_t row0 = (size_t)slab * S8_ROWS;
+    const int tid = threadIdx.x, H = A.H;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const NetLayout &la = A.la, &lc = A.lc;
+    const int ca = la.total, ad = A.act_dim;
+    const float invB = 1.0f / (float)Bk.B;
+    RingSlot *ring = wring[wave];
+    int rbase = 0;
+    unsigned long long *tl = nullptr;
+#ifdef SLAB_TIMELINE
+    if (slab == 0 && chain < 2) tl = A.tl + chain * 32;
+#endif
+    if (chain == 2) {   // plan workgroup
+        if (tid >= MT_THREADS) return;
+        mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
+                    reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+        return;
+    }
+    S8_TSTAMP(tl, 0);
+    const SlabNetPtrs &on = A.online;
+    if (chain == 0) {
+        // ------------------------------------------------------------------ critic side
+        const SlabNetPtrs &tn = A.target;
+        const PlanRec rec = s8_plan_rec(A.gs, row0);
+        float4 wbaT[6], wbcT[6], wbcA[6], whT[4], wqT[4], wqA[4];
+        s8_small_prefetch(tn.wf + la.w1, la.K1, wbaT);
+        s8_small_prefetch(tn.wf + ca + lc.w1, lc.K1, wbcT);
+        s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbcA);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            whT[j] = *reinterpret_cast<const float4 *>(tn.canon + la.w4 + (j < ad ? j : ad - 1) * H + 4 * lane);
+        wqT[0] = *reinterpret_cast<const float4 *>(tn.canon + ca + lc.w4 + 4 * lane);
+        wqA[0] = *reinterpret_cast<const float4 *>(on.canon + ca + lc.w4 + 4 * lane);
+        const float bhT = tn.canon[la.b4 + (lane < ad ? lane : 0)];
+        const float bqT = tn.canon[ca + lc.b4], bqA = on.canon[ca + lc.b4];
+        const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
+        __builtin_amdgcn_sched_barrier(0);
+        if (A.gs.plan) {
+            s8_gather(xin, A.gs, rec, 0, row0, A.ldx, A.act_off, ad, A.max_action, nullptr);
+            s8_gather(xin2, A.gs, rec, 1, row0, A.ldx, A.act_off, ad, A.max_action, const_cast<float *>(A.XA), rows[2]);
+        } else {
+            s8_load(xin, S8_LDX, A.ldx, A.XT + row0 * A.ldx, A.ldx);
+            s8_load(xin2, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
+            if (tid < S8_ROWS) rows[2][tid] = Bk.R[row0 + tid];
+        }
+        s8_ring_prologue(ring, rbase, tn.wf + la.w2);
+        s8_sync();
+        s8_trunk(xin, la, wbaT, tn.wf, tn.canon, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
+                 tn.wf + ca + lc.w2, tl, 1);
+        {   // target actor head -> action block of the target critic's input (models.py:24)
+            const float z = s8_rowdots(bufA, S8_LD, ad, whT);
+            if (lane < ad) {
+                const float th = tanhf(z + bhT);
+                const float u = (A.max_action * th) / A.max_action;
+                xin[wave * S8_LDX + A.act_off + lane] = u;
+                const_cast<float *>(A.XT)[(row0 + wave) * A.ldx + A.act_off + lane] = u;
+            }
+        }
+        s8_sync();
+        S8_TSTAMP(tl, 7);
+        s8_trunk(xin, lc, wbcT, tn.wf + ca, tn.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
+                 on.wf + ca + lc.w2, tl, 8);
+        {
+            const float q = s8_rowdots(bufA, S8_LD, 1, wqT);
+            if (lane == 0) {
+                rows[0][wave] = q + bqT;
+                A.QT[(row0 + wave) * 16] = q + bqT;
+            }
+        }
+        S8_TSTAMP(tl, 13);
+        // critic(x, a): forward with global copies (weight gradients) and masks (dX chain below)
+        s8_trunk(xin2, lc, wbcA, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0, ring, rbase,
+                 on.wd + ca + lc.w3, tl, 14, msk[0], msk[1], nullptr);
+        {
+            const float q = s8_rowdots(bufA, S8_LD, 1, wqA);
+            if (lane == 0) {
+                rows[1][wave] = q + bqA;
+                A.QA[(row0 + wave) * 16] = q + bqA;
+            }
+        }
+        s8_sync();
+        S8_TSTAMP(tl, 18);
+        // ---- critic loss (ddpg_agent.py:255-263)
+        float keep_g = 0.f, keep_a = 0.f;
+        if (tid < S8_ROWS) {
+            const size_t m = row0 + tid;
+            float g = 0.f, sq = 0.f;
+            if ((int)m < Bk.B) {
+                float y = rows[2][tid] + Bk.gamma * rows[0][tid];
+                y = fminf(fmaxf(y, -Bk.clip_ret), 0.f);
+                const float d = y - rows[1][tid];
+                sq = d * d;
+                g = -2.f * d * invB;
+            }
+            dq[tid] = g;
+            for (int o = 4; o > 0; o >>= 1) sq += __shfl_down(sq, o, 8);
+            keep_g = g;
+            keep_a = sq;
+        }
+        s8_sync();
+        s8_head_bwd_inplace(dq, w4c, bufA);   // bufA holds h3 of critic(x, a)
+        s8_sync();
+        S8_TSTAMP(tl, 19);
+        s8_store(bufA, S8_LD, H, Bk.dA3 + row0 * H, H);
+        s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD,
+                     msk[1]);
+        s8_sync();
+        S8_TSTAMP(tl, 20);
+        s8_store(bufB, S8_LD, H, Bk.dA2 + row0 * H, H);
+        s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + ca + lc.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[0]);
+        s8_sync();
+        S8_TSTAMP(tl, 21);
+        s8_store(bufA, S8_LD, H, Bk.dA1 + row0 * H, H);
+        if (tid < S8_ROWS) {
+            Bk.dQA[(row0 + tid) * 16] = keep_g;
+            if (tid == 0) Bk.part[slab] = keep_a;
+        }
+        if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
+            Bk.st->step += 1;
+            adam_prepare(Bk.st, Bk.adam);
+        }
+        S8_TSTAMP(tl, 22);
+        return;
+    }
+    // ---------------------------------------------------------------------- actor side
+    const PlanRec rec = s8_plan_rec(A.gs, row0);
+    float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
+    float w1n[4];
+    s8_small_prefetch(on.wf + la.w1, la.K1, wba);
+    s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        wh[j] = *reinterpret_cast<const float4 *>(on.canon + la.w4 + (j < ad ? j : ad - 1) * H + 4 * lane);
+    wq[0] = *reinterpret_cast<const float4 *>(on.canon + ca + lc.w4 + 4 * lane);
+    const float bh = on.canon[la.b4 + (lane < ad ? lane : 0)];
+    const float bq = on.canon[ca + lc.b4];
+    const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
+    {
+        const float *w1 = on.canon + ca + lc.w1 + (size_t)(tid & 255) * lc.K1 + A.act_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1n[j] = w1[j < ad ? j : ad - 1];
+    }
+    s8_small_prefetch(on.wd + la.w4, 16, wb4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
+    else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
+    s8_ring_prologue(ring, rbase, on.wf + la.w2);
+    s8_sync();
+    s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
+             tl, 1, msk[2], msk[3], msk[4]);
+    float u_mine = 0.f, th_mine = 0.f;
+    {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
+        const float z = s8_rowdots(bufA, S8_LD, ad, wh);
+        if (lane < ad) {
+            th_mine = tanhf(z + bh);
+            u_mine = (A.max_action * th_mine) / A.max_action;
+            xin[wave * S8_LDX + A.act_off + lane] = u_mine;
+            A.XP[(row0 + wave) * A.ldx + A.act_off + lane] = u_mine;
+            A.TP[(row0 + wave) * 16 + lane] = th_mine;
+        }
+    }
+    s8_sync();
+    S8_TSTAMP(tl, 7);
+    s8_trunk(xin, lc, wbc, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
+             on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr);
+    {
+        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
+        if (lane == 0) {
+            rows[1][wave] = q + bq;
+            A.QP[(row0 + wave) * 16] = q + bq;
+        }
+    }
+    if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
+    }
+    s8_sync();
+    S8_TSTAMP(tl, 13);
+    // ---- actor loss (ddpg_agent.py:265-267)
+    float keep_q = 0.f, keep_u = 0.f;
+    if (tid < S8_ROWS) {
+        const size_t m = row0 + tid;
+        const bool live = (int)m < Bk.B;
+        dq[tid] = live ? -invB : 0.f;
+        float sq = live ? rows[1][tid] : 0.f, su = 0.f;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ad) {
+                    const float u = xin[tid * S8_LDX + A.act_off + j];
+                    su += u * u;
+                }
+        }
+        for (int o = 4; o > 0; o >>= 1) {
+            sq += __shfl_down(sq, o, 8);
+            su += __shfl_down(su, o, 8);
+        }
+        keep_q = sq;
+        keep_u = su;
+    }
+    s8_sync();
+    s8_head_bwd_inplace(dq, w4c, bufA);   // bufA holds h3 of critic(x, pi(x))
+    s8_sync();
+    S8_TSTAMP(tl, 14);
+    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[1]);
+    s8_sync();
+    S8_TSTAMP(tl, 15);
+    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + ca + lc.w2, on.wd + la.w3, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[0]);
+    s8_sync();
+    S8_TSTAMP(tl, 16);
+    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh; lane j owns action j
+        float4 w1g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
+        const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
+        if (lane < 16) {
+            const size_t m = row0 + wave;
+            float v = 0.f;
+            if (lane < ad && (int)m < Bk.B) {
+                const float gu = Bk.action_l2 * (2.f * u_mine / (float)(Bk.B * ad)) + sj;
+                const float gt = (gu / A.max_action) * A.max_action;
+                v = gt * (1.f - th_mine * th_mine);
+            }
+            dz[wave * 20 + lane] = v;
+            Bk.dZ[m * 16 + lane] = v;
+        }
+    }
+    s8_sync();
+    S8_TSTAMP(tl, 17);
+    s8_small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[4]);
+    s8_sync();
+    S8_TSTAMP(tl, 18);
+    s8_store(bufB, S8_LD, H, Bk.dK3 + row0 * H, H);
+    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[3]);
+    s8_sync();
+    S8_TSTAMP(tl, 19);
+    s8_store(bufA, S8_LD, H, Bk.dK2 + row0 * H, H);
+    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + la.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[2]);
+    s8_sync();
+    S8_TSTAMP(tl, 20);
+    s8_store(bufB, S8_LD, H, Bk.dK1 + row0 * H, H);
+    if (tid == 0) {
+        Bk.part[nslab + slab] = keep_q;
+        Bk.part[2 * nslab + slab] = keep_u;
+    }
+    S8_TSTAMP(tl, 21);
 }

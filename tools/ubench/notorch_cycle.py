@@ -56,10 +56,10 @@ for nb in (40,):
     dt = time.perf_counter() - t0
     print(f"n_batches={nb}: {1e6*dt/(reps*nb):.1f} us/step  ({1e6*dt/reps:.0f} us/cycle)")
 tl = (C.c_uint64 * 192)(); _lib.check(lib.hp_agent_debug_timeline(h, tl))
-for ch, nm in ((0, "fwd T"), (1, "fwd A"), (2, "fwd P"), (3, "bwd critic"), (4, "bwd actor")):
-    v = [tl[ch * 32 + k] for k in range(16)]
+for ch, nm in ((0, "fwd T | merged critic side"), (1, "fwd A | merged actor side"), (2, "fwd P"), (3, "bwd critic"), (4, "bwd actor")):
+    v = [tl[ch * 32 + k] for k in range(32)]
     if v[0]:
-        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(16) if v[k]))
+        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(32) if v[k]))
 for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
     v = [tl[base + k] for k in range(8)]
     if v[0]:
