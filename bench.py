@@ -271,8 +271,13 @@ def main():
         # algorithmic MACs per transition (minimal algorithm): 5 forward passes 699,648;
         # backward 683,264 = 395,776 (dX chains) + 287,488 (weight gradients)
         macs = {"forward": 699_648, "backward_dx": 395_776, "weight_grad": 287_488}
+        merged = prof["backward_dx"]["launches_per_step"] == 0   # slab8: forward + backward dX in ONE kernel
+        if merged:
+            macs = {"forward_backward_dx": macs["forward"] + macs["backward_dx"], "weight_grad": macs["weight_grad"]}
+            prof["forward_backward_dx"] = prof.pop("forward")
+            prof.pop("backward_dx")
         ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
-        kern = {"forward": "k_fwd_slab8", "backward_dx": "k_bwd_slab8",
+        kern = {"forward": "k_fwd_slab", "backward_dx": "k_bwd_slab", "forward_backward_dx": "k_fb_slab8",
                 "weight_grad": "k_gemm_lds_adam (8 dW problems + Adam epilogue)"}
         per = {}
         for k, m in macs.items():
@@ -302,14 +307,14 @@ def main():
                 "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
                 "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
                 "event_pair_empty_us": round(ev_floor_us, 3),
-                "note": "dominant kernel by time; FP32 v_mfma_f32_4x4x1_16b_f32 (8-row slabs).  At batch 256 only 32 slabs x "
-                        "2-3 chains (64-96 of 256 CUs) have work and every chain is 8 dependent layers; a 256x256 layer costs a "
-                        "workgroup ~3.1 us against 1.9 us of MFMA issue, 2.0 us of LDS-DMA weight streaming and 2.6 us for both "
-                        "together in isolation (tools/ubench/stream_bw3.hip, DESIGN.md 3.1).  avg_launch_us = HIP-event "
-                        "pair around each eager launch on the launch stream; an event pair with nothing in between already reads "
-                        "event_pair_empty_us, so the rocprofv3 kernel durations in profiles/ (21.1 / 19.5 / 13.0 us for the three "
-                        "matrix kernels) lie between avg_launch_us and avg_launch_us_minus_empty_pair; achieved/frac use the "
-                        "conservative avg_launch_us",
+                "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup, FP32 "
+                        "v_mfma_f32_4x4x1_16b_f32, 8-row slabs.  At batch 256 there are 32 slabs x 2 chains = 64 workgroups (of "
+                        "256 CUs) and each chain is 16 dependent layers, 8 of them 256x256; such a layer costs a workgroup "
+                        "~3.0 us against 1.9 us of MFMA issue, 2.0 us of LDS-DMA weight streaming and 2.6 us for both together "
+                        "in isolation (tools/ubench/stream_bw3.hip, DESIGN.md 3.1).  avg_launch_us = HIP-event pair around each "
+                        "eager launch on the launch stream; an event pair with nothing in between already reads "
+                        "event_pair_empty_us, so the rocprofv3 kernel durations in profiles/ lie between avg_launch_us and "
+                        "avg_launch_us_minus_empty_pair; achieved/frac use the conservative avg_launch_us",
                 "all_matrix_kernels": per,
             }
         s_ms = prof["sample"]["ms_per_step"]
