@@ -261,7 +261,7 @@ def main():
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
                    "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
                    "parallelism": f"dp{world}" + (
-                       " (RCCL grad SUM all-reduce per update + normalizer MEAN per cycle, " +
+                       " (RCCL grad SUM all-reduce per update [reference semantics, utils.py:47] + normalizer MEAN per cycle, " +
                        ("issued by the library inside the cycle hipGraph)" if r.agent._native_comm is not None
                         else "issued through torch.distributed, host-driven loop)") if world > 1 else ""),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",

@@ -53,7 +53,8 @@ const char *hp_last_error(void);
 
 /* ---- context ---------------------------------------------------------------------- */
 int hp_ctx_create(int device_id, hp_ctx **out);
-/* stream == NULL selects a stream owned by the context */
+/* stream == NULL selects a stream owned by the context; to run on the legacy default stream (e.g. to be ordered
+ * with a framework that uses it) pass hipStreamLegacy, i.e. (void *)1 */
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
@@ -216,6 +217,10 @@ void hp_comm_destroy(hp_comm *comm);
  * normalizer sums), so the data-parallel loop needs no host round trip per update and stays inside
  * the cycle's hipGraph.  The split-phase calls above keep working for callers with their own transport. */
 int hp_agent_set_comm(hp_agent *ag, hp_comm *comm);
+/* Reduction applied to the gradients when a communicator is attached: 0 (default) = SUM, exactly utils.py:47 -- N
+ * ranks therefore step with N times the single-rank gradient; 1 = MEAN (SUM / world size), for callers who want the
+ * learning rate to keep its single-rank meaning at a larger global batch. */
+int hp_agent_set_grad_reduce(hp_agent *ag, int32_t mean);
 /* diagnostic: 0 = no cycle built yet, 1 = hp_agent_train_cycle replays a cached hipGraph, 2 = it issues eager
  * launches because a capture containing collectives was refused by the runtime */
 int hp_agent_cycle_mode(hp_agent *ag, int32_t *mode);

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "hp_comm_destroy": (None, [C.c_void_p]),
     "hp_agent_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_agent_cycle_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "hp_agent_set_grad_reduce": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
                                        f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
@@ -193,7 +194,9 @@ class Context:
         import torch
 
         torch.cuda.set_device(self.device_id)
-        self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream)
+        # torch's default stream has handle 0, which hp_ctx_set_stream reads as "the context's own stream": name the
+        # legacy default stream explicitly (hipStreamLegacy == 1), or the two sides would run unordered
+        self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream or 1)
 
     def synchronize(self):
         check(self.lib.hp_ctx_synchronize(self.h))

@@ -129,12 +129,27 @@ __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi)
 // four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
 // latency of p / m / v is paid once, not once per element (scalar version: the store to p[idx] may alias the next
 // element's load, which serialises them)
+struct AdamState4 {   // optimizer state of 4 consecutive elements + the step scalars, fetched ahead of the gradient
+    float4 p, m, v;
+    float neg_step_size, bc2_sqrt;
+};
+__device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, int idx0) {
+    S.neg_step_size = (idx0 < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
+    S.bc2_sqrt = F.st->bc2_sqrt;
+    S.p = *reinterpret_cast<const float4 *>(F.p + idx0);
+    S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
+    S.v = *reinterpret_cast<const float4 *>(F.v + idx0);
+}
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S);
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
-    const float neg_step_size = (idx0 < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
-    const float bc2_sqrt = F.st->bc2_sqrt;
-    const float4 p4 = *reinterpret_cast<const float4 *>(F.p + idx0);
-    const float4 m4 = *reinterpret_cast<const float4 *>(F.m + idx0);
-    const float4 v4 = *reinterpret_cast<const float4 *>(F.v + idx0);
+    AdamState4 S;
+    adam_fetch4(S, F, idx0);
+    adam_apply4(F, idx0, g, S);
+}
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S) {
+    const float neg_step_size = S.neg_step_size;
+    const float bc2_sqrt = S.bc2_sqrt;
+    const float4 p4 = S.p, m4 = S.m, v4 = S.v;
     float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -224,6 +239,7 @@ struct hp_agent {
     std::vector<void *> owned;
     // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
     hp_comm *comm = nullptr;
+    bool grad_mean = false;       // divide the all-reduced gradients by the world size (default: SUM, like the reference)
     bool comm_warm = false;       // the collectives of a cycle have each run once outside a capture
     bool graph_refused = false;   // capturing the cycle with collectives failed once: stay on eager launches
     // cycle graph cache
@@ -1068,7 +1084,9 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         if (with_adam) {
             // utils.sync_grads (utils.py:43-48): SUM over ranks between backward and the optimizer step; one
             // all-reduce covers both networks (the reference sends the actor's and the critic's separately)
-            if (a->comm) HP_TRY(comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
+            if (a->comm)
+                HP_TRY(a->grad_mean ? comm_allreduce_mean_f32(a->comm, a->grads, (size_t)a->n_arena)
+                                    : comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
             if (!fused) HP_TRY(enqueue_adam(a));
         }
     }
@@ -1406,6 +1424,13 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 }
 
 extern "C" {
+
+int hp_agent_set_grad_reduce(hp_agent *a, int32_t mean) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_grad_reduce: null handle");
+    if (a->grad_mean != (mean != 0)) drop_graph(a);
+    a->grad_mean = mean != 0;
+    return HP_OK;
+}
 
 // diagnostic: how hp_agent_train_cycle currently runs -- 0 nothing built yet, 1 cached hipGraph, 2 eager launches
 // (a capture containing collectives was refused)

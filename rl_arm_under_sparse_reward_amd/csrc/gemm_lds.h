@@ -100,6 +100,13 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
             ev[0] = b4.x; ev[1] = b4.y; ev[2] = b4.z; ev[3] = b4.w;
         }
     }
+    // ADAM: the optimizer state of this thread's 4 output elements comes in now as well -- cold loads whose latency
+    // would otherwise sit between the last MFMA and the parameter store
+    AdamState4 ast;
+    const bool adam_vec = ADAM && etile && (en + 3 < p.n_store);
+    if (ADAM) {
+        if (adam_vec) adam_fetch4(ast, *F, (int)(p.C - F->grads_base) + em * p.ldc + en);
+    }
     f32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
     float as0 = 0.f, as1 = 0.f;
     const float *Abase = p.A + (long long)m0 * p.a_si;
@@ -205,8 +212,8 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
     }
     if (ADAM) {
         const int base = (int)(p.C - F->grads_base) + em * p.ldc + en;
-        if (en + 3 < p.n_store) {
-            adam_apply4(*F, base, v);
+        if (adam_vec) {
+            adam_apply4(*F, base, v, ast);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

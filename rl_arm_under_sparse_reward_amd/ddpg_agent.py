@@ -73,6 +73,10 @@ class ddpg_agent:
         self._native_comm = self.comm.attach_native(self.ctx)
         if self._native_comm is not None:
             _lib.check(self.lib.hp_agent_set_comm(self.h, self._native_comm))
+        self._grad_mean = str(getattr(args, "grad_reduce", "sum")).lower() == "mean"
+        if getattr(args, "grad_reduce", "sum") not in ("sum", "mean"):
+            raise ValueError("grad_reduce must be 'sum' (reference semantics) or 'mean'")
+        _lib.check(self.lib.hp_agent_set_grad_reduce(self.h, int(self._grad_mean)))
         self._broadcast_params(self.comm)                       # sync_networks x2 (ddpg_agent.py:27-28)
         _lib.check(self.lib.hp_agent_sync_targets(self.h))      # targets := online (ddpg_agent.py:33-34)
         # her sampler + replay buffer (ddpg_agent.py:45-47)
@@ -132,7 +136,10 @@ class ddpg_agent:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_grad_buffer(self.h, C.byref(p), C.byref(n)))
-        comm.allreduce_sum_device(p.value, n.value)
+        if self._grad_mean:
+            comm.allreduce_mean_device(p.value, n.value)
+        else:
+            comm.allreduce_sum_device(p.value, n.value)                  # utils.py:47
 
     def _actor_forward(self, slot, x):
         x = _lib.as_f32(x)

@@ -235,8 +235,9 @@ def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
             agent.last_losses(n_cycles * n_batches), agent.o_norm.mean, agent.g_norm.std)
 
 
-@pytest.mark.parametrize("transport,graph", [("torch", False), ("native", False), ("native", True)])
-def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, monkeypatch):
+@pytest.mark.parametrize("transport,graph,reduce", [("torch", False, "sum"), ("native", False, "sum"), ("native", True, "sum"),
+                                                    ("torch", False, "mean"), ("native", True, "mean")])
+def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, monkeypatch):
     """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
     begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
     fused single-rank path bit for bit (a 1-rank SUM / MEAN is the identity).  transport "torch": collectives
@@ -261,7 +262,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, monkeypat
         comm = Communicator(0, force=True)
         assert comm.active and comm.world_size == 1
         torch.manual_seed(0)
-        args = Args(batch_size=256, buffer_size=32 * 100)
+        args = Args(batch_size=256, buffer_size=32 * 100, grad_reduce=reduce)   # 1 rank: SUM == MEAN == identity
         rng = fresh_rng(21)
         agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=comm, rng=rng)
         assert (comm.native is not None) == (transport == "native")
