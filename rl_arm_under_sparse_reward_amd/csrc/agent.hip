@@ -219,6 +219,7 @@ struct hp_agent {
     int n_arena = 0;
     float *params = nullptr, *targets = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     float *XA = nullptr, *XP = nullptr, *XT = nullptr, *R = nullptr, *TP = nullptr;
+    float *XA2 = nullptr, *XP2 = nullptr, *XT2 = nullptr, *R2 = nullptr;   // second input set (gather-ahead ping-pong)
     Pass AT, CT, CA, AP, CP;
     float *QT = nullptr, *QA = nullptr, *QP = nullptr, *dQA = nullptr, *dQP = nullptr;
     float *dA3 = nullptr, *dA2 = nullptr, *dA1 = nullptr;  // critic-loss path
@@ -232,6 +233,7 @@ struct hp_agent {
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
     bool merged_fb = true; // slab8: forward and backward in ONE launch (RLARM_FB=split: two kernels, for A/B)
+    bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
@@ -725,10 +727,16 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     hp_norm *on, *gn;
     const PlanRec *plan;
     double sq;
-    // slab engine: draw the NEXT update's index plan in a spare workgroup of the backward kernel
+    // slab engine: draw a LATER update's index plan in a spare workgroup of this update's kernel
     hp_rng *rng = nullptr;
     PlanRec *next_plan = nullptr;
     double future_p = 0.0;
+    // merged slab8 kernel: input sets ping-pong between updates.  xset = the set this update reads (and, when it
+    // gathers in-kernel, writes); pregathered = a previous launch already filled it; ahead_plan = plan of the NEXT
+    // update, gathered by spare workgroups of this launch into the other set.
+    int xset = 0;
+    bool pregathered = false;
+    const PlanRec *ahead_plan = nullptr;
 };
 
 static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam);
@@ -909,6 +917,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     hipStream_t s = a->ctx->stream;
     const int nslab = Mp / (a->slab8 ? S8_ROWS : SL_ROWS);
     FbSlabArgs P;
+    const int xs = gc ? gc->xset : 0;
+    float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
     {
         FwdSlabArgs &A = P.f;
         A.tl = a->timeline;
@@ -918,16 +928,17 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         if (gc) {
             hp_buffer *b = gc->b;
             A.gs.obs = b->d_obs; A.gs.ag = b->d_ag; A.gs.g = b->d_g; A.gs.act = b->d_act;
-            A.gs.plan = gc->plan; A.gs.plan_any = gc->plan; A.gs.onz = gc->on->d; A.gs.gnz = gc->gn->d;
+            A.gs.plan = gc->pregathered ? nullptr : gc->plan; A.gs.plan_any = gc->plan;
+            A.gs.onz = gc->on->d; A.gs.gnz = gc->gn->d;
             A.gs.sq_threshold = gc->sq; A.gs.clip_obs = a->cfg.clip_obs; A.gs.clip_range = a->cfg.clip_range;
             A.gs.T = b->T; A.gs.obs_dim = b->obs_dim; A.gs.goal_dim = b->goal_dim; A.gs.B = a->B;
-            A.gs.R = a->R;
+            A.gs.R = sR;
         }
         A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
         A.target = SlabNetPtrs{a->fragFT, nullptr, a->targets};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim; A.Mp = Mp;
         A.max_action = (float)a->cfg.max_action;
-        A.XA = a->XA; A.XT = a->XT; A.XP = a->XP; A.TP = a->TP;
+        A.XA = sXA; A.XT = sXT; A.XP = sXP; A.TP = a->TP;
         A.CAh1 = a->CA.h1; A.CAh2 = a->CA.h2; A.CAh3 = a->CA.h3;
         A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
         A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
@@ -942,7 +953,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.B = a->B; A.Mp = Mp;
         A.max_action = (float)a->cfg.max_action; A.gamma = (float)a->cfg.gamma;
         A.clip_ret = (float)(1.0 / (1.0 - a->cfg.gamma)); A.action_l2 = (float)a->cfg.action_l2;
-        A.QT = a->QT; A.QA = a->QA; A.QP = a->QP; A.R = a->R; A.XP = a->XP; A.TP = a->TP;
+        A.QT = a->QT; A.QA = a->QA; A.QP = a->QP; A.R = sR; A.XP = sXP; A.TP = a->TP;
         A.CAh1 = a->CA.h1; A.CAh2 = a->CA.h2; A.CAh3 = a->CA.h3;
         A.APh1 = a->AP.h1; A.APh2 = a->AP.h2; A.APh3 = a->AP.h3;
         A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
@@ -960,7 +971,18 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     if (a->slab8 && a->merged_fb) {
         // one launch: each workgroup carries its rows through forward AND backward (k_fb_slab8)
         ProfScope ps(a, PROF_GEMM_FWD);
-        hipLaunchKernelGGL(k_fb_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, P);
+        P.n_plan = ride ? 1 : 0;
+        P.n_ahead = 0;
+        P.ahead = P.f.gs;
+        P.aXT = P.aXA = P.aXP = nullptr;
+        if (gc && gc->ahead_plan) {   // next update's inputs into the other set
+            P.n_ahead = S8_AHEAD_WGS;
+            P.ahead.plan = gc->ahead_plan;
+            P.ahead.plan_any = gc->ahead_plan;
+            P.ahead.R = xs ? a->R : a->R2;
+            P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
+        }
+        hipLaunchKernelGGL(k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
     } else {
         {
@@ -982,11 +1004,11 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
         add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
         add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
-        add_dw(L, a->dA1, H, H, a->XA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+        add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
         add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
         add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
         add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
-        add_dw(L, a->dK1, H, H, a->XP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, adam_fuse(a));
@@ -1068,16 +1090,26 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // a spare workgroup of its backward kernel (same stream order of draws, so the same indices).  Layer engine:
     // one kernel draws all of them (nothing else consumes the stream in between, like the reference's inner loop).
     const bool ride = a->slab && with_adam;
+    // merged slab8 kernel: plans are drawn TWO updates ahead so that spare workgroups of update u can gather the inputs
+    // of update u+1 from a plan that an earlier launch finished (the order of draws in the stream is unchanged)
+    const bool ahead = ride && a->slab8 && a->merged_fb && a->gather_ahead;
+    const int lead = ahead ? 2 : 1;
     {
         ProfScope ps(a, PROF_PLAN);
-        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? 1 : n_updates, future_p, a->plan.as<PlanRec>()));
+        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? (n_updates < lead ? n_updates : lead) : n_updates,
+                               future_p, a->plan.as<PlanRec>()));
     }
     for (int u = 0; u < n_updates; ++u) {
         GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
-        if (ride && u + 1 < n_updates) {
+        if (ride && u + lead < n_updates) {
             gc.rng = rng;
-            gc.next_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
+            gc.next_plan = a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B;
             gc.future_p = future_p;
+        }
+        if (ahead) {
+            gc.xset = u & 1;
+            gc.pregathered = u > 0;
+            if (u + 1 < n_updates) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
         bool fused = false;
         HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm, &fused));
@@ -1190,6 +1222,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->params, a->n_arena); A(&a->targets, a->n_arena); A(&a->grads, a->n_arena);
     A(&a->adam_m, a->n_arena); A(&a->adam_v, a->n_arena);
     A(&a->XA, Mp * ldx); A(&a->XP, Mp * ldx); A(&a->XT, Mp * ldx); A(&a->R, Mp); A(&a->TP, 2 * Mp * 16);
+    A(&a->XA2, Mp * ldx); A(&a->XP2, Mp * ldx); A(&a->XT2, Mp * ldx); A(&a->R2, Mp);
     for (Pass *ps : {&a->AT, &a->CT, &a->CA, &a->AP, &a->CP}) { A(&ps->h1, Mp * H); A(&ps->h2, Mp * H); A(&ps->h3, Mp * H); }
     A(&a->QT, Mp * 16); A(&a->QA, Mp * 16); A(&a->QP, Mp * 16); A(&a->dQA, Mp * 16); A(&a->dQP, Mp * 16);
     A(&a->dA3, Mp * H); A(&a->dA2, Mp * H); A(&a->dA1, Mp * H);
@@ -1204,6 +1237,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
         const char *fb = getenv("RLARM_FB");
         a->merged_fb = !(fb && strcmp(fb, "split") == 0);
+        const char *ah = getenv("RLARM_AHEAD");
+        a->gather_ahead = !(ah && ah[0] == '0');
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);

@@ -24,6 +24,7 @@
 #define S8_LD 260
 #define S8_LDX 52
 #define S8_RING 12
+#define S8_AHEAD_WGS 4   // spare workgroups that gather the next update's inputs
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
 #define S8_TSTAMP(tl, k) do { if ((tl) && threadIdx.x == 0) (tl)[k] = wall_clock64(); } while (0)
@@ -679,7 +680,84 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 struct FbSlabArgs {
     FwdSlabArgs f;
     BwdSlabArgs b;
+    // Spare workgroups behind the 2 * nslab chain workgroups: n_plan (0/1) draws the index plan of a LATER update
+    // (b.next_plan), n_ahead gather the NEXT update's network inputs from its already drawn plan into the other input
+    // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
+    // (plan record -> replay-buffer rows).  The plan they read was finished by an EARLIER launch: no in-kernel handshake.
+    int n_plan, n_ahead;
+    GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
+    float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
 };
+
+// HER gather of rows [g * per, (g + 1) * per) of a minibatch into global input sets (same arithmetic as s8_gather:
+// her.py:26-38, ddpg_agent.py:228-243, normalizer.py:67-70).  One wavefront per row, 4 rows in flight per wavefront.
+__device__ __forceinline__ void s8_gather_ahead(const GatherSrc &G, float *XT, float *XA, float *XP, int ldx, int act_off,
+                                                int act_dim, float max_action, int g, int ng) {
+    const int wave = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int od = G.obs_dim, gd = G.goal_dim;
+    const int per = (G.B + ng - 1) / ng, r_begin = g * per, r_end = (r_begin + per < G.B) ? r_begin + per : G.B;
+    // this lane's normalizer statistics do not depend on the row
+    const bool is_obs = c < od, is_goal = !is_obs && c < od + gd, is_act = c >= act_off && c < act_off + act_dim;
+    float mu = 0.f;
+    double sd = 1.0;
+    if (is_obs) { mu = G.onz->mean[c]; sd = G.onz->std[c]; }
+    if (is_goal) { mu = G.gnz->mean[c - od]; sd = G.gnz->std[c - od]; }
+    for (int base = r_begin + wave * 4; base < r_end; base += S8_WAVES * 4) {
+        PlanRec rec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[k] = G.plan[(base + k < r_end) ? base + k : r_end - 1];
+        double v0[4], v1[4], an[4], gs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long e = rec[k].e;
+            const int t = rec[k].t;
+            const double *obs0 = G.obs + (e * (G.T + 1) + t) * od;
+            const double *g_src = rec[k].her ? G.ag + (e * (G.T + 1) + rec[k].fut) * gd : G.g + (e * G.T + t) * gd;
+            const double *ag_next = G.ag + (e * (G.T + 1) + t + 1) * gd;
+            // address-selected, unconditional loads (padding lanes re-read element 0)
+            const double *p0 = is_obs ? obs0 + od + c : (is_goal ? g_src + (c - od) : obs0);
+            const double *p1 = is_obs ? obs0 + c : (is_goal ? g_src + (c - od) : (is_act ? G.act + (e * G.T + t) * act_dim + (c - act_off) : obs0));
+            v0[k] = *p0;
+            v1[k] = *p1;
+            const int cc = c < gd ? c : gd - 1;   // lanes 0..gd-1 carry the reward operands
+            an[k] = ag_next[cc];
+            gs[k] = g_src[cc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = base + k;
+            if (m >= r_end) continue;
+            if (c < ldx) {
+                float x0 = 0.f, x1 = 0.f;
+                if (is_obs || is_goal) {
+                    double a = fmin(fmax(v0[k], -G.clip_obs), G.clip_obs);
+                    a = __ddiv_rn(__dsub_rn(a, (double)mu), sd);
+                    x0 = (float)fmin(fmax(a, -G.clip_range), G.clip_range);
+                    double b = fmin(fmax(v1[k], -G.clip_obs), G.clip_obs);
+                    b = __ddiv_rn(__dsub_rn(b, (double)mu), sd);
+                    x1 = (float)fmin(fmax(b, -G.clip_range), G.clip_range);
+                } else if (is_act) {
+                    x1 = (float)v1[k] / max_action;
+                }
+                if (c < act_off) {
+                    XT[(size_t)m * ldx + c] = x0;
+                    XP[(size_t)m * ldx + c] = x1;
+                }
+                XA[(size_t)m * ldx + c] = x1;
+            }
+            // reward: d^2 summed in index order by lane 0 (values of lanes 0..gd-1 via shuffles, same operation order
+            // as the in-kernel gather)
+            const double d = __dsub_rn(an[k], gs[k]);
+            const double sq = __dmul_rn(d, d);
+            double ssum = 0.0;
+            for (int j = 0; j < gd; ++j) {
+                const double sj = __shfl(sq, j);
+                ssum = (j == 0) ? sj : __dadd_rn(ssum, sj);
+            }
+            if (c == 0) G.R[m] = (ssum >= G.sq_threshold) ? -1.0f : -0.0f;
+        }
+    }
+}
 
 __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
     const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
@@ -719,10 +797,15 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #ifdef SLAB_TIMELINE
     if (slab == 0 && chain < 2) tl = A.tl + chain * 32;
 #endif
-    if (chain == 2) {   // plan workgroup
-        if (tid >= MT_THREADS) return;
-        mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
-                    reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+    if ((int)blockIdx.x >= 2 * nslab) {   // spare workgroups (see FbSlabArgs)
+        const int extra = (int)blockIdx.x - 2 * nslab;
+        if (extra < P.n_plan) {
+            if (tid >= MT_THREADS) return;
+            mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
+                        reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+        } else {
+            s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, extra - P.n_plan, P.n_ahead);
+        }
         return;
     }
     S8_TSTAMP(tl, 0);
