@@ -48,20 +48,31 @@ __device__ __forceinline__ void gl_stage(float *lds, const float *base, long lon
             *reinterpret_cast<float4 *>(lds + idx * GL_ROWK_LD + 4 * k4) = v;
         }
     } else {
-        const int total = kc * 8;  // 8 float4 per reduction row
-        for (int f = tid; f < total; f += GL_THREADS) {
-            const int k = f >> 3, i4 = f & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * i4 < valid) v = *reinterpret_cast<const float4 *>(base + k * s_k + 4 * i4);
-            *reinterpret_cast<float4 *>(lds + k * GL_KMAJ_LD + 4 * i4) = v;
+        // k-major operand: LDS-DMA (global_load_lds_dwordx4, ~3.6x the per-CU rate of global_load -> VGPR -> ds_write).
+        // A wave instruction fills 8 consecutive 128-byte LDS rows; which element lands where is chosen per lane through
+        // the SOURCE address, so the image can be swizzled for conflict-free fragment reads without padding:
+        //   element (k, col) lives at row k ^ ((k >> 3) & 1), 16-byte chunk (col >> 2) ^ (((k >> 2) & 1) << 2)
+        // (gl_frag: the 4 q-groups of a wavefront then hit 4 different 16-bank groups).  Columns past `valid`
+        // re-read the last valid chunk: their products are computed and never stored.
+        const int wave = tid >> 6, lane = tid & 63;
+        const int nchunk = valid >> 2;
+        for (int R = 8 * wave; R < kc; R += 8 * GL_WAVES) {
+            const int rowp = R + (lane >> 3);
+            const int k = rowp ^ ((rowp >> 3) & 1);
+            int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
+            gch = gch < nchunk ? gch : nchunk - 1;
+            __builtin_amdgcn_global_load_lds(base + k * s_k + 4 * gch, lds + R * 32, 16, 0, 0);
         }
     }
 }
 
 __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag, int S, int i, int q) {
     if (rowk) return *reinterpret_cast<const float4 *>(lds + (frag * 16 + i) * GL_ROWK_LD + 16 * S + 4 * q);
-    const float *p = lds + (16 * S + 4 * q) * GL_KMAJ_LD + frag * 16 + i;
-    return make_float4(p[0], p[GL_KMAJ_LD], p[2 * GL_KMAJ_LD], p[3 * GL_KMAJ_LD]);
+    // swizzled k-major image (gl_stage): k = 16 S + 4 q + c
+    const int fr = frag ^ (q & 1);
+    const float *p = lds + fr * 16 + i;
+    const int k0 = 16 * S + 4 * q, x = q >> 1;
+    return make_float4(p[((k0 + 0) ^ x) * 32], p[((k0 + 1) ^ x) * 32], p[((k0 + 2) ^ x) * 32], p[((k0 + 3) ^ x) * 32]);
 }
 
 // ADAM = true (single-rank weight-gradient launch of the slab engines): the epilogue applies the optimizer step to
