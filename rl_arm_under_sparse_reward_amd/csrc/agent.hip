@@ -233,6 +233,7 @@ struct hp_agent {
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
     bool merged_fb = true; // slab8: forward and backward in ONE launch (RLARM_FB=split: two kernels, for A/B)
+    bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
@@ -884,8 +885,7 @@ static int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, 
     // serialised cold round trips per thread for p/m/v) measured 92.9 vs 67.5 us per update and was parked; with four
     // elements per thread (one float4 load per state array, float4 store into the forward fragment copy) it is the
     // faster path, 57.2 vs 60.5 us, and the default.  RLARM_FUSE_ADAM=0 keeps the separate k_adam_frag4 launch for A/B.
-    static const bool kFuseAdam = [] { const char *e = getenv("RLARM_FUSE_ADAM"); return !(e && e[0] == '0'); }();
-    fuse_adam = fuse_adam && kFuseAdam;
+    fuse_adam = fuse_adam && a->fuse_adam_ok;
     if (fused) *fused = a->slab && fuse_adam;
     if (a->slab) return enqueue_forward_backward_slab(a, gc, fuse_adam);   // gather fused into the forward kernel
     if (gc) HP_TRY(enqueue_gather(a, gc->b, gc->on, gc->gn, gc->plan, gc->sq));
@@ -1237,6 +1237,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
         const char *fb = getenv("RLARM_FB");
         a->merged_fb = !(fb && strcmp(fb, "split") == 0);
+        const char *fa = getenv("RLARM_FUSE_ADAM");
+        a->fuse_adam_ok = !(fa && fa[0] == '0');
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
     }
