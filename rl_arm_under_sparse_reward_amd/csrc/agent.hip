@@ -1445,15 +1445,18 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
                               double sq, int n_batches, PlanRec *norm_plan) {
     // ddpg_agent._update_normalizer (:187-212)
     HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, b->T, 1, future_p, norm_plan));
-    HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs));
-    HP_TRY(norm_launch_begin(on));
-    HP_TRY(norm_launch_begin(gn));
-    if (a->comm) {   // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
+    if (!a->comm) {   // single rank: update + recompute_stats of both normalizers in one launch
+        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, true));
+    } else {
+        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
+        HP_TRY(norm_launch_begin(on));
+        HP_TRY(norm_launch_begin(gn));
+        // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
         HP_TRY(comm_allreduce_mean_f32(a->comm, on->d->sync, (size_t)(2 * on->size + 1)));
         HP_TRY(comm_allreduce_mean_f32(a->comm, gn->d->sync, (size_t)(2 * gn->size + 1)));
+        HP_TRY(norm_launch_end(on));
+        HP_TRY(norm_launch_end(gn));
     }
-    HP_TRY(norm_launch_end(on));
-    HP_TRY(norm_launch_end(gn));
     // ddpg_agent.py:145-150
     HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq, n_batches, true));
     HP_TRY(enqueue_polyak(a));

@@ -195,6 +195,6 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
 
 // norm.hip
 int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,
-                                 double clip_obs);
+                                 double clip_obs, bool recompute);
 int norm_launch_begin(hp_norm *nz);
 int norm_launch_end(hp_norm *nz);

@@ -38,37 +38,93 @@ __global__ void k_norm_update_rows(NormDev *nz, const double *__restrict__ v, lo
     if (c == 0) nz->local_count[0] = (float)((double)nz->local_count[0] + (double)rows);
 }
 
+// recompute_stats (normalizer.py:40-57) for one column, begin and end in one go (single rank: nothing to exchange in
+// between).  ls / lss / lc: the local accumulators as they stood; same expressions as k_norm_begin + k_norm_end.
+__device__ __forceinline__ void norm_recompute_column(NormDev *nz, int c, int size, float ls, float lss, float lc,
+                                                      double eps_sq, int std_f32, float &cnt_out) {
+    const float cnt = __fadd_rn(nz->total_count[0], lc);
+    cnt_out = cnt;
+    if (c < size) {
+        nz->sync[c] = ls;
+        nz->sync[size + c] = lss;
+        nz->local_sum[c] = 0.f;
+        nz->local_sumsq[c] = 0.f;
+        const float ts = __fadd_rn(nz->total_sum[c], ls);
+        const float tss = __fadd_rn(nz->total_sumsq[c], lss);
+        nz->total_sum[c] = ts;
+        nz->total_sumsq[c] = tss;
+        const float m = (float)__ddiv_rn((double)ts, (double)cnt);
+        nz->mean[c] = m;
+        const float var = __fsub_rn((float)__ddiv_rn((double)tss, (double)cnt), __fmul_rn(m, m));
+        if (std_f32) nz->std[c] = (double)(float)__dsqrt_rn((double)fmaxf((float)eps_sq, var));
+        else nz->std[c] = __dsqrt_rn(fmax(eps_sq, (double)var));
+    }
+}
+
 // ddpg_agent._update_normalizer (:187-212) on the episodes staged by the last store:
-// rows are the HER-sampled transitions in `plan`; obs -> o_norm, (relabelled) g -> g_norm.
+// rows are the HER-sampled transitions in `plan`; obs -> o_norm, (relabelled) g -> g_norm.  The column sums are
+// sequential in the row index (order-exact), but the loads are not: 10 rows are fetched at a time (plan records, then
+// values), which turns 100 dependent round trips into 10.  recompute != 0 (single rank): recompute_stats of both
+// normalizers follows in the same launch.
+#define NORM_UNROLL 10
 __global__ void k_norm_update_from_plan(NormDev *onz, NormDev *gnz, const PlanRec *__restrict__ plan,
                                         long long rows, const double *__restrict__ s_obs,
                                         const double *__restrict__ s_ag, const double *__restrict__ s_g, int T,
-                                        int obs_dim, int goal_dim, double clip_obs) {
+                                        int obs_dim, int goal_dim, double clip_obs, int recompute, double o_eps_sq,
+                                        int o_std_f32, double g_eps_sq, int g_std_f32) {
     const int c = threadIdx.x;
-    if (c < obs_dim) {
-        double s = 0.0, ss = 0.0;
-        for (long long r = 0; r < rows; ++r) {
-            const PlanRec p = plan[r];
-            double x = clipd(s_obs[((long long)p.e * (T + 1) + p.t) * obs_dim + c], -clip_obs, clip_obs);
-            s = __dadd_rn(s, x);
-            ss = __dadd_rn(ss, __dmul_rn(x, x));
+    const bool goal = c >= 64;
+    const int j = goal ? c - 64 : c;
+    NormDev *nz = goal ? gnz : onz;
+    const int size = goal ? goal_dim : obs_dim;
+    const bool act = j < size;
+    double s = 0.0, ss = 0.0;
+    if (act) {
+        for (long long r0 = 0; r0 < rows; r0 += NORM_UNROLL) {
+            PlanRec p[NORM_UNROLL];
+            double x[NORM_UNROLL];
+#pragma unroll
+            for (int k = 0; k < NORM_UNROLL; ++k) p[k] = plan[r0 + k < rows ? r0 + k : rows - 1];
+#pragma unroll
+            for (int k = 0; k < NORM_UNROLL; ++k) {
+                const double *src = !goal ? s_obs + ((long long)p[k].e * (T + 1) + p[k].t) * obs_dim + j
+                                          : (p[k].her ? s_ag + ((long long)p[k].e * (T + 1) + p[k].fut) * goal_dim + j
+                                                      : s_g + ((long long)p[k].e * T + p[k].t) * goal_dim + j);
+                x[k] = *src;
+            }
+#pragma unroll
+            for (int k = 0; k < NORM_UNROLL; ++k)
+                if (r0 + k < rows) {
+                    const double v = clipd(x[k], -clip_obs, clip_obs);
+                    s = __dadd_rn(s, v);
+                    ss = __dadd_rn(ss, __dmul_rn(v, v));
+                }
         }
-        norm_accumulate(onz, c, s, ss);
-    } else if (c >= 64 && c - 64 < goal_dim) {  // second wavefront: goal columns
-        const int j = c - 64;
-        double s = 0.0, ss = 0.0;
-        for (long long r = 0; r < rows; ++r) {
-            const PlanRec p = plan[r];
-            double raw = p.her ? s_ag[((long long)p.e * (T + 1) + p.fut) * goal_dim + j]
-                               : s_g[((long long)p.e * T + p.t) * goal_dim + j];
-            double x = clipd(raw, -clip_obs, clip_obs);
-            s = __dadd_rn(s, x);
-            ss = __dadd_rn(ss, __dmul_rn(x, x));
-        }
-        norm_accumulate(gnz, j, s, ss);
     }
-    if (c == 0) onz->local_count[0] = (float)((double)onz->local_count[0] + (double)rows);
-    if (c == 64) gnz->local_count[0] = (float)((double)gnz->local_count[0] + (double)rows);
+    // normalizer.update: float32 accumulators += float64 column sums; count += rows
+    float ls = 0.f, lss = 0.f;
+    if (act) {
+        ls = (float)__dadd_rn((double)nz->local_sum[j], s);
+        lss = (float)__dadd_rn((double)nz->local_sumsq[j], ss);
+    }
+    const float lc = (float)((double)nz->local_count[0] + (double)rows);
+    __syncthreads();   // every lane has read local_count before lane 0 of its wave rewrites it
+    if (!recompute) {
+        if (act) {
+            nz->local_sum[j] = ls;
+            nz->local_sumsq[j] = lss;
+        }
+        if (j == 0) nz->local_count[0] = lc;
+        return;
+    }
+    float cnt;
+    norm_recompute_column(nz, j, size, ls, lss, lc, goal ? g_eps_sq : o_eps_sq, goal ? g_std_f32 : o_std_f32, cnt);
+    __syncthreads();   // total_count is read by every lane of the wave's normalizer above
+    if (j == 0) {
+        nz->sync[2 * size] = lc;
+        nz->local_count[0] = 0.f;
+        nz->total_count[0] = cnt;
+    }
 }
 
 // recompute_stats part 1 (normalizer.py:41-48): snapshot + reset the local accumulators
@@ -142,10 +198,11 @@ __global__ void k_norm_set(NormDev *nz, const float *mean, const double *std, in
 
 // ------------------------------------------------------------------------------ launchers
 int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,
-                                 double clip_obs) {
+                                 double clip_obs, bool recompute) {
     hipLaunchKernelGGL(k_norm_update_from_plan, dim3(1), dim3(128), 0, o->ctx->stream, o->d, g->d, d_plan,
                        (long long)rows, b->st_obs.as<double>(), b->st_ag.as<double>(), b->st_g.as<double>(), (int)b->T,
-                       (int)b->obs_dim, (int)b->goal_dim, clip_obs);
+                       (int)b->obs_dim, (int)b->goal_dim, clip_obs, recompute ? 1 : 0, o->eps * o->eps, o->std_f32,
+                       g->eps * g->eps, g->std_f32);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -288,7 +345,7 @@ int hp_norm_update_from_staged(hp_buffer *b, hp_rng *rng, hp_norm *o_norm, hp_no
     const int64_t rows = b->T;  // ddpg_agent.py:194 -- num_transitions = T regardless of episode count
     HP_TRY(b->plan.ensure(rows * sizeof(PlanRec)));
     HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, rows, 1, future_p, b->plan.as<PlanRec>()));
-    return norm_launch_update_from_plan(o_norm, g_norm, b, b->plan.as<PlanRec>(), rows, clip_obs);
+    return norm_launch_update_from_plan(o_norm, g_norm, b, b->plan.as<PlanRec>(), rows, clip_obs, false);
 }
 
 void hp_norm_destroy(hp_norm *nz) {
