@@ -56,7 +56,7 @@ def parse():
 class Runner:
     """Builds the device-side state for one rank and advances it in units of steps."""
 
-    def __init__(self, a, rank, world):
+    def __init__(self, a, rank, world, force_dp=False):
         import torch
 
         from rl_arm_under_sparse_reward_amd import _lib
@@ -74,7 +74,8 @@ class Runner:
         args = Args(batch_size=a.batch, buffer_size=a.episodes * 100, replay_k=a.replay_k, seed=125 + rank)
         self.rng = DeviceRandomState(args.seed, ctx=self.ctx)
         torch.manual_seed(0)                 # same initial networks on every rank (plus the broadcast)
-        self.agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=Communicator(local), ctx=self.ctx, rng=self.rng)
+        self.agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=Communicator(local, force=force_dp), ctx=self.ctx,
+                                rng=self.rng)
         # resident shard (BASELINE.md section 3 recipe)
         eps = make_episodes(a.episodes, seed=1 + rank)
         self.agent.buffer.store_episode(eps)
@@ -219,12 +220,18 @@ def main():
         a.gpus = world
     import torch
 
-    if world > 1:
+    # RLARM_BENCH_FORCE_DP=1 (diagnostic): run the data-parallel code path -- process group, library-side RCCL
+    # communicator, collectives inside the cycle graph -- in a 1-rank group, e.g. to check it on a single-GPU box
+    force_dp = world == 1 and os.environ.get("RLARM_BENCH_FORCE_DP") == "1"
+    if world > 1 or force_dp:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
-    r = Runner(a, rank, world)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    r = Runner(a, rank, world, force_dp)
     r.run_steps(a.warmup)
     r.sync()
     barrier(world)
@@ -245,6 +252,9 @@ def main():
         prof = profile_kernels(r)
     if world > 1:
         barrier(world)
+    dp_native = r.agent._native_comm is not None
+    if world > 1 or force_dp:
+        r.agent.close_comm()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -262,8 +272,8 @@ def main():
                    "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
                    "parallelism": f"dp{world}" + (
                        " (RCCL grad SUM all-reduce per update [reference semantics, utils.py:47] + normalizer MEAN per cycle, " +
-                       ("issued by the library inside the cycle hipGraph)" if r.agent._native_comm is not None
-                        else "issued through torch.distributed, host-driven loop)") if world > 1 else ""),
+                       ("issued by the library inside the cycle hipGraph)" if dp_native
+                        else "issued through torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])]},
     }
@@ -327,9 +337,17 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER Python's output at exit:
+    # drain it first so that the JSON record is the last line on stdout
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

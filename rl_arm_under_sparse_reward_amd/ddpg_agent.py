@@ -97,6 +97,15 @@ class ddpg_agent:
         self.success_rates = []
         self.model_path = os.path.join(self.args.save_dir, self.args.env_name)
 
+    def close_comm(self):
+        """Detach and destroy the library-side RCCL communicator (call on every rank before
+        torch.distributed.destroy_process_group / interpreter exit)."""
+        if self._native_comm is not None:
+            self.ctx.synchronize()
+            _lib.check(self.lib.hp_agent_set_comm(self.h, None))
+            self._native_comm = None
+            self.comm.close()
+
     # ------------------------------------------------------------------ parameter plumbing
     def _count(self, slot):
         return int(self.lib.hp_agent_param_count(self.h, slot))

@@ -269,6 +269,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         got = _run_cycles(agent, graph=graph)
         _lib.Context.default().synchronize()
         torch.cuda.synchronize()
+        agent.close_comm()
         del agent
     finally:
         if comm is not None:
