@@ -167,6 +167,9 @@ int64_t hp_agent_param_count(hp_agent *ag, int32_t net);   /* 140548 / 140801 fo
 /* flat float32 vectors in named_parameters() order (utils.py:18-40): fc1.weight, fc1.bias, ... */
 int hp_agent_set_params(hp_agent *ag, int32_t net, const float *flat_host, int64_t n);
 int hp_agent_get_params(hp_agent *ag, int32_t net, float *flat_host, int64_t n);
+/* gradients of the last hp_agent_update_minibatch / hp_agent_forward_backward (the sampled update loops of a single
+ * rank consume the weight gradients in the optimizer epilogue without writing them out; bias gradients are always
+ * written) */
 int hp_agent_get_grads(hp_agent *ag, int32_t net, float *flat_host, int64_t n);  /* net = actor|critic */
 int hp_agent_get_adam(hp_agent *ag, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step);
 

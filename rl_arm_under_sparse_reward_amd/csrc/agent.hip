@@ -106,6 +106,7 @@ struct AdamFuse {
     int nslab, B, act_dim;
     float action_l2;
     float *loss_log;
+    int keep_grads;                   // also write the gradient out (the fused epilogue itself does not need it in memory)
 };
 
 __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
@@ -1011,7 +1012,11 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
-            hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, adam_fuse(a));
+            // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
+            // the ~6.7 MB this kernel leaves dirty in L2 for the end-of-kernel write-back
+            AdamFuse F = adam_fuse(a);
+            F.keep_grads = (gc == nullptr) ? 1 : 0;
+            hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
             HP_TRY(launch_group(a, L, PROF_DW));
@@ -1024,6 +1029,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     AdamFuse F;
     F.p = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
     F.grads_base = a->grads; F.st = a->d_state; F.am = arena_map(a); F.n_actor = a->la.total;
+    F.keep_grads = 1;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? S8_ROWS : SL_ROWS); F.B = a->B; F.act_dim = a->cfg.act_dim;

@@ -214,7 +214,9 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         default: break;
     }
     GL_STAMP(4);
-    if (en + 3 < p.n_store) {
+    if (ADAM && !F->keep_grads) {
+        // gradient consumed by the optimizer epilogue below, not materialised
+    } else if (en + 3 < p.n_store) {
         *reinterpret_cast<float4 *>(p.C + (long long)em * p.ldc + en) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
@@ -231,6 +233,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
                 if (en + j < p.n_store) adam_apply(*F, base + j, v[j]);
         }
     }
+    GL_STAMP(5);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }
