@@ -233,7 +233,6 @@ struct hp_agent {
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
-    bool merged_fb = true; // slab8: forward and backward in ONE launch (RLARM_FB=split: two kernels, for A/B)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -969,7 +968,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.T = ride ? gc->b->T : 0;
         A.plan_batch = a->B;
     }
-    if (a->slab8 && a->merged_fb) {
+    if (a->slab8) {
         // one launch: each workgroup carries its rows through forward AND backward (k_fb_slab8)
         ProfScope ps(a, PROF_GEMM_FWD);
         P.n_plan = ride ? 1 : 0;
@@ -988,14 +987,12 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     } else {
         {
             ProfScope ps(a, PROF_GEMM_FWD);
-            if (a->slab8) hipLaunchKernelGGL(k_fwd_slab8, dim3(3 * nslab), dim3(S8_THREADS), 0, s, P.f);
-            else hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, P.f);
+            hipLaunchKernelGGL(k_fwd_slab, dim3(nslab, 3), dim3(SL_THREADS), 0, s, P.f);
             HP_CHECK_HIP(hipGetLastError());
         }
         {
             ProfScope ps(a, PROF_GEMM_BWD);
-            if (a->slab8) hipLaunchKernelGGL(k_bwd_slab8, dim3(2 * nslab + (ride ? 1 : 0)), dim3(S8_THREADS), 0, s, P.b);
-            else hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, P.b);
+            hipLaunchKernelGGL(k_bwd_slab, dim3(2 * nslab + (ride ? 1 : 0)), dim3(SL_THREADS), 0, s, P.b);
             HP_CHECK_HIP(hipGetLastError());
         }
     }
@@ -1098,7 +1095,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const bool ride = a->slab && with_adam;
     // merged slab8 kernel: plans are drawn TWO updates ahead so that spare workgroups of update u can gather the inputs
     // of update u+1 from a plan that an earlier launch finished (the order of draws in the stream is unchanged)
-    const bool ahead = ride && a->slab8 && a->merged_fb && a->gather_ahead;
+    const bool ahead = ride && a->slab8 && a->gather_ahead;
     const int lead = ahead ? 2 : 1;
     {
         ProfScope ps(a, PROF_PLAN);
@@ -1241,8 +1238,6 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         const char *e = getenv("RLARM_ENGINE");
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
-        const char *fb = getenv("RLARM_FB");
-        a->merged_fb = !(fb && strcmp(fb, "split") == 0);
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');
         const char *ah = getenv("RLARM_AHEAD");

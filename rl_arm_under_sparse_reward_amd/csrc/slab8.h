@@ -1,26 +1,29 @@
-// slab8.h -- row-slab engine, 8 batch rows per workgroup on v_mfma_f32_4x4x1_16b_f32 (included by agent.hip).
+// slab8.h -- row-slab engine on v_mfma_f32_4x4x1_16b_f32, S8_ROWS (= 4) batch rows per workgroup (included by agent.hip;
+// the name dates from its 8-row first version).
 //
-// Why a second slab kernel family: with 16-row slabs on the 16x16x4 MFMA (slab.h) a 256x256 layer costs a
-// workgroup 1024 MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The
-// 4x4x1 instruction (16 independent 4x4 outer products per issue, measured 8.7 cycles = 92 % of the 16x16x4
-// FLOP rate, tools/ubench/mfma4x4.hip) lets a slab be 8 rows: lane l of a wavefront owns output column
-// 64*cg + l, accumulator register r owns row r of a 4-row group, the A operand is the 4 activations of that
-// row group at one reduction index (the same for all 16 blocks: an LDS broadcast read), the B operand is ONE
-// weight per lane.  Half the MFMA time per layer, twice the workgroups (96 at batch 256), same weight stream.
+// Why a second slab engine: with 16-row slabs on the 16x16x4 MFMA (slab.h) a 256x256 layer costs a workgroup 1024
+// MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The 4x4x1 instruction (16
+// independent 4x4 outer products per issue, measured 8.7 cycles = 92 % of the 16x16x4 FLOP rate,
+// tools/ubench/mfma4x4.hip) lets a slab be as thin as 4 rows: lane l of a wavefront owns output column 64*cg + l,
+// accumulator register r owns row r, the A operand is the 4 activations of the slab at one reduction index (the same
+// for all 16 blocks: block broadcast), the B operand is ONE weight per lane.  The per-workgroup time of a layer is
+// set by streaming its 256 KiB of weights through the CU (2.0 us), not by the rows, so thinner slabs cost nothing
+// per workgroup, shrink the matrix work that competes with the stream (8 rows: 1.9 us of MFMA issue per layer and
+// 2.6 us for both together; 4 rows: 0.95 us and 2.0 us, tools/ubench/stream_bw3.hip modes 4 / 9) and double the
+// number of busy CUs (128 at batch 256).
 //   wave w of 8:  column group cg = w & 3 (64 output columns),  reduction half kh = w >> 2
-//   per super-step (4 reduction indices): B = float4 per lane (1 KiB block, LDS-DMA ring as in slab.h),
-//   A = two ds_read_b128 (row group 0 / 1), 8 MFMAs (2 row groups x 4 indices, alternating accumulators)
-//   the two reduction halves meet in LDS (8 KiB), the kh == 0 waves run the epilogue.
+//   per block (4 reduction indices): B = float4 per lane (1 KiB, LDS-DMA ring), 4 MFMAs into one accumulator
+//   the two reduction halves meet in LDS (4 KiB), the kh == 0 waves run the epilogue.
 // Fragment-ordered copies for this engine (same arena offsets as the canonical layout):
 //   forward  Wf8[((n >> 6) * K/4 + (k >> 2)) * 256 + (n & 63) * 4 + (k & 3)] = W[n][k]     (layers 1-3)
 //   dX       Wd8[((k >> 6) * N/4 + (n >> 2)) * 256 + (k & 63) * 4 + (n & 3)] = W[n][k]     (layers 2-4)
-// The 4- and 1-wide heads and the 4 action columns of the critic's input gradient are 8 x 4 dot products of
+// The 4- and 1-wide heads and the 4 action columns of the critic's input gradient are S8_ROWS x 4 dot products of
 // length 256: one wavefront per row, float4 per lane, shuffle tree -- no matrix pipe, canonical weights.
 #pragma once
 
 #define S8_THREADS 512
 #define S8_WAVES 8
-#define S8_ROWS 8
+#define S8_ROWS 4
 #define S8_LD 260
 #define S8_LDX 52
 #define S8_RING 12
@@ -79,26 +82,19 @@ __device__ __forceinline__ const float4 *s8_wblock(const float *wlayer, int cg, 
 // two ds_read_b128 per super-step -- the LDS pipe, shared with the weight DMA, was the limiter.
 // TB = (block index within the wave's half) % 4 selects which quarter of register j the 4 indices of a block hit.
 template <int TB>
-__device__ __forceinline__ void s8_mma8(f32x4 &c0, f32x4 &c1, const float a0, const float a1, const float4 b) {
+__device__ __forceinline__ void s8_mma4(f32x4 &c0, const float a0, const float4 b) {
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.x, c0, 4, 4 * TB + 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.x, c1, 4, 4 * TB + 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.y, c0, 4, 4 * TB + 1, 0);
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.y, c1, 4, 4 * TB + 1, 0);
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.z, c0, 4, 4 * TB + 2, 0);
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.z, c1, 4, 4 * TB + 2, 0);
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.w, c0, 4, 4 * TB + 3, 0);
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b.w, c1, 4, 4 * TB + 3, 0);
 }
 
 // load this wave's A operand for NJ groups of 16 reduction indices starting at index k0
 template <int NJ>
-__device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, float (&a0)[8], float (&a1)[8]) {
+__device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, float (&a0)[8]) {
     const int i = threadIdx.x & 3, blk = (threadIdx.x & 63) >> 2;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        a0[j] = lin[i * ld_in + k0 + 16 * j + blk];
-        a1[j] = lin[(4 + i) * ld_in + k0 + 16 * j + blk];
-    }
+    for (int j = 0; j < NJ; ++j) a0[j] = lin[i * ld_in + k0 + 16 * j + blk];
 }
 
 // The ring is CONTINUOUS across the 256x256 layers of a chain: block t of the current layer lives in slot
@@ -129,9 +125,8 @@ __device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, cons
 // block T+1 is issued BEFORE the 8 MFMAs of block T, so its latency hides under this wave's own matrix work instead
 // of being exposed once per block (with two waves per SIMD the other wave covered only part of it).
 template <int T, bool HAS_NEXT>
-__device__ __forceinline__ void s8_ring_step(f32x4 &c0, f32x4 &c1, RingSlot *ring, int rbase, const float *wlayer,
-                                             const float *nxt, int cg, int b0, const float (&a0)[8],
-                                             const float (&a1)[8], const float4 bcur) {
+__device__ __forceinline__ void s8_ring_step(f32x4 &c0, RingSlot *ring, int rbase, const float *wlayer,
+                                             const float *nxt, int cg, int b0, const float (&a0)[8], const float4 bcur) {
     float4 bnext = bcur;
     if constexpr (T + 1 < 32) {
         // DMA blocks possibly outstanding here: T+1 .. T+R-1 (fewer at the tail of a chain's last layer)
@@ -146,44 +141,36 @@ __device__ __forceinline__ void s8_ring_step(f32x4 &c0, f32x4 &c1, RingSlot *rin
         if constexpr (T + S8_RING < 32) s8_ring_issue(ring, rbase, wlayer, cg, b0, T + S8_RING);
         else s8_ring_issue(ring, rbase + 32, nxt, cg, b0, T + S8_RING - 32);
     }
-    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], bcur);
-    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bnext);
+    s8_mma4<T % 4>(c0, a0[T / 4], bcur);
+    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bnext);
 }
 
-// combine the two reduction halves and run the epilogue.  c0/c1: this wave's partial [row group][row][col = lane]
+// combine the two reduction halves and run the epilogue.  c0: this wave's partial [row][col = lane]
 // mask_out (SE_BIAS_RELU, may be null): LDS byte per column, bit r = (output row r > 0) -- the ReLU mask the backward
 // stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
 // instead of the 8 gate values in e[].
-__device__ __forceinline__ void s8_finish(f32x4 c0, f32x4 c1, int epi, const float *e, float *pbuf, float *lout,
-                                          int ld_out, const unsigned char *mask_in = nullptr,
-                                          unsigned char *mask_out = nullptr) {
+__device__ __forceinline__ void s8_finish(f32x4 c0, int epi, const float *e, float *pbuf, float *lout, int ld_out,
+                                          const unsigned char *mask_in = nullptr, unsigned char *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pbuf[r * 256 + col] = c0[r];
-            pbuf[(4 + r) * 256 + col] = c1[r];
-        }
+        for (int r = 0; r < 4; ++r) pbuf[r * 256 + col] = c0[r];
     }
     s8_sync();
     if (kh == 0) {
         unsigned bits = mask_in ? (unsigned)mask_in[col] : 0u, outbits = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v0 = c0[r] + pbuf[r * 256 + col], v1 = c1[r] + pbuf[(4 + r) * 256 + col];
+            const float v0 = c0[r] + pbuf[r * 256 + col];
             if (epi == SE_BIAS_RELU) {
-                const float o0 = fmaxf(v0 + e[0], 0.f), o1 = fmaxf(v1 + e[0], 0.f);
+                const float o0 = fmaxf(v0 + e[0], 0.f);
                 lout[r * ld_out + col] = o0;
-                lout[(4 + r) * ld_out + col] = o1;
                 outbits |= (o0 > 0.f ? 1u : 0u) << r;
-                outbits |= (o1 > 0.f ? 1u : 0u) << (4 + r);
             } else if (mask_in) {
                 lout[r * ld_out + col] = ((bits >> r) & 1u) ? v0 : 0.f;
-                lout[(4 + r) * ld_out + col] = ((bits >> (4 + r)) & 1u) ? v1 : 0.f;
             } else {
                 lout[r * ld_out + col] = (e[r] > 0.f) ? v0 : 0.f;
-                lout[(4 + r) * ld_out + col] = (e[4 + r] > 0.f) ? v1 : 0.f;
             }
         }
         if (mask_out) mask_out[col] = (unsigned char)outbits;
@@ -198,7 +185,7 @@ __device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float 
         e[0] = aux[col];
     } else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) e[r] = aux[(size_t)r * ldaux + col];
+        for (int r = 0; r < S8_ROWS; ++r) e[r] = aux[(size_t)r * ldaux + col];
     }
 }
 
@@ -213,23 +200,22 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-    float a0[8], a1[8];
-    s8_aload<8>(lin, ld_in, 4 * b0, a0, a1);
+    f32x4 c0 = {0, 0, 0, 0};
+    float a0[8];
+    s8_aload<8>(lin, ld_in, 4 * b0, a0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S8_RING - 1) : "memory");   // block 0 has landed
     const float4 bfirst = ring[rbase % S8_RING][threadIdx.x & 63];
-    if (nxt) s8_ring_step<0, true>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bfirst);
-    else s8_ring_step<0, false>(c0, c1, ring, rbase, wlayer, nxt, cg, b0, a0, a1, bfirst);
+    if (nxt) s8_ring_step<0, true>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bfirst);
+    else s8_ring_step<0, false>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bfirst);
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
-    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c0, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
 template <int T, int HALF>
-__device__ __forceinline__ void s8_small_steps(f32x4 &c0, f32x4 &c1, const float4 (&b)[6], const float (&a0)[8],
-                                               const float (&a1)[8]) {
-    s8_mma8<T % 4>(c0, c1, a0[T / 4], a1[T / 4], b[T]);
-    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, c1, b, a0, a1);
+__device__ __forceinline__ void s8_small_steps(f32x4 &c0, const float4 (&b)[6], const float (&a0)[8]) {
+    s8_mma4<T % 4>(c0, a0[T / 4], b[T]);
+    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, b, a0);
 }
 
 // All weight blocks of a small layer (reduction length Kred = 16 / 32 / 48 -> 2 / 4 / 6 blocks per reduction half) in
@@ -253,23 +239,24 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
-    f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-    float a0[8], a1[8];
-    s8_aload<2>(lin, ld_in, 4 * b0, a0, a1);   // at most 24 indices per half; lanes past the row end read unused padding
+    f32x4 c0 = {0, 0, 0, 0};
+    float a0[8];
+    s8_aload<2>(lin, ld_in, 4 * b0, a0);   // at most 24 indices per half; lanes past the row end read unused padding
     switch (half) {
-        case 2: s8_small_steps<0, 2>(c0, c1, b, a0, a1); break;
-        case 4: s8_small_steps<0, 4>(c0, c1, b, a0, a1); break;
-        case 6: s8_small_steps<0, 6>(c0, c1, b, a0, a1); break;
+        case 2: s8_small_steps<0, 2>(c0, b, a0); break;
+        case 4: s8_small_steps<0, 4>(c0, b, a0); break;
+        case 6: s8_small_steps<0, 6>(c0, b, a0); break;
         default: break;   // other input widths are rejected on the host
     }
-    s8_finish(c0, c1, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c0, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
-// 8 x nout dot products of length 256 (nout <= 4): wave r owns row r, lane p the reduction indices 4p..4p+3;
+// S8_ROWS x nout dot products of length 256 (nout <= 4): wave r < S8_ROWS owns row r (the other waves compute on
+// row r & (S8_ROWS - 1) and their result is ignored), lane p the reduction indices 4p..4p+3;
 // wv[j] = this lane's float4 of weights for output j (loaded by the caller well ahead of time).  On return lane j
 // (j < nout) holds output j of the wave's row (other lanes: unspecified).
 __device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int nout, const float4 (&wv)[4]) {
-    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), p = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & (S8_ROWS - 1), p = threadIdx.x & 63;
     const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
     float mine = 0.f;
 #pragma unroll
@@ -305,7 +292,7 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
 // Unconditional (rows past the batch re-read the last record, plan_any is never null): a load under a branch is
 // merged with its default through a register copy, which makes the compiler wait for it on the spot.
 __device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0) {
-    const int m = (int)row0 + (int)(threadIdx.x >> 6);
+    const int m = (int)row0 + (int)((threadIdx.x >> 6) & (S8_ROWS - 1));
     return G.plan_any[m < G.B ? m : G.B - 1];
 }
 
@@ -313,6 +300,7 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const 
                                           int act_off, int act_dim, float max_action, float *Xout,
                                           float *rew_lds = nullptr) {
     const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (r >= S8_ROWS) return;   // one wavefront per row; the upper waves have none
     const size_t m = row0 + r;
     const bool live = (int)m < G.B;
     const long long e = rec.e;
@@ -378,294 +366,6 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
     S8_TSTAMP(tl, tbase + 3);
     if (g3) s8_store(bufA, S8_LD, H, g3 + row0 * H, H);
 }
-
-__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fwd_slab8(const FwdSlabArgs A) {
-    __shared__ __attribute__((aligned(16))) float xin[S8_ROWS * S8_LDX];
-    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
-    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
-    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
-    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
-    const int nslab = A.Mp / S8_ROWS;
-    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
-    const size_t row0 = (size_t)slab * S8_ROWS;
-    const int tid = threadIdx.x, H = A.H;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    RingSlot *ring = wring[wave];
-    int rbase = 0;
-    const NetLayout &la = A.la, &lc = A.lc;
-    const int ca = la.total;
-#ifdef SLAB_TIMELINE
-    if (slab == 0 && tid == 0) A.tl[chain * 32] = wall_clock64();
-#endif
-    if (chain == 1) {   // critic(x, a)
-        const PlanRec rec = s8_plan_rec(A.gs, row0);   // per branch: a value live across the branch gets a register
-        float4 wb[6], wq[4];                           // copy, and the copy waits for the load
-        s8_small_prefetch(A.online.wf + ca + lc.w1, lc.K1, wb);
-        wq[0] = *reinterpret_cast<const float4 *>(A.online.canon + ca + lc.w4 + 4 * lane);
-        const float bq = A.online.canon[ca + lc.b4];
-        __builtin_amdgcn_sched_barrier(0);
-        if (A.gs.plan) s8_gather(xin, A.gs, rec, 1, row0, A.ldx, A.act_off, A.act_dim, A.max_action, const_cast<float *>(A.XA));
-        else s8_load(xin, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
-        s8_ring_prologue(ring, rbase, A.online.wf + ca + lc.w2);
-        s8_sync();
-        s8_trunk(xin, lc, wb, A.online.wf + ca, A.online.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0,
-                 ring, rbase, nullptr, slab == 0 ? A.tl + chain * 32 : nullptr, 1);
-        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
-        if (lane == 0) A.QA[(row0 + wave) * 16] = q + bq;
-        return;
-    }
-    const bool tgt = (chain == 0);
-    const SlabNetPtrs &net = tgt ? A.target : A.online;
-    float *X = tgt ? const_cast<float *>(A.XT) : A.XP;
-    const PlanRec rec = s8_plan_rec(A.gs, row0);
-    // everything that does not depend on the activations is fetched now: first-layer weight blocks of both trunks,
-    // the head rows and biases (cold loads whose latency would otherwise sit on the chain once per use)
-    float4 wba[6], wbc[6], wh[4], wq[4];
-    s8_small_prefetch(net.wf + la.w1, la.K1, wba);
-    s8_small_prefetch(net.wf + ca + lc.w1, lc.K1, wbc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)   // branch free: rows past act_dim re-read the last one
-        wh[j] = *reinterpret_cast<const float4 *>(net.canon + la.w4 + (j < A.act_dim ? j : A.act_dim - 1) * H + 4 * lane);
-    wq[0] = *reinterpret_cast<const float4 *>(net.canon + ca + lc.w4 + 4 * lane);
-    const float bh = net.canon[la.b4 + (lane < A.act_dim ? lane : 0)];
-    const float bq = net.canon[ca + lc.b4];
-    __builtin_amdgcn_sched_barrier(0);
-    if (A.gs.plan) s8_gather(xin, A.gs, rec, tgt ? 0 : 2, row0, A.ldx, A.act_off, A.act_dim, A.max_action, tgt ? nullptr : X);
-    else s8_load(xin, S8_LDX, A.ldx, X + row0 * A.ldx, A.ldx);
-    s8_ring_prologue(ring, rbase, net.wf + la.w2);
-    s8_sync();
-    s8_trunk(xin, la, wba, net.wf, net.canon, H, bufA, bufB, pbuf, tgt ? nullptr : A.APh1, tgt ? nullptr : A.APh2,
-             tgt ? nullptr : A.APh3, row0, ring, rbase, net.wf + ca + lc.w2, slab == 0 ? A.tl + chain * 32 : nullptr, 1);
-    S8_STAMP(5);
-    {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
-        const float z = s8_rowdots(bufA, S8_LD, A.act_dim, wh);
-        if (lane < A.act_dim) {
-            const float th = tanhf(z + bh);
-            const float u = (A.max_action * th) / A.max_action;
-            xin[wave * S8_LDX + A.act_off + lane] = u;
-            X[(row0 + wave) * A.ldx + A.act_off + lane] = u;
-            if (!tgt) A.TP[(row0 + wave) * 16 + lane] = th;
-        }
-    }
-    s8_sync();
-    S8_STAMP(7);
-    s8_trunk(xin, lc, wbc, net.wf + ca, net.canon + ca, H, bufA, bufB, pbuf, tgt ? nullptr : A.CPh1, tgt ? nullptr : A.CPh2,
-             tgt ? nullptr : A.CPh3, row0, ring, rbase, nullptr, slab == 0 ? A.tl + chain * 32 : nullptr, 8);
-    {
-        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
-        float *Q = tgt ? A.QT : A.QP;
-        if (lane == 0) Q[(row0 + wave) * 16] = q + bq;
-    }
-    S8_STAMP(13);
-}
-
-// dY of the top hidden layer from a per-row head gradient: d3[m][n] = dq[m] * w4[n] * (h3[m][n] > 0).
-// H == 256 (checked on the host): a thread owns column tid & 255 of rows (tid >> 8) + 2 i, i < 4.  The operands are
-// fetched at kernel entry (s8_head_bwd_fetch) so their latency overlaps the loss prologue.
-struct S8HeadOps { float w; float h[4]; };
-__device__ __forceinline__ void s8_head_bwd_fetch(S8HeadOps &o, const float *__restrict__ w4row, const float *__restrict__ h3) {
-    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
-    o.w = w4row[c];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o.h[i] = h3[(size_t)(r0 + 2 * i) * 256 + c];
-}
-__device__ __forceinline__ void s8_head_bwd(const float *dq_rows, const S8HeadOps &o, float *lout) {
-    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lout[(r0 + 2 * i) * S8_LD + c] = (o.h[i] > 0.f) ? dq_rows[r0 + 2 * i] * o.w : 0.f;
-}
-
-__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bwd_slab8(const BwdSlabArgs A) {
-    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
-    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
-    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
-    __shared__ float dq[S8_ROWS];
-    __shared__ __attribute__((aligned(16))) float dz[S8_ROWS * 20];
-    __shared__ __attribute__((aligned(16))) float w1t[4 * 256];
-    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
-    const int nslab = A.nslab;
-    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
-    const size_t row0 = (size_t)slab * S8_ROWS;
-    const int tid = threadIdx.x, H = A.H;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const NetLayout &la = A.la, &lc = A.lc;
-    const int ca = la.total;
-    const float invB = 1.0f / (float)A.B;
-    RingSlot *ring = wring[wave];
-    int rbase = 0;
-    if (chain == 2) {   // plan workgroup: draws the next update's indices (see BwdSlabArgs)
-        if (tid >= MT_THREADS) return;
-        mt_her_plan(A.rng, A.meta->current_size, A.T, A.plan_batch, 1, A.future_p, A.next_plan,
-                    reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
-        return;
-    }
-    // NOTE on stores: gfx9 counts stores on vmcnt too, and with a store pending next to loads the compiler can no
-    // longer rely on in-order return -- every wait it inserts becomes vmcnt(0), which drains the weight DMA queue.
-    // All small global stores of this kernel (Adam step scalars, loss partials, dQ) are therefore parked in registers
-    // and written at the very end of the workgroup.
-    S8_STAMP(0);
-    // per-row loss operands first (the loss is the head of the chain and vmcnt retires in order), then the prefetches
-    // unconditional and merged by ADDRESS, not by value (threads 8.. repeat rows 0..7; padded rows exist): a loaded
-    // value that meets a default or another branch's value in a phi gets a register copy that waits for the load
-    float l0, lu[4];
-    {
-        const size_t m = row0 + (tid & (S8_ROWS - 1));
-        const bool c0 = (chain == 0);
-        const float *xp = A.XP + m * A.ldx + A.act_off;
-        const int ad1 = A.act_dim - 1;
-        l0 = *(c0 ? A.R + m : A.QP + m * 16);
-        lu[0] = *(c0 ? A.QT + m * 16 : xp);
-        lu[1] = *(c0 ? A.QA + m * 16 : xp + (1 < ad1 ? 1 : ad1));
-        lu[2] = *(c0 ? A.QA + m * 16 : xp + (2 < ad1 ? 2 : ad1));
-        lu[3] = *(c0 ? A.QA + m * 16 : xp + (3 < ad1 ? 3 : ad1));
-    }
-    const float l1 = lu[0], l2 = lu[1];   // critic chain: Q_target, Q(x, a)
-    S8HeadOps hops;
-    s8_head_bwd_fetch(hops, A.online.canon + ca + lc.w4, (chain == 0 ? A.CAh3 : A.CPh3) + row0 * H);
-    if (chain == 0) {
-        // ---- critic loss (ddpg_agent.py:255-263)
-        s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
-        __builtin_amdgcn_sched_barrier(0);
-        float keep_g = 0.f, keep_a = 0.f;
-        if (tid < S8_ROWS) {
-            const size_t m = row0 + tid;
-            float g = 0.f, sq = 0.f;
-            if ((int)m < A.B) {
-                float y = l0 + A.gamma * l1;
-                y = fminf(fmaxf(y, -A.clip_ret), 0.f);
-                const float d = y - l2;
-                sq = d * d;
-                g = -2.f * d * invB;
-            }
-            dq[tid] = g;
-            for (int o = 4; o > 0; o >>= 1) sq += __shfl_down(sq, o, 8);
-            keep_g = g;
-            keep_a = sq;
-        }
-        s8_sync();
-        S8_STAMP(1);
-        s8_head_bwd(dq, hops, bufA);
-        s8_sync();
-        S8_STAMP(2);
-        s8_store(bufA, S8_LD, H, A.dA3 + row0 * H, H);
-        s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CAh2 + row0 * H, H,
-                     pbuf, bufB, S8_LD);
-        s8_sync();
-        S8_STAMP(3);
-        s8_store(bufB, S8_LD, H, A.dA2 + row0 * H, H);
-        s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, nullptr, SE_MASK, A.CAh1 + row0 * H, H, pbuf, bufA,
-                     S8_LD);
-        s8_sync();
-        S8_STAMP(4);
-        s8_store(bufA, S8_LD, H, A.dA1 + row0 * H, H);
-        if (tid < S8_ROWS) {
-            A.dQA[(row0 + tid) * 16] = keep_g;
-            if (tid == 0) A.part[slab] = keep_a;
-        }
-        if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
-            A.st->step += 1;
-            adam_prepare(A.st, A.adam);
-        }
-        S8_STAMP(5);
-        return;
-    }
-    // ---- actor loss (ddpg_agent.py:265-267)
-    // operands of the action-gradient stage and of the actor's head layer, fetched now (cold, strided: the 16 first-
-    // layer weights W1c[4p + c][act_off + j] this lane needs, its row's action / tanh values, the 2 head-layer blocks)
-    const int K1c = lc.K1, ad = A.act_dim;
-    float4 wb4[6];
-    float w1n[4] = {0.f, 0.f, 0.f, 0.f};   // thread n < 256: W1c[n][act_off + j] (one line per n; staged in LDS as w1t[j][n])
-    {   // branch free (threads 256.. duplicate 0..255, columns past act_dim re-read the last one)
-        const float *w1 = A.online.canon + ca + lc.w1 + (size_t)(tid & 255) * K1c + A.act_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1n[j] = w1[j < ad ? j : ad - 1];
-    }
-    s8_small_prefetch(A.online.wd + la.w4, 16, wb4);
-    float u_mine = 0.f, th_mine = 0.f;
-    {
-        const size_t m = row0 + wave;   // padded rows exist (Mp rows allocated) and hold zeros
-        const int jl = lane < ad ? lane : 0;
-        u_mine = A.XP[m * A.ldx + A.act_off + jl];
-        th_mine = A.TP[m * 16 + jl];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    s8_ring_prologue(ring, rbase, A.online.wd + ca + lc.w3);
-    __builtin_amdgcn_sched_barrier(0);
-    float keep_q = 0.f, keep_u = 0.f;
-    if (tid < S8_ROWS) {
-        const size_t m = row0 + tid;
-        const bool live = (int)m < A.B;
-        dq[tid] = live ? -invB : 0.f;
-        float sq = live ? l0 : 0.f, su = 0.f;
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < A.act_dim) su += lu[j] * lu[j];
-        }
-        for (int o = 4; o > 0; o >>= 1) {
-            sq += __shfl_down(sq, o, 8);
-            su += __shfl_down(su, o, 8);
-        }
-        keep_q = sq;
-        keep_u = su;
-    }
-    s8_sync();
-    S8_STAMP(1);
-    s8_head_bwd(dq, hops, bufA);
-    s8_sync();
-    S8_STAMP(2);
-    s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + ca + lc.w3, A.online.wd + ca + lc.w2, SE_MASK, A.CPh2 + row0 * H, H, pbuf,
-                 bufB, S8_LD);
-    if (tid < 256) {   // parked until now so that the strided loads had two stages to land
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
-    }
-    s8_sync();
-    S8_STAMP(3);
-    s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + ca + lc.w2, A.online.wd + la.w3, SE_MASK, A.CPh1 + row0 * H, H, pbuf, bufA,
-                 S8_LD);
-    s8_sync();
-    S8_STAMP(4);
-    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh; lane j owns action j
-        float4 w1g[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
-        const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
-        if (lane < 16) {
-            const size_t m = row0 + wave;
-            float v = 0.f;
-            if (lane < ad && (int)m < A.B) {
-                const float gu = A.action_l2 * (2.f * u_mine / (float)(A.B * ad)) + sj;
-                const float gt = (gu / A.max_action) * A.max_action;
-                v = gt * (1.f - th_mine * th_mine);
-            }
-            dz[wave * 20 + lane] = v;
-            A.dZ[m * 16 + lane] = v;
-        }
-    }
-    s8_sync();
-    S8_STAMP(5);
-    // actor layer 4 backward: reduction over the 16 padded head outputs
-    s8_small_layer(dz, 20, 16, wb4, SE_MASK, A.APh3 + row0 * H, H, pbuf, bufB, S8_LD);
-    s8_sync();
-    S8_STAMP(6);
-    s8_store(bufB, S8_LD, H, A.dK3 + row0 * H, H);
-    s8_big_layer(bufB, S8_LD, ring, rbase, A.online.wd + la.w3, A.online.wd + la.w2, SE_MASK, A.APh2 + row0 * H, H, pbuf, bufA,
-                 S8_LD);
-    s8_sync();
-    S8_STAMP(7);
-    s8_store(bufA, S8_LD, H, A.dK2 + row0 * H, H);
-    s8_big_layer(bufA, S8_LD, ring, rbase, A.online.wd + la.w2, nullptr, SE_MASK, A.APh1 + row0 * H, H, pbuf, bufB, S8_LD);
-    s8_sync();
-    S8_STAMP(8);
-    s8_store(bufB, S8_LD, H, A.dK1 + row0 * H, H);
-    if (tid == 0) {
-        A.part[nslab + slab] = keep_q;
-        A.part[2 * nslab + slab] = keep_u;
-    }
-    S8_STAMP(9);
-}
-
 
 // ===================================================================================================================
 // Merged forward + backward: one launch per update instead of two.
@@ -760,9 +460,9 @@ __device__ __forceinline__ void s8_gather_ahead(const GatherSrc &G, float *XT, f
 }
 
 __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
-    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;   // H == 256: a thread owns column c of rows r0, r0 + 2, ...
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < S8_ROWS / 2; ++i) {
         const int r = r0 + 2 * i;
         const float h = buf[r * S8_LD + c];
         buf[r * S8_LD + c] = (h > 0.f) ? dq_rows[r] * w4c : 0.f;
@@ -841,7 +541,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                  tn.wf + ca + lc.w2, tl, 1);
         {   // target actor head -> action block of the target critic's input (models.py:24)
             const float z = s8_rowdots(bufA, S8_LD, ad, whT);
-            if (lane < ad) {
+            if (lane < ad && wave < S8_ROWS) {
                 const float th = tanhf(z + bhT);
                 const float u = (A.max_action * th) / A.max_action;
                 xin[wave * S8_LDX + A.act_off + lane] = u;
@@ -854,7 +554,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                  on.wf + ca + lc.w2, tl, 8);
         {
             const float q = s8_rowdots(bufA, S8_LD, 1, wqT);
-            if (lane == 0) {
+            if (lane == 0 && wave < S8_ROWS) {
                 rows[0][wave] = q + bqT;
                 A.QT[(row0 + wave) * 16] = q + bqT;
             }
@@ -865,7 +565,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                  on.wd + ca + lc.w3, tl, 14, msk[0], msk[1], nullptr);
         {
             const float q = s8_rowdots(bufA, S8_LD, 1, wqA);
-            if (lane == 0) {
+            if (lane == 0 && wave < S8_ROWS) {
                 rows[1][wave] = q + bqA;
                 A.QA[(row0 + wave) * 16] = q + bqA;
             }
@@ -885,7 +585,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 g = -2.f * d * invB;
             }
             dq[tid] = g;
-            for (int o = 4; o > 0; o >>= 1) sq += __shfl_down(sq, o, 8);
+            for (int o = S8_ROWS / 2; o > 0; o >>= 1) sq += __shfl_down(sq, o, S8_ROWS);
             keep_g = g;
             keep_a = sq;
         }
@@ -943,7 +643,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float u_mine = 0.f, th_mine = 0.f;
     {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
         const float z = s8_rowdots(bufA, S8_LD, ad, wh);
-        if (lane < ad) {
+        if (lane < ad && wave < S8_ROWS) {
             th_mine = tanhf(z + bh);
             u_mine = (A.max_action * th_mine) / A.max_action;
             xin[wave * S8_LDX + A.act_off + lane] = u_mine;
@@ -957,7 +657,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
              on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr);
     {
         const float q = s8_rowdots(bufA, S8_LD, 1, wq);
-        if (lane == 0) {
+        if (lane == 0 && wave < S8_ROWS) {
             rows[1][wave] = q + bq;
             A.QP[(row0 + wave) * 16] = q + bq;
         }
@@ -983,9 +683,9 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     su += u * u;
                 }
         }
-        for (int o = 4; o > 0; o >>= 1) {
-            sq += __shfl_down(sq, o, 8);
-            su += __shfl_down(su, o, 8);
+        for (int o = S8_ROWS / 2; o > 0; o >>= 1) {
+            sq += __shfl_down(sq, o, S8_ROWS);
+            su += __shfl_down(su, o, S8_ROWS);
         }
         keep_q = sq;
         keep_u = su;
@@ -1005,7 +705,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
         const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
-        if (lane < 16) {
+        if (lane < 16 && wave < S8_ROWS) {
             const size_t m = row0 + wave;
             float v = 0.f;
             if (lane < ad && (int)m < Bk.B) {

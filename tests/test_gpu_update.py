@@ -280,10 +280,10 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
 
-@pytest.mark.parametrize("switch", ["RLARM_AHEAD=0", "RLARM_FB=split", "RLARM_FUSE_ADAM=0"])
+@pytest.mark.parametrize("switch", ["RLARM_AHEAD=0", "RLARM_FUSE_ADAM=0"])
 def test_engine_variants_are_bit_identical(switch, monkeypatch):
-    """The default slab8 path (merged forward+backward kernel, next minibatch gathered one launch ahead, Adam in the
-    weight-gradient epilogue) against the same engine with one of those turned off: same arithmetic, same summation
+    """The default slab8 path (next minibatch gathered one launch ahead, Adam in the weight-gradient epilogue) against
+    the same engine with one of those turned off: same arithmetic, same summation
     order, same RNG stream -> identical bits after 3 cycles."""
     torch.manual_seed(0)
     ref_agent, _ = make_agent(batch=256, n_eps=32, seed=21)

@@ -124,7 +124,17 @@ __global__ __launch_bounds__(512) void k_mix(const float4 *__restrict__ src, int
                 const int nb = b + i + R;
                 dma16(w + (size_t)(nb < nper ? nb : nper - 1) * 64, &ring[wave][i][0]);
                 if (MODE == 5) { mma8(c0, c1, a0, a1, bc); c0[0] += bcur.x; }
-                else mma8(c0, c1, a0, a1, bcur);
+                else if (MODE == 8) {   // half the matrix work per block (4-row slabs): 2 accumulators over even/odd indices
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.x, c0, 4, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.y, c1, 4, 1, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.z, c0, 4, 2, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.w, c1, 4, 3, 0);
+                } else if (MODE == 9) {   // half the matrix work, ONE accumulator (4 dependent MFMAs per block)
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.x, c0, 4, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.y, c0, 4, 1, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.z, c0, 4, 2, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bcur.w, c0, 4, 3, 0);
+                } else mma8(c0, c1, a0, a1, bcur);
                 bcur = bnext;
             }
         }
@@ -160,13 +170,15 @@ int main(int argc, char **argv) {
         const double us = c / 100.0;
         printf("nwg=%d mode=%d: %.2f us per 256 KiB -> %.1f GB/s per WG\n", nwg, mode, us * 262144.0 / bytes, bytes / us / 1e3);
     }
-    for (int mode = 4; mode < 8; ++mode) {
+    for (int mode = 4; mode < 10; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             switch (mode) {
                 case 4: hipLaunchKernelGGL(k_mix<4>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
                 case 5: hipLaunchKernelGGL(k_mix<5>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
                 case 6: hipLaunchKernelGGL(k_mix<6>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
                 case 7: hipLaunchKernelGGL(k_mix<7>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
+                case 8: hipLaunchKernelGGL(k_mix<8>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
+                case 9: hipLaunchKernelGGL(k_mix<9>, dim3(nwg), dim3(512), 0, 0, src, nper, t, sink); break;
             }
             CK(hipDeviceSynchronize());
         }
