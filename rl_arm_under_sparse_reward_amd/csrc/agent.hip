@@ -90,7 +90,18 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #define LOSS_LOG 4096
 
 #include "slab.h"
+// the 4x4x1 slab engine, compiled for two slab heights (see slab8.h)
+#define S8_NRG 1
+#define S8_NS s8r4
 #include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
+#define S8_NRG 2
+#define S8_NS s8r8
+#include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
+#undef S8_ROWS
 
 // Adam (torch.optim.Adam, _single_tensor_adam, no weight decay / amsgrad) on one arena element, plus the
 // fragment-ordered copies of the slab engines.  Shared by k_adam_frag and the weight-gradient GEMM epilogue
@@ -232,7 +243,8 @@ struct hp_agent {
     float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
-    bool slab8 = true;     // 8-row slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
+    bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
+    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 512, 8 rows beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -915,7 +927,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
-    const int nslab = Mp / (a->slab8 ? S8_ROWS : SL_ROWS);
+    const int nslab = Mp / (a->slab8 ? a->s8_rows : SL_ROWS);
     FbSlabArgs P;
     const int xs = gc ? gc->xset : 0;
     float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
@@ -982,7 +994,10 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             P.ahead.R = xs ? a->R : a->R2;
             P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
         }
-        hipLaunchKernelGGL(k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
+        if (a->s8_rows == 4)
+            hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
+        else
+            hipLaunchKernelGGL(s8r8::k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
     } else {
         {
@@ -1029,7 +1044,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.keep_grads = 1;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
-    F.part = a->part; F.nslab = a->Mp / (a->slab8 ? S8_ROWS : SL_ROWS); F.B = a->B; F.act_dim = a->cfg.act_dim;
+    F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : SL_ROWS); F.B = a->B; F.act_dim = a->cfg.act_dim;
     F.action_l2 = (float)a->cfg.action_l2; F.loss_log = a->loss_log;
     return F;
 }
@@ -1232,12 +1247,19 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
     A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
     A(&a->loss_log, LOSS_LOG * 2);
-    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / S8_ROWS));
+    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / 4));
     {
         // RLARM_ENGINE = slab8 (default) | slab16 | layers: the alternatives stay for A/B runs and debugging
         const char *e = getenv("RLARM_ENGINE");
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
+        // Thin slabs buy latency at small batches (more CUs busy, less matrix work per streamed weight block) and cost
+        // L2 weight traffic per row: measured 48.4 vs 52.7 us/update at batch 256 but 116 vs 80.6 us at batch 1024.
+        a->s8_rows = (a->B <= 512) ? 4 : 8;
+        if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
+            if (strcmp(sr, "4") == 0) a->s8_rows = 4;
+            if (strcmp(sr, "8") == 0) a->s8_rows = 8;
+        }
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');
         const char *ah = getenv("RLARM_AHEAD");

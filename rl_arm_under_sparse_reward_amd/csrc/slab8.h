@@ -19,11 +19,12 @@
 //   dX       Wd8[((k >> 6) * N/4 + (n >> 2)) * 256 + (k & 63) * 4 + (n & 3)] = W[n][k]     (layers 2-4)
 // The 4- and 1-wide heads and the 4 action columns of the critic's input gradient are S8_ROWS x 4 dot products of
 // length 256: one wavefront per row, float4 per lane, shuffle tree -- no matrix pipe, canonical weights.
-#pragma once
+#ifndef RLARM_SLAB8_SHARED
+#define RLARM_SLAB8_SHARED
+
 
 #define S8_THREADS 512
 #define S8_WAVES 8
-#define S8_ROWS 4
 #define S8_LD 260
 #define S8_LDX 52
 #define S8_RING 12
@@ -64,6 +65,28 @@ __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int i
     if (layer >= 2) off_d = base + w0 + frag8_dx_index(n, k, N);
 }
 
+// arguments of k_fb_slab8 (both row counts)
+struct FbSlabArgs {
+    FwdSlabArgs f;
+    BwdSlabArgs b;
+    // Spare workgroups behind the 2 * nslab chain workgroups: n_plan (0/1) draws the index plan of a LATER update
+    // (b.next_plan), n_ahead gather the NEXT update's network inputs from its already drawn plan into the other input
+    // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
+    // (plan record -> replay-buffer rows).  The plan they read was finished by an EARLIER launch: no in-kernel handshake.
+    int n_plan, n_ahead;
+    GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
+    float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
+};
+
+#endif  // RLARM_SLAB8_SHARED
+
+// ---- everything below is compiled once per slab height: S8_NRG row groups of 4 (S8_NRG = 1: 4-row slabs, the
+// small-batch choice; S8_NRG = 2: 8-row slabs, half the weight traffic per row for batches that fill the chip),
+// each time inside its own namespace S8_NS (agent.hip includes this file twice)
+#undef S8_ROWS
+#define S8_ROWS (4 * S8_NRG)
+namespace S8_NS {
+
 __device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (see slab.h)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -82,19 +105,27 @@ __device__ __forceinline__ const float4 *s8_wblock(const float *wlayer, int cg, 
 // two ds_read_b128 per super-step -- the LDS pipe, shared with the weight DMA, was the limiter.
 // TB = (block index within the wave's half) % 4 selects which quarter of register j the 4 indices of a block hit.
 template <int TB>
-__device__ __forceinline__ void s8_mma4(f32x4 &c0, const float a0, const float4 b) {
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.x, c0, 4, 4 * TB + 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.y, c0, 4, 4 * TB + 1, 0);
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.z, c0, 4, 4 * TB + 2, 0);
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b.w, c0, 4, 4 * TB + 3, 0);
+__device__ __forceinline__ void s8_mma(f32x4 (&c)[S8_NRG], const float (&a)[S8_NRG], const float4 b) {
+    const float bk[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < S8_NRG; ++g) {   // row groups alternate: independent accumulators back to back
+            if (k == 0) c[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], bk[0], c[g], 4, 4 * TB + 0, 0);
+            if (k == 1) c[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], bk[1], c[g], 4, 4 * TB + 1, 0);
+            if (k == 2) c[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], bk[2], c[g], 4, 4 * TB + 2, 0);
+            if (k == 3) c[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], bk[3], c[g], 4, 4 * TB + 3, 0);
+        }
 }
 
 // load this wave's A operand for NJ groups of 16 reduction indices starting at index k0
 template <int NJ>
-__device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, float (&a0)[8]) {
+__device__ __forceinline__ void s8_aload(const float *lin, int ld_in, int k0, float (&a)[8][S8_NRG]) {
     const int i = threadIdx.x & 3, blk = (threadIdx.x & 63) >> 2;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) a0[j] = lin[i * ld_in + k0 + 16 * j + blk];
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < S8_NRG; ++g) a[j][g] = lin[(4 * g + i) * ld_in + k0 + 16 * j + blk];
 }
 
 // The ring is CONTINUOUS across the 256x256 layers of a chain: block t of the current layer lives in slot
@@ -125,8 +156,9 @@ __device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, cons
 // block T+1 is issued BEFORE the 8 MFMAs of block T, so its latency hides under this wave's own matrix work instead
 // of being exposed once per block (with two waves per SIMD the other wave covered only part of it).
 template <int T, bool HAS_NEXT>
-__device__ __forceinline__ void s8_ring_step(f32x4 &c0, RingSlot *ring, int rbase, const float *wlayer,
-                                             const float *nxt, int cg, int b0, const float (&a0)[8], const float4 bcur) {
+__device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring, int rbase, const float *wlayer,
+                                             const float *nxt, int cg, int b0, const float (&a)[8][S8_NRG],
+                                             const float4 bcur) {
     float4 bnext = bcur;
     if constexpr (T + 1 < 32) {
         // DMA blocks possibly outstanding here: T+1 .. T+R-1 (fewer at the tail of a chain's last layer)
@@ -141,38 +173,44 @@ __device__ __forceinline__ void s8_ring_step(f32x4 &c0, RingSlot *ring, int rbas
         if constexpr (T + S8_RING < 32) s8_ring_issue(ring, rbase, wlayer, cg, b0, T + S8_RING);
         else s8_ring_issue(ring, rbase + 32, nxt, cg, b0, T + S8_RING - 32);
     }
-    s8_mma4<T % 4>(c0, a0[T / 4], bcur);
-    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bnext);
+    s8_mma<T % 4>(c, a[T / 4], bcur);
+    if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c, ring, rbase, wlayer, nxt, cg, b0, a, bnext);
 }
 
 // combine the two reduction halves and run the epilogue.  c0: this wave's partial [row][col = lane]
 // mask_out (SE_BIAS_RELU, may be null): LDS byte per column, bit r = (output row r > 0) -- the ReLU mask the backward
 // stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
 // instead of the 8 gate values in e[].
-__device__ __forceinline__ void s8_finish(f32x4 c0, int epi, const float *e, float *pbuf, float *lout, int ld_out,
-                                          const unsigned char *mask_in = nullptr, unsigned char *mask_out = nullptr) {
+__device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
+                                          int ld_out, const unsigned char *mask_in = nullptr,
+                                          unsigned char *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pbuf[r * 256 + col] = c0[r];
+        for (int g = 0; g < S8_NRG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pbuf[(4 * g + r) * 256 + col] = c[g][r];
     }
     s8_sync();
     if (kh == 0) {
         unsigned bits = mask_in ? (unsigned)mask_in[col] : 0u, outbits = 0u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v0 = c0[r] + pbuf[r * 256 + col];
-            if (epi == SE_BIAS_RELU) {
-                const float o0 = fmaxf(v0 + e[0], 0.f);
-                lout[r * ld_out + col] = o0;
-                outbits |= (o0 > 0.f ? 1u : 0u) << r;
-            } else if (mask_in) {
-                lout[r * ld_out + col] = ((bits >> r) & 1u) ? v0 : 0.f;
-            } else {
-                lout[r * ld_out + col] = (e[r] > 0.f) ? v0 : 0.f;
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < S8_NRG; ++g) {
+                const int row = 4 * g + r;
+                const float v = c[g][r] + pbuf[row * 256 + col];
+                if (epi == SE_BIAS_RELU) {
+                    const float o = fmaxf(v + e[0], 0.f);
+                    lout[row * ld_out + col] = o;
+                    outbits |= (o > 0.f ? 1u : 0u) << row;
+                } else if (mask_in) {
+                    lout[row * ld_out + col] = ((bits >> row) & 1u) ? v : 0.f;
+                } else {
+                    lout[row * ld_out + col] = (e[row] > 0.f) ? v : 0.f;
+                }
             }
-        }
         if (mask_out) mask_out[col] = (unsigned char)outbits;
     }
 }
@@ -200,22 +238,24 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 c0 = {0, 0, 0, 0};
-    float a0[8];
-    s8_aload<8>(lin, ld_in, 4 * b0, a0);
+    f32x4 c[S8_NRG];
+#pragma unroll
+    for (int g = 0; g < S8_NRG; ++g) c[g] = f32x4{0, 0, 0, 0};
+    float a[8][S8_NRG];
+    s8_aload<8>(lin, ld_in, 4 * b0, a);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S8_RING - 1) : "memory");   // block 0 has landed
     const float4 bfirst = ring[rbase % S8_RING][threadIdx.x & 63];
-    if (nxt) s8_ring_step<0, true>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bfirst);
-    else s8_ring_step<0, false>(c0, ring, rbase, wlayer, nxt, cg, b0, a0, bfirst);
+    if (nxt) s8_ring_step<0, true>(c, ring, rbase, wlayer, nxt, cg, b0, a, bfirst);
+    else s8_ring_step<0, false>(c, ring, rbase, wlayer, nxt, cg, b0, a, bfirst);
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
-    s8_finish(c0, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
 template <int T, int HALF>
-__device__ __forceinline__ void s8_small_steps(f32x4 &c0, const float4 (&b)[6], const float (&a0)[8]) {
-    s8_mma4<T % 4>(c0, a0[T / 4], b[T]);
-    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c0, b, a0);
+__device__ __forceinline__ void s8_small_steps(f32x4 (&c)[S8_NRG], const float4 (&b)[6], const float (&a)[8][S8_NRG]) {
+    s8_mma<T % 4>(c, a[T / 4], b[T]);
+    if constexpr (T + 1 < HALF) s8_small_steps<T + 1, HALF>(c, b, a);
 }
 
 // All weight blocks of a small layer (reduction length Kred = 16 / 32 / 48 -> 2 / 4 / 6 blocks per reduction half) in
@@ -239,16 +279,18 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
-    f32x4 c0 = {0, 0, 0, 0};
-    float a0[8];
-    s8_aload<2>(lin, ld_in, 4 * b0, a0);   // at most 24 indices per half; lanes past the row end read unused padding
+    f32x4 c[S8_NRG];
+#pragma unroll
+    for (int g = 0; g < S8_NRG; ++g) c[g] = f32x4{0, 0, 0, 0};
+    float a[8][S8_NRG];
+    s8_aload<2>(lin, ld_in, 4 * b0, a);   // at most 24 indices per half; lanes past the row end read unused padding
     switch (half) {
-        case 2: s8_small_steps<0, 2>(c0, b, a0); break;
-        case 4: s8_small_steps<0, 4>(c0, b, a0); break;
-        case 6: s8_small_steps<0, 6>(c0, b, a0); break;
+        case 2: s8_small_steps<0, 2>(c, b, a); break;
+        case 4: s8_small_steps<0, 4>(c, b, a); break;
+        case 6: s8_small_steps<0, 6>(c, b, a); break;
         default: break;   // other input widths are rejected on the host
     }
-    s8_finish(c0, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
 // S8_ROWS x nout dot products of length 256 (nout <= 4): wave r < S8_ROWS owns row r (the other waves compute on
@@ -377,17 +419,6 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
 // LDS slab it was computed in, the ReLU masks as one byte per column (s8_finish); the weight ring runs on from the
 // forward fragment copies into the dX copies without draining.  Arithmetic and summation order are those of
 // k_fwd_slab8 + k_bwd_slab8 (same device functions), so the results are bit-identical.
-struct FbSlabArgs {
-    FwdSlabArgs f;
-    BwdSlabArgs b;
-    // Spare workgroups behind the 2 * nslab chain workgroups: n_plan (0/1) draws the index plan of a LATER update
-    // (b.next_plan), n_ahead gather the NEXT update's network inputs from its already drawn plan into the other input
-    // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
-    // (plan record -> replay-buffer rows).  The plan they read was finished by an EARLIER launch: no in-kernel handshake.
-    int n_plan, n_ahead;
-    GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
-    float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
-};
 
 // HER gather of rows [g * per, (g + 1) * per) of a minibatch into global input sets (same arithmetic as s8_gather:
 // her.py:26-38, ddpg_agent.py:228-243, normalizer.py:67-70).  One wavefront per row, 4 rows in flight per wavefront.
@@ -737,3 +768,5 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     S8_TSTAMP(tl, 21);
 }
+
+}  // namespace S8_NS
