@@ -244,7 +244,7 @@ struct hp_agent {
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
-    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 512, 8 rows beyond (RLARM_SLAB_ROWS overrides)
+    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 rows beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -1254,8 +1254,10 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
         a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
         // Thin slabs buy latency at small batches (more CUs busy, less matrix work per streamed weight block) and cost
-        // L2 weight traffic per row: measured 48.4 vs 52.7 us/update at batch 256 but 116 vs 80.6 us at batch 1024.
-        a->s8_rows = (a->B <= 512) ? 4 : 8;
+        // L2 weight traffic per row: measured (4 vs 8 rows, us/update) 48.4 vs 52.4 at batch 256, 50.0 vs 54.4 at 384,
+        // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the
+        // 256 CUs with room for the spare workgroups.
+        a->s8_rows = (a->B <= 448) ? 4 : 8;
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;
