@@ -259,6 +259,10 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    import ctypes as C
+    from rl_arm_under_sparse_reward_amd import _lib as _l
+    mhz = C.c_double()
+    _l.check(r.ctx.lib.hp_ctx_clock_mhz(r.ctx.h, C.byref(mhz)))      # shader clock right after the timed region
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.batch * a.steps / dt
     out = {
@@ -275,7 +279,8 @@ def main():
                        ("issued by the library inside the cycle hipGraph)" if dp_native
                         else "issued through torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
-                   "final_losses": [float(losses[0]), float(losses[1])]},
+                   "final_losses": [float(losses[0]), float(losses[1])],
+                   "shader_clock_mhz_after_run": round(mhz.value)},
     }
     if prof:
         # algorithmic MACs per transition (minimal algorithm): 5 forward passes 699,648;
@@ -318,13 +323,15 @@ def main():
                 "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
                 "event_pair_empty_us": round(ev_floor_us, 3),
                 "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup, FP32 "
-                        "v_mfma_f32_4x4x1_16b_f32, 8-row slabs.  At batch 256 there are 32 slabs x 2 chains = 64 workgroups (of "
-                        "256 CUs) and each chain is 16 dependent layers, 8 of them 256x256; such a layer costs a workgroup "
-                        "~3.0 us against 1.9 us of MFMA issue, 2.0 us of LDS-DMA weight streaming and 2.6 us for both together "
-                        "in isolation (tools/ubench/stream_bw3.hip, DESIGN.md 3.1).  avg_launch_us = HIP-event pair around each "
-                        "eager launch on the launch stream; an event pair with nothing in between already reads "
-                        "event_pair_empty_us, so the rocprofv3 kernel durations in profiles/ lie between avg_launch_us and "
-                        "avg_launch_us_minus_empty_pair; achieved/frac use the conservative avg_launch_us",
+                        "v_mfma_f32_4x4x1_16b_f32, 4-row slabs up to batch 448 (8-row beyond).  At batch 256 there are 64 slabs x 2 "
+                        "chains = 128 workgroups (of 256 CUs) and each chain is 16 dependent layers, 8 of them 256x256; such a "
+                        "layer costs a workgroup ~2.6 us against 2.0 us of LDS-DMA weight streaming per CU (139 GB/s), 0.95 us "
+                        "of MFMA issue and 2.0 us for both together in isolation (tools/ubench/stream_bw3.hip, DESIGN.md 3.1): "
+                        "the binding resource is the per-CU weight stream of a latency chain, not the matrix pipes.  "
+                        "avg_launch_us = HIP-event pair around each eager launch on the launch stream; an event pair with "
+                        "nothing in between already reads event_pair_empty_us, so the rocprofv3 kernel durations in profiles/ "
+                        "lie between avg_launch_us and avg_launch_us_minus_empty_pair; achieved/frac use the conservative "
+                        "avg_launch_us",
                 "all_matrix_kernels": per,
             }
         s_ms = prof["sample"]["ms_per_step"]

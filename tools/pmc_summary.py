@@ -36,7 +36,7 @@ def main():
         print(path)
         for name, counter, n, avg, _ in per_kernel(path)[:14]:
             print(f"  {str(name)[:50]:50s} {counter:12s} n={n:6d} avg={avg:12.1f} KiB/launch")
-            short = str(name).split("(")[0]
+            short = str(name).split("(")[0].split("::")[-1]   # k_fb_slab8 lives in a namespace per slab height
             table.setdefault(short, {})[counter] = avg
     if out_json:
         kernels = {}
