@@ -233,11 +233,13 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
                                              const float *__restrict__ wlayer, const float *__restrict__ nxt, int epi,
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                              int ld_out, const unsigned char *mask_in = nullptr,
-                                             unsigned char *mask_out = nullptr) {
+                                             unsigned char *mask_out = nullptr, unsigned long long *tl2 = nullptr,
+                                             int k2 = 0) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
+    S8_TSTAMP(tl2, k2);
     f32x4 c[S8_NRG];
 #pragma unroll
     for (int g = 0; g < S8_NRG; ++g) c[g] = f32x4{0, 0, 0, 0};
@@ -249,7 +251,9 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     else s8_ring_step<0, false>(c, ring, rbase, wlayer, nxt, cg, b0, a, bfirst);
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
+    S8_TSTAMP(tl2, k2 + 1);
     s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    S8_TSTAMP(tl2, k2 + 2);
 }
 
 template <int T, int HALF>
@@ -399,7 +403,8 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
     s8_sync();
     S8_TSTAMP(tl, tbase + 1);
     if (g1) s8_store(bufA, S8_LD, H, g1 + row0 * H, H);
-    s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2);
+    s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2,
+                 tl, 24);
     s8_sync();
     S8_TSTAMP(tl, tbase + 2);
     if (g2) s8_store(bufB, S8_LD, H, g2 + row0 * H, H);

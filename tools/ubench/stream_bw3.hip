@@ -189,5 +189,16 @@ int main(int argc, char **argv) {
         const double us = c / 100.0;
         printf("nwg=%d mode=%d: %.2f us per 256 KiB (32 blocks per wave)\n", nwg, mode, us * 262144.0 / bytes);
     }
+    {   // 4 waves per workgroup, each streaming twice the blocks (same bytes per workgroup), 4-row MFMA work (mode 9)
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(k_mix<9>, dim3(nwg), dim3(256), 0, 0, src, 2 * nper, t, sink);
+            CK(hipDeviceSynchronize());
+        }
+        CK(hipMemcpy(h.data(), t, nwg * 8, hipMemcpyDeviceToHost));
+        double c = 0;
+        for (int i = 0; i < nwg; ++i) c += h[i];
+        c /= nwg;
+        printf("nwg=%d mode=9 with 4 waves x 64 blocks: %.2f us per 256 KiB\n", nwg, (c / 100.0) * 262144.0 / bytes);
+    }
     return 0;
 }
