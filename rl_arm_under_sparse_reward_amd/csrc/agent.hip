@@ -1530,6 +1530,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
     const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
                       a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&
                       a->g_sq == sq_threshold && a->g_stage == b->st_obs.p;
+    if (s == hipStreamLegacy) a->graph_refused = true;   // the legacy default stream cannot be captured: eager launches
     if (a->graph_refused) {   // see below
         HP_TRY(ensure_plan(a, n_batches));
         HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
