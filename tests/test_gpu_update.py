@@ -295,3 +295,26 @@ def test_engine_variants_are_bit_identical(switch, monkeypatch):
     got = _run_cycles(agent, graph=True)
     for a, b in zip(want, got):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+@pytest.mark.parametrize("batch", [256, 1024])
+def test_repeated_runs_are_bit_identical(batch, monkeypatch):
+    """Race check for the concurrent pieces of a cycle (index plans drawn two updates ahead, next minibatch gathered by
+    spare workgroups, input sets ping-ponging): 60 cycles = 2400 updates twice, then once with gather-ahead off --
+    identical parameters and sampler state every time.  Batch 256 runs 4-row slabs, 1024 8-row slabs."""
+    def run():
+        torch.manual_seed(0)
+        agent, rng = make_agent(batch=batch, n_eps=32, seed=21)
+        agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
+        for c in range(60):
+            agent.train_cycle(make_episodes(2, seed=300 + c % 7, mode="walk"), 40)
+        st = rng.get_state()
+        return (agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_CRITIC_TARGET),
+                np.asarray(st[1]), np.asarray([st[2]]))
+    first = run()
+    second = run()
+    monkeypatch.setenv("RLARM_AHEAD", "0")
+    third = run()
+    for other in (second, third):
+        for a, b in zip(first, other):
+            assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
