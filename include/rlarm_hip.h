@@ -199,7 +199,9 @@ int hp_agent_forward_backward(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_
 int hp_agent_grad_buffer(hp_agent *ag, void **dev_grads, int64_t *n_floats);
 int hp_agent_param_buffer(hp_agent *ag, void **dev_params, int64_t *n_floats); /* actor|critic, for Bcast (utils.py:6-15) */
 int hp_agent_apply(hp_agent *ag);
-int hp_agent_sync_targets(hp_agent *ag); /* ddpg_agent.py:33-34: targets := online nets */
+/* ddpg_agent.py:33-34: targets := online nets.  Also the call that makes parameters written through
+ * hp_agent_param_buffer (broadcast from rank 0) take effect in the kernels' weight copies. */
+int hp_agent_sync_targets(hp_agent *ag);
 
 /* ---- rank exchange on RCCL (one process per GPU; replaces mpi4py) -------------------------------
  * The three exchanges of the reference: sync_networks (utils.py:6-15, Bcast from rank 0), sync_grads

@@ -1332,6 +1332,9 @@ int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, in
 int hp_agent_sync_targets(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_sync_targets: null handle");
     HP_CHECK_HIP(hipMemcpyAsync(a->targets, a->params, sizeof(float) * a->n_arena, hipMemcpyDeviceToDevice, a->ctx->stream));
+    // the online parameters may just have been overwritten through hp_agent_param_buffer (sync_networks on a rank other
+    // than 0): their fragment-ordered copies are rebuilt here too, not only the targets'
+    HP_TRY(enqueue_relayout(a, false));
     return enqueue_relayout(a, true);
 }
 

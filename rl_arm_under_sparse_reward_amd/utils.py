@@ -77,21 +77,35 @@ class Communicator:
         return self._dist.get_rank() if self._dist else 0
 
     # ---- tensor-level collectives (host or device tensors)
+    def _staged(self, t: torch.Tensor):
+        """A gloo group moves host memory: device tensors go through a host copy (test / debugging transport)."""
+        return t.is_cuda and self._dist.get_backend() == "gloo"
+
     def allreduce_sum_(self, t: torch.Tensor):
         if self._dist:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+            if self._staged(t):
+                h = t.cpu()
+                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return t
 
     def allreduce_mean_(self, t: torch.Tensor):
         """normalizer.py:60-64: Allreduce(SUM) then divide by the number of ranks."""
         if self._dist:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+            self.allreduce_sum_(t)
             t /= self.world_size
         return t
 
     def broadcast_(self, t: torch.Tensor, root=0):
         if self._dist:
-            self._dist.broadcast(t, src=root)
+            if self._staged(t):
+                h = t.cpu()
+                self._dist.broadcast(h, src=root)
+                t.copy_(h)
+            else:
+                self._dist.broadcast(t, src=root)
         return t
 
     # ---- zero-copy collectives on library-owned device vectors
