@@ -54,7 +54,15 @@ class Communicator:
         self._dist.broadcast(ident, src=0)
         raw = (C.c_uint8 * 128)(*ident.cpu().tolist())
         h = C.c_void_p()
-        _lib.check(lib.hp_comm_create(ctx.h, raw, self.rank, self.world_size, C.byref(h)))
+        status = lib.hp_comm_create(ctx.h, raw, self.rank, self.world_size, C.byref(h))
+        # all ranks must agree on the transport: if the communicator could not be created anywhere (RCCL not loadable,
+        # two ranks on one GPU, ...) everybody falls back to torch.distributed
+        ok = torch.tensor([1 if status == 0 else 0], dtype=torch.int32, device=ident.device)
+        self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if status == 0:
+                lib.hp_comm_destroy(h)
+            return None
         self.native, self._native_lib = h, lib
         return h
 
