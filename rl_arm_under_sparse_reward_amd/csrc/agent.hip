@@ -1252,7 +1252,9 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // RLARM_ENGINE = slab8 (default) | slab16 | layers: the alternatives stay for A/B runs and debugging
         const char *e = getenv("RLARM_ENGINE");
         a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
-        a->slab8 = a->slab && !(e && strcmp(e, "slab16") == 0);
+        // thin slabs (4x4x1 MFMA) up to batch 1792, 16-row slabs (16x16x4 MFMA, a quarter of the weight traffic per row)
+        // beyond: measured 110.9 vs 117.2 us/update at batch 1536, 167.0 vs 135.5 at 2048, 318.8 vs 250.1 at 4096
+        a->slab8 = a->slab && (e ? strcmp(e, "slab16") != 0 : a->B <= 1792);
         // Thin slabs buy latency at small batches (more CUs busy, less matrix work per streamed weight block) and cost
         // L2 weight traffic per row: measured (4 vs 8 rows, us/update) 48.4 vs 52.4 at batch 256, 50.0 vs 54.4 at 384,
         // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the
