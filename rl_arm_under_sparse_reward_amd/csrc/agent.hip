@@ -101,7 +101,14 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #include "slab8.h"
 #undef S8_NRG
 #undef S8_NS
+#define S8_NRG 4
+#define S8_NS s8r16
+#include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
 #undef S8_ROWS
+#undef S8_RING
+#undef S8_RPW
 
 // Adam (torch.optim.Adam, _single_tensor_adam, no weight decay / amsgrad) on one arena element, plus the
 // fragment-ordered copies of the slab engines.  Shared by k_adam_frag and the weight-gradient GEMM epilogue
@@ -244,7 +251,7 @@ struct hp_agent {
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
-    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 rows beyond (RLARM_SLAB_ROWS overrides)
+    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -996,8 +1003,10 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         }
         if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
-        else
+        else if (a->s8_rows == 8)
             hipLaunchKernelGGL(s8r8::k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
+        else
+            hipLaunchKernelGGL(s8r16::k_fb_slab8, dim3(2 * nslab + P.n_plan + P.n_ahead), dim3(S8_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
     } else {
         {
@@ -1259,10 +1268,12 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // L2 weight traffic per row: measured (4 vs 8 rows, us/update) 48.4 vs 52.4 at batch 256, 50.0 vs 54.4 at 384,
         // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the
         // 256 CUs with room for the spare workgroups.
-        a->s8_rows = (a->B <= 448) ? 4 : 8;
+        // 8 vs 16 rows: 60.6 vs 87.4 at 768, 89.3 vs 91.1 at 1024, 111.0 vs 99.6 at 1536 (16-row slabs are MFMA-bound).
+        a->s8_rows = (a->B <= 448) ? 4 : (a->B <= 1280 ? 8 : 16);
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;
+            if (strcmp(sr, "16") == 0) a->s8_rows = 16;
         }
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');

@@ -27,7 +27,6 @@
 #define S8_WAVES 8
 #define S8_LD 260
 #define S8_LDX 52
-#define S8_RING 12
 #define S8_AHEAD_WGS 4   // spare workgroups that gather the next update's inputs
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
@@ -81,11 +80,17 @@ struct FbSlabArgs {
 #endif  // RLARM_SLAB8_SHARED
 
 // ---- everything below is compiled once per slab height: S8_NRG row groups of 4 (S8_NRG = 1: 4-row slabs, the
-// small-batch choice; S8_NRG = 2: 8-row slabs, half the weight traffic per row for batches that fill the chip),
+// small-batch choice; S8_NRG = 2 / 4: 8- / 16-row slabs, less weight traffic per row for batches that fill the chip),
 // each time inside its own namespace S8_NS (agent.hip includes this file twice)
 #undef S8_ROWS
 #define S8_ROWS (4 * S8_NRG)
+#undef S8_RING
+#define S8_RING (S8_NRG >= 4 ? 10 : 12)   // 16-row slabs need the LDS for their activation buffers
+#undef S8_RPW
+#define S8_RPW ((S8_ROWS + S8_WAVES - 1) / S8_WAVES)   // rows per wavefront in the one-wavefront-per-row stages
 namespace S8_NS {
+
+typedef unsigned short s8_mask_t;   // ReLU mask of one column: bit r = row r of the slab
 
 __device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (see slab.h)
     __builtin_amdgcn_sched_barrier(0);
@@ -182,8 +187,8 @@ __device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring,
 // stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
 // instead of the 8 gate values in e[].
 __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
-                                          int ld_out, const unsigned char *mask_in = nullptr,
-                                          unsigned char *mask_out = nullptr) {
+                                          int ld_out, const s8_mask_t *mask_in = nullptr,
+                                          s8_mask_t *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
@@ -211,7 +216,7 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
                     lout[row * ld_out + col] = (e[row] > 0.f) ? v : 0.f;
                 }
             }
-        if (mask_out) mask_out[col] = (unsigned char)outbits;
+        if (mask_out) mask_out[col] = (s8_mask_t)outbits;
     }
 }
 
@@ -232,8 +237,8 @@ __device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float 
 __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSlot *ring, int &rbase,
                                              const float *__restrict__ wlayer, const float *__restrict__ nxt, int epi,
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
-                                             int ld_out, const unsigned char *mask_in = nullptr,
-                                             unsigned char *mask_out = nullptr, unsigned long long *tl2 = nullptr,
+                                             int ld_out, const s8_mask_t *mask_in = nullptr,
+                                             s8_mask_t *mask_out = nullptr, unsigned long long *tl2 = nullptr,
                                              int k2 = 0) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
@@ -277,8 +282,8 @@ __device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlay
 // small layer: weights already in registers (s8_small_prefetch), no ring
 __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
                                                const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
-                                               int ld_out, const unsigned char *mask_in = nullptr,
-                                               unsigned char *mask_out = nullptr) {
+                                               int ld_out, const s8_mask_t *mask_in = nullptr,
+                                               s8_mask_t *mask_out = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
@@ -297,12 +302,12 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
     s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
 }
 
-// S8_ROWS x nout dot products of length 256 (nout <= 4): wave r < S8_ROWS owns row r (the other waves compute on
-// row r & (S8_ROWS - 1) and their result is ignored), lane p the reduction indices 4p..4p+3;
+// nout (<= 4) dot products of length 256 for ONE row (wavefront-wide; callers walk rows wave, wave + 8, ... and clamp
+// the row index for wavefronts that have none): lane p takes the reduction indices 4p..4p+3;
 // wv[j] = this lane's float4 of weights for output j (loaded by the caller well ahead of time).  On return lane j
 // (j < nout) holds output j of the wave's row (other lanes: unspecified).
-__device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int nout, const float4 (&wv)[4]) {
-    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & (S8_ROWS - 1), p = threadIdx.x & 63;
+__device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int row, int nout, const float4 (&wv)[4]) {
+    const int p = threadIdx.x & 63;
     const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
     float mine = 0.f;
 #pragma unroll
@@ -337,22 +342,24 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
 // this thread's row of the index plan: the first load of the kernel (everything else in the gather depends on it).
 // Unconditional (rows past the batch re-read the last record, plan_any is never null): a load under a branch is
 // merged with its default through a register copy, which makes the compiler wait for it on the spot.
-__device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0) {
-    const int m = (int)row0 + (int)((threadIdx.x >> 6) & (S8_ROWS - 1));
+__device__ __forceinline__ PlanRec s8_plan_rec(const GatherSrc &G, size_t row0, int r = -1) {
+    if (r < 0) r = (int)((threadIdx.x >> 6) & (S8_ROWS - 1));   // this wavefront's first row
+    const int m = (int)row0 + (r < S8_ROWS ? r : S8_ROWS - 1);
     return G.plan_any[m < G.B ? m : G.B - 1];
 }
 
 __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const PlanRec rec, int which, size_t row0, int ldx,
                                           int act_off, int act_dim, float max_action, float *Xout,
                                           float *rew_lds = nullptr) {
-    const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (r >= S8_ROWS) return;   // one wavefront per row; the upper waves have none
+    const int l = threadIdx.x & 63;
+    for (int r = threadIdx.x >> 6, it = 0; r < S8_ROWS; r += S8_WAVES, ++it) {   // one wavefront per row
+    const PlanRec rc = (it == 0) ? rec : s8_plan_rec(G, row0, r);
     const size_t m = row0 + r;
     const bool live = (int)m < G.B;
-    const long long e = rec.e;
-    const int t = rec.t, od = G.obs_dim, gd = G.goal_dim;
+    const long long e = rc.e;
+    const int t = rc.t, od = G.obs_dim, gd = G.goal_dim;
     const double *obs_row = G.obs + (e * (G.T + 1) + t + (which == 0 ? 1 : 0)) * od;
-    const double *g_src = rec.her ? G.ag + (e * (G.T + 1) + rec.fut) * gd : G.g + (e * G.T + t) * gd;
+    const double *g_src = rc.her ? G.ag + (e * (G.T + 1) + rc.fut) * gd : G.g + (e * G.T + t) * gd;
     if (l < ldx) {
         const int c = l;
         float x = 0.f;
@@ -388,6 +395,7 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const 
         G.R[m] = rew;
         if (rew_lds) rew_lds[r] = rew;
     }
+    }
 }
 
 // xin (K1 wide) -> h1 -> h2 -> h3.  Ring: layer 2 in flight on entry, `nxt` on exit.  m1..m3 (LDS, may be null):
@@ -396,8 +404,8 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
                                          const float *canon, int H,
                                          float *bufA, float *bufB, float *pbuf, float *g1, float *g2, float *g3,
                                          size_t row0, RingSlot *ring, int &rbase, const float *nxt,
-                                         unsigned long long *tl, int tbase, unsigned char *m1 = nullptr,
-                                         unsigned char *m2 = nullptr, unsigned char *m3 = nullptr) {
+                                         unsigned long long *tl, int tbase, s8_mask_t *m1 = nullptr,
+                                         s8_mask_t *m2 = nullptr, s8_mask_t *m3 = nullptr) {
     S8_TSTAMP(tl, tbase);
     s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1);
     s8_sync();
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ float rows[3][S8_ROWS];          // per-row scalars: Q' | Q (or Q_pi) | reward
     __shared__ __attribute__((aligned(16))) float dz[S8_ROWS * 20];
     __shared__ __attribute__((aligned(16))) float w1t[4 * 256];
-    __shared__ unsigned char msk[5][256];       // ReLU masks: critic h1, h2 | actor h1, h2, h3
+    __shared__ s8_mask_t msk[5][256];       // ReLU masks: critic h1, h2 | actor h1, h2, h3
     __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
     const int nslab = A.Mp / S8_ROWS;
     const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
@@ -576,12 +584,16 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_trunk(xin, la, wbaT, tn.wf, tn.canon, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
                  tn.wf + ca + lc.w2, tl, 1);
         {   // target actor head -> action block of the target critic's input (models.py:24)
-            const float z = s8_rowdots(bufA, S8_LD, ad, whT);
-            if (lane < ad && wave < S8_ROWS) {
-                const float th = tanhf(z + bhT);
-                const float u = (A.max_action * th) / A.max_action;
-                xin[wave * S8_LDX + A.act_off + lane] = u;
-                const_cast<float *>(A.XT)[(row0 + wave) * A.ldx + A.act_off + lane] = u;
+#pragma unroll
+            for (int i = 0; i < S8_RPW; ++i) {
+                const int rr = wave + S8_WAVES * i;
+                const float z = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, whT);
+                if (lane < ad && rr < S8_ROWS) {
+                    const float th = tanhf(z + bhT);
+                    const float u = (A.max_action * th) / A.max_action;
+                    xin[rr * S8_LDX + A.act_off + lane] = u;
+                    const_cast<float *>(A.XT)[(row0 + rr) * A.ldx + A.act_off + lane] = u;
+                }
             }
         }
         s8_sync();
@@ -589,10 +601,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_trunk(xin, lc, wbcT, tn.wf + ca, tn.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
                  on.wf + ca + lc.w2, tl, 8);
         {
-            const float q = s8_rowdots(bufA, S8_LD, 1, wqT);
-            if (lane == 0 && wave < S8_ROWS) {
-                rows[0][wave] = q + bqT;
-                A.QT[(row0 + wave) * 16] = q + bqT;
+#pragma unroll
+            for (int i = 0; i < S8_RPW; ++i) {
+                const int rr = wave + S8_WAVES * i;
+                const float q = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, 1, wqT);
+                if (lane == 0 && rr < S8_ROWS) {
+                    rows[0][rr] = q + bqT;
+                    A.QT[(row0 + rr) * 16] = q + bqT;
+                }
             }
         }
         S8_TSTAMP(tl, 13);
@@ -600,10 +616,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_trunk(xin2, lc, wbcA, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0, ring, rbase,
                  on.wd + ca + lc.w3, tl, 14, msk[0], msk[1], nullptr);
         {
-            const float q = s8_rowdots(bufA, S8_LD, 1, wqA);
-            if (lane == 0 && wave < S8_ROWS) {
-                rows[1][wave] = q + bqA;
-                A.QA[(row0 + wave) * 16] = q + bqA;
+#pragma unroll
+            for (int i = 0; i < S8_RPW; ++i) {
+                const int rr = wave + S8_WAVES * i;
+                const float q = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, 1, wqA);
+                if (lane == 0 && rr < S8_ROWS) {
+                    rows[1][rr] = q + bqA;
+                    A.QA[(row0 + rr) * 16] = q + bqA;
+                }
             }
         }
         s8_sync();
@@ -676,15 +696,18 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
              tl, 1, msk[2], msk[3], msk[4]);
-    float u_mine = 0.f, th_mine = 0.f;
-    {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
-        const float z = s8_rowdots(bufA, S8_LD, ad, wh);
-        if (lane < ad && wave < S8_ROWS) {
-            th_mine = tanhf(z + bh);
-            u_mine = (A.max_action * th_mine) / A.max_action;
-            xin[wave * S8_LDX + A.act_off + lane] = u_mine;
-            A.XP[(row0 + wave) * A.ldx + A.act_off + lane] = u_mine;
-            A.TP[(row0 + wave) * 16 + lane] = th_mine;
+    float u_mine[S8_RPW], th_mine[S8_RPW];
+#pragma unroll
+    for (int i = 0; i < S8_RPW; ++i) {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
+        const int rr = wave + S8_WAVES * i;
+        u_mine[i] = th_mine[i] = 0.f;
+        const float z = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, wh);
+        if (lane < ad && rr < S8_ROWS) {
+            th_mine[i] = tanhf(z + bh);
+            u_mine[i] = (A.max_action * th_mine[i]) / A.max_action;
+            xin[rr * S8_LDX + A.act_off + lane] = u_mine[i];
+            A.XP[(row0 + rr) * A.ldx + A.act_off + lane] = u_mine[i];
+            A.TP[(row0 + rr) * 16 + lane] = th_mine[i];
         }
     }
     s8_sync();
@@ -692,10 +715,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_trunk(xin, lc, wbc, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
              on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr);
     {
-        const float q = s8_rowdots(bufA, S8_LD, 1, wq);
-        if (lane == 0 && wave < S8_ROWS) {
-            rows[1][wave] = q + bq;
-            A.QP[(row0 + wave) * 16] = q + bq;
+#pragma unroll
+        for (int i = 0; i < S8_RPW; ++i) {
+            const int rr = wave + S8_WAVES * i;
+            const float q = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, 1, wq);
+            if (lane == 0 && rr < S8_ROWS) {
+                rows[1][rr] = q + bq;
+                A.QP[(row0 + rr) * 16] = q + bq;
+            }
         }
     }
     if (tid < 256) {
@@ -740,17 +767,21 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         float4 w1g[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
-        const float sj = s8_rowdots(bufA, S8_LD, ad, w1g);
-        if (lane < 16 && wave < S8_ROWS) {
-            const size_t m = row0 + wave;
-            float v = 0.f;
-            if (lane < ad && (int)m < Bk.B) {
-                const float gu = Bk.action_l2 * (2.f * u_mine / (float)(Bk.B * ad)) + sj;
-                const float gt = (gu / A.max_action) * A.max_action;
-                v = gt * (1.f - th_mine * th_mine);
+#pragma unroll
+        for (int i = 0; i < S8_RPW; ++i) {
+            const int rr = wave + S8_WAVES * i;
+            const float sj = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, w1g);
+            if (lane < 16 && rr < S8_ROWS) {
+                const size_t m = row0 + rr;
+                float v = 0.f;
+                if (lane < ad && (int)m < Bk.B) {
+                    const float gu = Bk.action_l2 * (2.f * u_mine[i] / (float)(Bk.B * ad)) + sj;
+                    const float gt = (gu / A.max_action) * A.max_action;
+                    v = gt * (1.f - th_mine[i] * th_mine[i]);
+                }
+                dz[rr * 20 + lane] = v;
+                Bk.dZ[m * 16 + lane] = v;
             }
-            dz[wave * 20 + lane] = v;
-            Bk.dZ[m * 16 + lane] = v;
         }
     }
     s8_sync();
