@@ -110,7 +110,7 @@ def test_three_sampled_updates_from_seed_golden():
     assert state_equal(rng, g["key"], g["pos"])            # sampler consumed exactly the reference's words
 
 
-@pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (1024, 4)])
+@pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (1024, 4), (7, 4), (449, 4), (1281, 4)])   # 4-, 8-, 16-row slabs, ragged
 def test_updates_track_oracle_over_a_cycle(batch, k):
     """40 updates + polyak against the torch-CPU oracle fed the same (bit-identical) minibatches."""
     torch.set_num_threads(4)
