@@ -101,7 +101,8 @@ int hp_buffer_read(hp_buffer *buf, int32_t which, int64_t first, int64_t n, doub
 /* replay_buffer.sample (:46-55) -> her_sampler.sample_her_transitions (her.py:13-41) with the
  * sparse goal-distance reward of bmirobot_env_push_F.py:20-23,84-90 inlined.
  *   future_p      her.py:8  (1 - 1/(1+replay_k));  0 disables relabelling
- *   sq_threshold  smallest double s with sqrt(s) > distance_threshold (reward = -(s >= sq_threshold))
+ *   sq_threshold  smallest double s with sqrt(s) > distance_threshold (reward = -(s >= sq_threshold));
+ *                 a NEGATIVE value selects the dense reward of compute_reward (:89-90): r = float32(-sqrt(s))
  * Any host output pointer may be NULL.  r is float32 [B] with bit patterns 0x80000000 / 0xBF800000.
  * e/t/future_t/her expose the drawn indices for parity tests (future_t is defined for every
  * sample; the reference uses it only where her != 0). */

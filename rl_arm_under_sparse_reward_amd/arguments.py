@@ -34,4 +34,5 @@ class Args:
     train_type: str = "push"
     env_name: str = "bmirobot_push seed125"
     distance_threshold: float = 0.05    # bmirobot_push_F.py:20 / bmirobot_pickandplace_v2.py:19
+    reward_type: str = "sparse"         # bmirobot_push_F.py:9; "dense" = -distance (compute_reward :89-90)
     grad_reduce: str = "sum"            # data-parallel gradient exchange: "sum" = utils.py:47 (reference), or "mean"

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_gather_fused(const double *__restrict__
             const double sq = __dmul_rn(d, d);
             s = (c == 0) ? sq : __dadd_rn(s, sq);
         }
-        R[i] = (s >= sq_threshold) ? -1.0f : -0.0f;
+        R[i] = hp_reward(s, sq_threshold);
     }
 }
 

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
             double sq = __dmul_rn(d, d);
             s = (c == 0) ? sq : __dadd_rn(s, sq);
         }
-        o_r[i] = (s >= sq_threshold) ? -1.0f : -0.0f;  // -(d > thr).astype(float32)
+        o_r[i] = hp_reward(s, sq_threshold);  // -(d > thr).astype(float32), or float32(-d)
     }
 }
 

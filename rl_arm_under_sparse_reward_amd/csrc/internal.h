@@ -172,6 +172,17 @@ struct hp_norm {
     bool in_recompute = false;
 };
 
+// Reward of a relabelled transition from the squared goal distance s (compute_reward, bmirobot_env_push_F.py:84-90):
+//   sq_threshold >= 0: sparse, -(d > thr) == -(s >= sq_threshold) with sq_threshold the smallest double whose correctly
+//                      rounded square root exceeds thr -- no square root on the device;
+//   sq_threshold <  0: dense, -d (the env returns it in float64; the learner narrows it to float32, ddpg_agent.py:243).
+#ifdef __HIPCC__
+__device__ __forceinline__ float hp_reward(double s, double sq_threshold) {
+    if (sq_threshold < 0.0) return (float)(-__dsqrt_rn(s));
+    return (s >= sq_threshold) ? -1.0f : -0.0f;
+}
+#endif
+
 // rank exchange (comm.hip): one RCCL communicator bound to the context's stream
 struct hp_comm {
     hp_ctx *ctx = nullptr;

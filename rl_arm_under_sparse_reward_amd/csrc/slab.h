@@ -448,7 +448,7 @@ __device__ __forceinline__ void slab_gather(float *xin, const GatherSrc &G, int 
                 const double sq = __dmul_rn(d, d);
                 s = (c == 0) ? sq : __dadd_rn(s, sq);
             }
-            rew = (s >= G.sq_threshold) ? -1.0f : -0.0f;
+            rew = hp_reward(s, G.sq_threshold);
         }
         G.R[m] = rew;
     }

@@ -390,7 +390,7 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const 
                 const double sq = __dmul_rn(d, d);
                 s = (c == 0) ? sq : __dadd_rn(s, sq);
             }
-            rew = (s >= G.sq_threshold) ? -1.0f : -0.0f;
+            rew = hp_reward(s, G.sq_threshold);
         }
         G.R[m] = rew;
         if (rew_lds) rew_lds[r] = rew;
@@ -498,7 +498,7 @@ __device__ __forceinline__ void s8_gather_ahead(const GatherSrc &G, float *XT, f
                 const double sj = __shfl(sq, j);
                 ssum = (j == 0) ? sj : __dadd_rn(ssum, sj);
             }
-            if (c == 0) G.R[m] = (ssum >= G.sq_threshold) ? -1.0f : -0.0f;
+            if (c == 0) G.R[m] = hp_reward(ssum, G.sq_threshold);
         }
     }
 }

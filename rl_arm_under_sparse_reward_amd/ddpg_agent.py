@@ -84,7 +84,10 @@ class ddpg_agent:
         self.her_module = her_sampler(args.replay_strategy, args.replay_k, reward_func,
                                       distance_threshold=None if reward_func is not None and hasattr(
                                           getattr(reward_func, "__self__", None), "distance_threshold")
-                                      else getattr(args, "distance_threshold", 0.05), rng=self.rng)
+                                      else getattr(args, "distance_threshold", 0.05),
+                                      reward_type=None if reward_func is not None and hasattr(
+                                          getattr(reward_func, "__self__", None), "reward_type")
+                                      else getattr(args, "reward_type", "sparse"), rng=self.rng)
         self.buffer = replay_buffer(self.env_params, self.args.buffer_size, self.her_module.sample_her_transitions,
                                     rng=self.rng, ctx=self.ctx)
         if getattr(self.args, "add_demo", False):

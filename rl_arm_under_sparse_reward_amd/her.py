@@ -12,8 +12,9 @@ bmirobot_env_push_F.py:84-90) run as HIP kernels; see csrc/rng.hip and csrc/buff
 passes `env.compute_reward` of a bmirobot env whose reward is sparse with
 `distance_threshold = 0.05` (bmirobot_push_F.py:9,20).  If the callable is a bound method
 of an object with `distance_threshold` / `reward_type` attributes they are honoured;
-anything else must be described with the keyword arguments.  A dense reward type is
-refused loudly rather than silently computed on the host.
+anything else must be described with the keyword arguments.  Both branches of the envs'
+compute_reward run on the device: 'sparse' (-(d > threshold)) and 'dense' (-d); any other
+reward is refused loudly rather than silently computed on the host.
 """
 from __future__ import annotations
 
@@ -58,12 +59,14 @@ class her_sampler:
             distance_threshold = getattr(owner, "distance_threshold", 0.05)
         if reward_type is None:
             reward_type = getattr(owner, "reward_type", "sparse")
-        if reward_type != "sparse":
+        if reward_type not in ("sparse", "dense"):
             raise NotImplementedError(
-                "only the sparse goal-distance reward of the bmirobot tasks runs on the device "
+                "only the goal-distance rewards of the bmirobot tasks ('sparse', 'dense') run on the device "
                 f"(got reward_type={reward_type!r}); there is no host fallback")
+        self.reward_type = reward_type
         self.distance_threshold = float(distance_threshold)
-        self.sq_threshold = squared_threshold(self.distance_threshold)
+        # the kernels take the squared threshold; a negative value selects the dense reward -d (compute_reward :89-90)
+        self.sq_threshold = squared_threshold(self.distance_threshold) if reward_type == "sparse" else -1.0
         self._rng = rng
 
     @property

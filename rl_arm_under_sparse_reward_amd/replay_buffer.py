@@ -82,6 +82,11 @@ class DeviceEpisodeBuffer:
             o.her = _lib.ptr(idx["her"], C.c_uint8)
         _lib.check(self.lib.hp_buffer_sample(self.h, rng.h, B, float(future_p), float(sq_threshold), C.byref(o)))
         tr["r"] = r                                                   # her.py:38 expand_dims(..., 1)
+        if float(sq_threshold) < 0:
+            # dense reward: the env returns -d in float64 (compute_reward :89-90); same arithmetic on the gathered rows
+            # (the device value above is its float32 narrowing, which is what the learner consumes)
+            diff = tr["ag_next"] - tr["g"]
+            tr["r"] = -np.sqrt((diff * diff).sum(axis=-1))[:, None]
         if with_indices:
             idx["her"] = idx["her"].astype(bool)
             return tr, idx

@@ -122,7 +122,7 @@ def test_empty_and_invalid_calls_raise_like_the_reference():
     with pytest.raises(TypeError):
         replay_buffer(ENV_PARAMS, 1000, lambda b, n: b)  # no host sample functions
     with pytest.raises(NotImplementedError):
-        her_sampler("future", 4, reward_type="dense")
+        her_sampler("future", 4, reward_type="shaped")   # only compute_reward's two branches run on the device
 
 
 def test_her_sampler_on_host_episode_dict():
@@ -153,3 +153,21 @@ def test_non_future_strategy_never_relabels():
     tr = buf.sample(64)
     for key in KEYS:
         assert np.array_equal(bits(tr[key]), bits(ref[key])), key
+
+
+def test_dense_reward_matches_compute_reward_bitwise():
+    """reward_type='dense' (compute_reward :89-90, -d in float64): the sampler returns the env's float64 values, the
+    learner's float32 reward vector is their narrowing (checked through the update test below)."""
+    from oracle.her_replay import compute_reward
+    from rl_arm_under_sparse_reward_amd.her import her_sampler
+    from rl_arm_under_sparse_reward_amd.replay_buffer import replay_buffer
+    rng = fresh_rng(31)
+    hs = her_sampler("future", 4, None, distance_threshold=0.05, reward_type="dense", rng=rng)
+    assert hs.sq_threshold < 0
+    buf = replay_buffer(dict(ENV_PARAMS), 40 * 100, hs.sample_her_transitions, rng=rng)
+    buf.store_episode(make_episodes(40, seed=5, mode="walk"))
+    tr = buf.sample(512)
+    want = compute_reward(tr["ag_next"], tr["g"], reward_type="dense")[:, None]
+    assert tr["r"].dtype == np.float64 and tr["r"].shape == (512, 1)
+    assert np.array_equal(tr["r"].view(np.uint64), want.view(np.uint64))
+    assert (tr["r"] <= 0).all() and (tr["r"] < 0).any()

@@ -318,3 +318,36 @@ def test_repeated_runs_are_bit_identical(batch, monkeypatch):
     for other in (second, third):
         for a, b in zip(first, other):
             assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def test_dense_reward_updates_track_oracle():
+    """Same chained comparison as above with reward_type='dense': r = float32(-d) on both sides."""
+    from functools import partial
+    from oracle.her_replay import compute_reward
+    torch.set_num_threads(4)
+    n_eps, batch = 64, 256
+    eps = make_episodes(n_eps, seed=3, mode="walk")
+    torch.manual_seed(0)
+    agent, rng = make_agent(batch=batch, n_eps=n_eps, seed=7, reward_type="dense")
+    assert agent.her_module.sq_threshold < 0
+    a0 = {kk: v.detach().clone() for kk, v in agent.actor_network.state_dict().items()}
+    c0 = {kk: v.detach().clone() for kk, v in agent.critic_network.state_dict().items()}
+    learner = oupd.DDPGLearner(a0, c0)
+    rs = np.random.RandomState(7)
+    st = EpisodeStore(100, 27, 3, 4, n_eps * 100)
+    fp = future_probability("future", 4)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    st.store_episode(eps, rs)
+    agent.buffer.store_episode(eps)
+    agent._update_normalizer()
+    update_normalizers(on, gn, eps, fp, rs)
+    n_up = 20
+    agent._update_network(n_up)
+    got = agent.last_losses(n_up)
+    dense = partial(compute_reward, reward_type="dense")
+    for i in range(n_up):
+        tr, _ = st.sample(batch, fp, rs, reward_fn=dense)
+        res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
+        assert abs(got[i, 0] - res["actor_loss"]) <= 1e-4 * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
+        assert abs(got[i, 1] - res["critic_loss"]) <= 1e-4 * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
+    assert state_equal(rng, *rs.get_state()[1:3])
