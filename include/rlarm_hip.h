@@ -114,6 +114,10 @@ typedef struct {
 } hp_sample_out;
 int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *host_out);
+/* diagnostic: average device microseconds of the sampler's two kernels (index draw; gather + relabel + reward into the
+ * reference's dict layout), `reps` back-to-back launches each, no host copies.  Consumes 1 + reps index draws. */
+int hp_buffer_sample_device_us(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
+                               int32_t reps, double *draw_us, double *gather_us);
 
 /* ---- running normalizer ----------------------------------------------------------------
  * normalizer.py:5-70.  float32 accumulators/totals/mean; std is float64 when std_f32 == 0

@@ -65,6 +65,8 @@ PROTOTYPES = {
     "hp_buffer_last_slots": (C.c_int, [C.c_void_p, i64p, C.c_int64]),
     "hp_buffer_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, f64p]),
     "hp_buffer_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.POINTER(SampleOut)]),
+    "hp_buffer_sample_device_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int32, f64p,
+                                             f64p]),
     "hp_buffer_destroy": (None, [C.c_void_p]),
     "hp_norm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, c_void_pp]),
     "hp_norm_update": (C.c_int, [C.c_void_p, f64p, C.c_int64]),

@@ -209,6 +209,43 @@ int hp_buffer_read(hp_buffer *b, int32_t which, int64_t first, int64_t n, double
     return HP_OK;
 }
 
+// diagnostic: device time of the standalone sampler kernels (no host copies): one index draw, then `reps` launches each of
+// the index-draw kernel and of the gather / relabel / reward kernel on that plan, bracketed by HIP events.  The stream
+// position advances by 1 + reps draws.
+int hp_buffer_sample_device_us(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
+                               int32_t reps, double *draw_us, double *gather_us) {
+    HP_REQUIRE(b && rng && draw_us && gather_us && batch > 0 && reps > 0, HP_ERR_INVALID, "hp_buffer_sample_device_us: bad argument");
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    hipStream_t s = b->ctx->stream;
+    const size_t row = (size_t)(2 * b->obs_dim + 3 * b->goal_dim + b->act_dim);
+    HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
+    HP_TRY(b->out.ensure(batch * row * 8 + batch * 4));
+    PlanRec *d_plan = b->plan.as<PlanRec>();
+    double *d_out = b->out.as<double>();
+    float *d_r = reinterpret_cast<float *>(d_out + batch * row);
+    hipEvent_t e0, e1, e2;
+    HP_CHECK_HIP(hipEventCreate(&e0));
+    HP_CHECK_HIP(hipEventCreate(&e1));
+    HP_CHECK_HIP(hipEventCreate(&e2));
+    HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));   // warm
+    HP_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    HP_CHECK_HIP(hipEventRecord(e1, s));
+    for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));
+    HP_CHECK_HIP(hipEventRecord(e2, s));
+    HP_CHECK_HIP(hipEventSynchronize(e2));
+    float ms01 = 0.f, ms12 = 0.f;
+    HP_CHECK_HIP(hipEventElapsedTime(&ms01, e0, e1));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms12, e1, e2));
+    *draw_us = 1e3 * ms01 / reps;
+    *gather_us = 1e3 * ms12 / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    return HP_OK;
+}
+
 int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *o) {
     HP_REQUIRE(b && rng && o, HP_ERR_INVALID, "hp_buffer_sample: null argument");
