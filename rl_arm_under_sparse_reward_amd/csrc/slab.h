@@ -56,7 +56,7 @@ __host__ __device__ __forceinline__ int frag_dx_index(int n, int k, int N) {
 struct ArenaMap {  // enough of the arena geometry to find (layer, n, k) of a flat index on the device
     NetLayout la, lc;
     int H;
-    int mode;      // 0: 16-row slab fragment order (slab.h), 1: 8-row slab order (slab8.h)
+    int mode;      // 0: 16-row slab fragment order (slab.h), 1: thin-slab order (slab8.h)
 };
 
 // canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases

@@ -1,5 +1,5 @@
-// slab8.h -- row-slab engine on v_mfma_f32_4x4x1_16b_f32, S8_ROWS (= 4) batch rows per workgroup (included by agent.hip;
-// the name dates from its 8-row first version).
+// slab8.h -- row-slab engine on v_mfma_f32_4x4x1_16b_f32, S8_ROWS = 4 * S8_NRG (4, 8 or 16) batch rows per workgroup;
+// included by agent.hip once per slab height (the name dates from its 8-row first version).
 //
 // Why a second slab engine: with 16-row slabs on the 16x16x4 MFMA (slab.h) a 256x256 layer costs a workgroup 1024
 // MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The 4x4x1 instruction (16
@@ -338,7 +338,7 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
     }
 }
 
-// HER gather for the 8 rows of a slab (same arithmetic as slab_gather / k_gather_fused); 64 threads per row
+// HER gather for the rows of a slab (same arithmetic as slab_gather / k_gather_fused); one wavefront per row
 // this thread's row of the index plan: the first load of the kernel (everything else in the gather depends on it).
 // Unconditional (rows past the batch re-read the last record, plan_any is never null): a load under a branch is
 // merged with its default through a register copy, which makes the compiler wait for it on the spot.
@@ -426,12 +426,12 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
 // Merged forward + backward: one launch per update instead of two.
 //   chain 0 (critic side):  actor_target -> critic_target -> Q';  critic(x, a) -> Q;  critic loss;  critic dX chain
 //   chain 1 (actor side):   actor -> critic(x, pi(x)) -> Q_pi;  actor loss;  dX through the critic and the actor
-//   chain 2: the workgroup that draws the next update's HER indices (as in k_bwd_slab8)
+//   spare workgroups: index plan of a later update, gather of the next update's inputs (FbSlabArgs)
 // Both chains are 8 256x256 layers long, no workgroup waits for another.  What the split kernels hand over through
 // global memory stays on chip here: Q / Q' / reward / action / tanh in LDS or registers, the top hidden layer in the
 // LDS slab it was computed in, the ReLU masks as one byte per column (s8_finish); the weight ring runs on from the
 // forward fragment copies into the dX copies without draining.  Arithmetic and summation order are those of
-// k_fwd_slab8 + k_bwd_slab8 (same device functions), so the results are bit-identical.
+// the separate forward and backward kernels this one replaced (same device functions): it reproduced their results bit for bit.
 
 // HER gather of rows [g * per, (g + 1) * per) of a minibatch into global input sets (same arithmetic as s8_gather:
 // her.py:26-38, ddpg_agent.py:228-243, normalizer.py:67-70).  One wavefront per row, 4 rows in flight per wavefront.
