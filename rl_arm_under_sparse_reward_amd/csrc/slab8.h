@@ -306,18 +306,48 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
 // the row index for wavefronts that have none): lane p takes the reduction indices 4p..4p+3;
 // wv[j] = this lane's float4 of weights for output j (loaded by the caller well ahead of time).  On return lane j
 // (j < nout) holds output j of the wave's row (other lanes: unspecified).
+// lane i += lane i + O for O in {8, 4, 2, 1}: inside a 16-lane row this is a DPP row shift (VALU speed) instead of a
+// trip through the LDS crossbar; lanes whose partner falls outside the row add 0, which only affects lanes the tree
+// never reads.  Same pairs as __shfl_down, so the same bits in lane 0 of each row.
+template <int O>
+__device__ __forceinline__ float s8_row_shl_add(float s) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x100 + O, 0xf, 0xf, true);   // row_shl:O, zero fill
+    return s + __int_as_float(moved);
+}
+__device__ __forceinline__ float s8_wave_sum_to_lane0(float s) {
+    s += __shfl_down(s, 32);
+    s += __shfl_down(s, 16);
+    s = s8_row_shl_add<8>(s);
+    s = s8_row_shl_add<4>(s);
+    s = s8_row_shl_add<2>(s);
+    s = s8_row_shl_add<1>(s);
+    return s;
+}
+
 __device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int row, int nout, const float4 (&wv)[4]) {
     const int p = threadIdx.x & 63;
     const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
+    if (nout == 1) {
+        const float s = s8_wave_sum_to_lane0((h.x * wv[0].x + h.y * wv[0].y) + (h.z * wv[0].z + h.w * wv[0].w));
+        return __shfl(s, 0);
+    }
+    // several outputs: the reduction trees advance TOGETHER (independent cross-lane moves in flight per level instead
+    // of one dependent chain per output; same tree per output, so the same bits).  wv[j] for j >= nout holds a valid
+    // duplicate row (callers clamp), its result is dropped.
+    float s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (h.x * wv[j].x + h.y * wv[j].y) + (h.z * wv[j].z + h.w * wv[j].w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += __shfl_down(s[j], 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += __shfl_down(s[j], 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = s8_row_shl_add<1>(s8_row_shl_add<2>(s8_row_shl_add<4>(s8_row_shl_add<8>(s[j]))));
     float mine = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (j < nout) {
-            float s = (h.x * wv[j].x + h.y * wv[j].y) + (h.z * wv[j].z + h.w * wv[j].w);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-            const float tot = __shfl(s, 0);
-            if (p == j) mine = tot;
-        }
+        const float tot = __shfl(s[j], 0);
+        if (p == j && j < nout) mine = tot;
     }
     return mine;
 }
@@ -696,6 +726,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
              tl, 1, msk[2], msk[3], msk[4]);
+    S8_TSTAMP(tl, 5);
     float u_mine[S8_RPW], th_mine[S8_RPW];
 #pragma unroll
     for (int i = 0; i < S8_RPW; ++i) {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
@@ -710,6 +741,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             A.TP[(row0 + rr) * 16 + lane] = th_mine[i];
         }
     }
+    S8_TSTAMP(tl, 6);
     s8_sync();
     S8_TSTAMP(tl, 7);
     s8_trunk(xin, lc, wbc, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
