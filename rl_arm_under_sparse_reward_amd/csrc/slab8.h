@@ -183,12 +183,13 @@ __device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring,
 }
 
 // combine the two reduction halves and run the epilogue.  c0: this wave's partial [row][col = lane]
-// mask_out (SE_BIAS_RELU, may be null): LDS byte per column, bit r = (output row r > 0) -- the ReLU mask the backward
+// gout (may be null): global [rows][256] copy of the output.
+// mask_out (SE_BIAS_RELU, may be null): LDS word per column, bit r = (output row r > 0) -- the ReLU mask the backward
 // stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
 // instead of the 8 gate values in e[].
 __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
                                           int ld_out, const s8_mask_t *mask_in = nullptr,
-                                          s8_mask_t *mask_out = nullptr) {
+                                          s8_mask_t *mask_out = nullptr, float *gout = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
@@ -206,15 +207,19 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
             for (int g = 0; g < S8_NRG; ++g) {
                 const int row = 4 * g + r;
                 const float v = c[g][r] + pbuf[row * 256 + col];
+                float o;
                 if (epi == SE_BIAS_RELU) {
-                    const float o = fmaxf(v + e[0], 0.f);
-                    lout[row * ld_out + col] = o;
+                    o = fmaxf(v + e[0], 0.f);
                     outbits |= (o > 0.f ? 1u : 0u) << row;
                 } else if (mask_in) {
-                    lout[row * ld_out + col] = ((bits >> row) & 1u) ? v : 0.f;
+                    o = ((bits >> row) & 1u) ? v : 0.f;
                 } else {
-                    lout[row * ld_out + col] = (e[row] > 0.f) ? v : 0.f;
+                    o = (e[row] > 0.f) ? v : 0.f;
                 }
+                lout[row * ld_out + col] = o;
+                // global copy for the weight-gradient GEMM straight from the register (a wavefront writes 64
+                // consecutive floats of one row): no second pass over the LDS slab before the next layer can start
+                if (gout) gout[(size_t)row * 256 + col] = o;
             }
         if (mask_out) mask_out[col] = (s8_mask_t)outbits;
     }
@@ -239,7 +244,7 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                              int ld_out, const s8_mask_t *mask_in = nullptr,
                                              s8_mask_t *mask_out = nullptr, unsigned long long *tl2 = nullptr,
-                                             int k2 = 0) {
+                                             int k2 = 0, float *gout = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
     if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
@@ -257,7 +262,7 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
     S8_TSTAMP(tl2, k2 + 1);
-    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout);
     S8_TSTAMP(tl2, k2 + 2);
 }
 
@@ -283,7 +288,7 @@ __device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlay
 __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
                                                const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                                int ld_out, const s8_mask_t *mask_in = nullptr,
-                                               s8_mask_t *mask_out = nullptr) {
+                                               s8_mask_t *mask_out = nullptr, float *gout = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
@@ -299,7 +304,7 @@ __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int 
         case 6: s8_small_steps<0, 6>(c, b, a); break;
         default: break;   // other input widths are rejected on the host
     }
-    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out);
+    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout);
 }
 
 // nout (<= 4) dot products of length 256 for ONE row (wavefront-wide; callers walk rows wave, wave + 8, ... and clamp
@@ -437,19 +442,18 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
                                          unsigned long long *tl, int tbase, s8_mask_t *m1 = nullptr,
                                          s8_mask_t *m2 = nullptr, s8_mask_t *m3 = nullptr) {
     S8_TSTAMP(tl, tbase);
-    s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1);
+    s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1,
+                   g1 ? g1 + row0 * H : nullptr);
     s8_sync();
     S8_TSTAMP(tl, tbase + 1);
-    if (g1) s8_store(bufA, S8_LD, H, g1 + row0 * H, H);
     s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2,
-                 tl, 24);
+                 tl, 24, g2 ? g2 + row0 * H : nullptr);
     s8_sync();
     S8_TSTAMP(tl, tbase + 2);
-    if (g2) s8_store(bufB, S8_LD, H, g2 + row0 * H, H);
-    s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD, nullptr, m3);
+    s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD, nullptr, m3, nullptr,
+                 0, g3 ? g3 + row0 * H : nullptr);
     s8_sync();
     S8_TSTAMP(tl, tbase + 3);
-    if (g3) s8_store(bufA, S8_LD, H, g3 + row0 * H, H);
 }
 
 // ===================================================================================================================
@@ -681,14 +685,13 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 19);
         s8_store(bufA, S8_LD, H, Bk.dA3 + row0 * H, H);
         s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD,
-                     msk[1]);
+                     msk[1], nullptr, nullptr, 0, Bk.dA2 + row0 * H);
         s8_sync();
         S8_TSTAMP(tl, 20);
-        s8_store(bufB, S8_LD, H, Bk.dA2 + row0 * H, H);
-        s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + ca + lc.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[0]);
+        s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + ca + lc.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[0],
+                     nullptr, nullptr, 0, Bk.dA1 + row0 * H);
         s8_sync();
         S8_TSTAMP(tl, 21);
-        s8_store(bufA, S8_LD, H, Bk.dA1 + row0 * H, H);
         if (tid < S8_ROWS) {
             Bk.dQA[(row0 + tid) * 16] = keep_g;
             if (tid == 0) Bk.part[slab] = keep_a;
@@ -818,18 +821,17 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     s8_sync();
     S8_TSTAMP(tl, 17);
-    s8_small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[4]);
+    s8_small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[4], nullptr, Bk.dK3 + row0 * H);
     s8_sync();
     S8_TSTAMP(tl, 18);
-    s8_store(bufB, S8_LD, H, Bk.dK3 + row0 * H, H);
-    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[3]);
+    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[3], nullptr,
+                 nullptr, 0, Bk.dK2 + row0 * H);
     s8_sync();
     S8_TSTAMP(tl, 19);
-    s8_store(bufA, S8_LD, H, Bk.dK2 + row0 * H, H);
-    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + la.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[2]);
+    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + la.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[2], nullptr,
+                 nullptr, 0, Bk.dK1 + row0 * H);
     s8_sync();
     S8_TSTAMP(tl, 20);
-    s8_store(bufB, S8_LD, H, Bk.dK1 + row0 * H, H);
     if (tid == 0) {
         Bk.part[nslab + slab] = keep_q;
         Bk.part[2 * nslab + slab] = keep_u;
