@@ -17,7 +17,12 @@
  *   - "dev" pointers are HIP device addresses (e.g. torch.Tensor.data_ptr());
  *   - all kernels are enqueued on the context's stream (hp_ctx_set_stream), so work
  *     is ordered with whatever else the caller enqueues on that stream;
- *   - one calling thread per handle (the reference's locks are never contended).
+ *   - calls on the handles of one context are serialised by a per-context lock held for the
+ *     duration of each call (the reference's per-object locks, replay_buffer.py:29,34,48 and
+ *     normalizer.py:22,27,42): a host feeder thread may call hp_buffer_store while another
+ *     thread drives hp_agent_train_cycle; the order in which the calls win the lock is the
+ *     order of their work on the stream and of their draws from the shared hp_rng.
+ *     hp_ctx_synchronize waits outside the lock.
  *   - there is NO CPU fallback: without a gfx950 device hp_ctx_create fails.
  */
 #ifndef RLARM_HIP_H
@@ -194,6 +199,12 @@ int hp_agent_get_losses(hp_agent *ag, float *out_host, int32_t n_last);
 int hp_agent_soft_update(hp_agent *ag);
 /* actor forward on host inputs (rollout side, ddpg_agent.py:114-116): x [rows, obs+goal] -> actions [rows, act] */
 int hp_agent_actor_forward(hp_agent *ag, int32_t net, const float *x_host, int64_t rows, float *actions_host);
+/* rollout side in one call (ddpg_agent._preproc_inputs :163-171 + actor, :114-116 / :288-292): float64 observation
+ * and goal rows -> normalise with the two normalizers (clip at each normalizer's default_clip_range), float32, actor
+ * forward -> actions [rows, act].  clip_obs > 0 additionally clips the raw values first (_preproc_og); the reference's
+ * rollouts do not, so the drop-in passes 0.  rows = the environments of a vectorised feeder stepped in lockstep. */
+int hp_agent_act(hp_agent *ag, hp_norm *o_norm, hp_norm *g_norm, int32_t net, const double *obs_host,
+                 const double *g_host, int64_t rows, double clip_obs, float *actions_host);
 
 /* Split-phase update for data-parallel ranks (utils.sync_grads, utils.py:43-48):
  *   forward_backward: sample + forwards + backwards, leaves SUM-able gradients in one flat device

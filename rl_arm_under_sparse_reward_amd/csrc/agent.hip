@@ -619,6 +619,29 @@ __global__ void k_pack_rows(const float *__restrict__ src, int rows, int width, 
     dst[(long long)r * ld + col0 + c] = src[idx];
 }
 
+// rollout inputs (ddpg_agent._preproc_inputs :163-171): normalised, clipped observation | goal rows in float32, the same
+// float64 arithmetic as the sampled minibatch rows (slab8.h s8_gather)
+__global__ void k_policy_inputs(const double *__restrict__ obs, const double *__restrict__ g, int rows, int od, int gd,
+                                const NormDev *__restrict__ onz, const NormDev *__restrict__ gnz, double clip_obs,
+                                double clip_o, double clip_g, float *X, int ld) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = od + gd;
+    if (idx >= (long long)rows * w) return;
+    const int r = (int)(idx / w), c = (int)(idx - (long long)r * w);
+    double v;
+    if (c < od) {
+        v = fmin(fmax(obs[(long long)r * od + c], -clip_obs), clip_obs);
+        v = __ddiv_rn(__dsub_rn(v, (double)onz->mean[c]), onz->std[c]);
+        v = fmin(fmax(v, -clip_o), clip_o);
+    } else {
+        const int j = c - od;
+        v = fmin(fmax(g[(long long)r * gd + j], -clip_obs), clip_obs);
+        v = __ddiv_rn(__dsub_rn(v, (double)gnz->mean[j]), gnz->std[j]);
+        v = fmin(fmax(v, -clip_g), clip_g);
+    }
+    X[(long long)r * ld + c] = (float)v;
+}
+
 __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, int act_off, int act_dim,
                                  float max_action, float *out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1300,6 +1323,7 @@ int64_t hp_agent_param_count(hp_agent *a, int32_t net) {
 
 int hp_agent_set_params(hp_agent *a, int32_t net, const float *flat_host, int64_t n) {
     HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_set_params: null argument");
+    HP_SERIALISE(a);
     HP_REQUIRE(net >= 0 && net <= 3, HP_ERR_INVALID, "hp_agent_set_params: net=%d not in 0..3", net);
     const bool critic = (net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET);
     const bool target = net >= 2;
@@ -1317,6 +1341,7 @@ int hp_agent_set_params(hp_agent *a, int32_t net, const float *flat_host, int64_
 
 int hp_agent_get_params(hp_agent *a, int32_t net, float *flat_host, int64_t n) {
     HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_get_params: null argument");
+    HP_SERIALISE(a);
     HP_REQUIRE(net >= 0 && net <= 3, HP_ERR_INVALID, "hp_agent_get_params: net=%d not in 0..3", net);
     return arena_read(a, net >= 2 ? a->targets : a->params, net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET,
                       flat_host, n);
@@ -1324,12 +1349,14 @@ int hp_agent_get_params(hp_agent *a, int32_t net, float *flat_host, int64_t n) {
 
 int hp_agent_get_grads(hp_agent *a, int32_t net, float *flat_host, int64_t n) {
     HP_REQUIRE(a && flat_host, HP_ERR_INVALID, "hp_agent_get_grads: null argument");
+    HP_SERIALISE(a);
     HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_CRITIC, HP_ERR_INVALID, "hp_agent_get_grads: net must be actor or critic");
     return arena_read(a, a->grads, net == HP_NET_CRITIC, flat_host, n);
 }
 
 int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_get_adam: null handle");
+    HP_SERIALISE(a);
     HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_CRITIC, HP_ERR_INVALID, "hp_agent_get_adam: net must be actor or critic");
     if (m_host) HP_TRY(arena_read(a, a->adam_m, net == HP_NET_CRITIC, m_host, n));
     if (v_host) HP_TRY(arena_read(a, a->adam_v, net == HP_NET_CRITIC, v_host, n));
@@ -1344,6 +1371,7 @@ int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, in
 
 int hp_agent_sync_targets(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_sync_targets: null handle");
+    HP_SERIALISE(a);
     HP_CHECK_HIP(hipMemcpyAsync(a->targets, a->params, sizeof(float) * a->n_arena, hipMemcpyDeviceToDevice, a->ctx->stream));
     // the online parameters may just have been overwritten through hp_agent_param_buffer (sync_networks on a rank other
     // than 0): their fragment-ordered copies are rebuilt here too, not only the targets'
@@ -1354,6 +1382,7 @@ int hp_agent_sync_targets(hp_agent *a) {
 int hp_agent_update_minibatch(hp_agent *a, const float *x, const float *x_next, const float *actions, const float *r,
                               float *losses_host) {
     HP_REQUIRE(a && x && x_next && actions && r, HP_ERR_INVALID, "hp_agent_update_minibatch: null argument");
+    HP_SERIALISE(a);
     const int B = a->B, Mp = a->Mp, ldx = a->ldx, xd = a->xdim, ad = a->cfg.act_dim;
     std::vector<float> hxa((size_t)Mp * ldx, 0.f), hxp((size_t)Mp * ldx, 0.f), hxt((size_t)Mp * ldx, 0.f), hr(Mp, 0.f);
     const float maxa = (float)a->cfg.max_action;
@@ -1384,6 +1413,7 @@ int hp_agent_update_minibatch(hp_agent *a, const float *x, const float *x_next, 
 int hp_agent_sample_and_update(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
                                double sq_threshold, int32_t n_updates) {
     HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_sample_and_update"));
+    HP_SERIALISE(a);
     HP_REQUIRE(n_updates > 0, HP_ERR_INVALID, "hp_agent_sample_and_update: n_updates must be positive");
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     HP_TRY(ensure_plan(a, n_updates));
@@ -1395,6 +1425,7 @@ int hp_agent_sample_and_update(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *
 int hp_agent_forward_backward(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
                               double sq_threshold) {
     HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_forward_backward"));
+    HP_SERIALISE(a);
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     HP_TRY(ensure_plan(a, 1));
     return enqueue_updates(a, b, on, gn, rng, future_p, sq_threshold, 1, false);
@@ -1402,6 +1433,7 @@ int hp_agent_forward_backward(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 
 int hp_agent_grad_buffer(hp_agent *a, void **dev_grads, int64_t *n_floats) {
     HP_REQUIRE(a && dev_grads && n_floats, HP_ERR_INVALID, "hp_agent_grad_buffer: null argument");
+    HP_SERIALISE(a);
     *dev_grads = a->grads;
     *n_floats = a->n_arena;
     return HP_OK;
@@ -1409,6 +1441,7 @@ int hp_agent_grad_buffer(hp_agent *a, void **dev_grads, int64_t *n_floats) {
 
 int hp_agent_param_buffer(hp_agent *a, void **dev_params, int64_t *n_floats) {
     HP_REQUIRE(a && dev_params && n_floats, HP_ERR_INVALID, "hp_agent_param_buffer: null argument");
+    HP_SERIALISE(a);
     *dev_params = a->params;
     *n_floats = a->n_arena;
     return HP_OK;
@@ -1416,6 +1449,7 @@ int hp_agent_param_buffer(hp_agent *a, void **dev_params, int64_t *n_floats) {
 
 int hp_agent_apply(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_apply: null handle");
+    HP_SERIALISE(a);
     HP_TRY(enqueue_adam(a));
     a->host_steps += 1;
     return HP_OK;
@@ -1423,6 +1457,7 @@ int hp_agent_apply(hp_agent *a) {
 
 int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
     HP_REQUIRE(a && out_host, HP_ERR_INVALID, "hp_agent_get_losses: null argument");
+    HP_SERIALISE(a);
     HP_REQUIRE(n_last > 0 && n_last <= LOSS_LOG, HP_ERR_INVALID, "hp_agent_get_losses: n_last must be in [1, %d]", LOSS_LOG);
     hipStream_t s = a->ctx->stream;
     AgentDevState h;
@@ -1441,24 +1476,27 @@ int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
 
 int hp_agent_soft_update(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_soft_update: null handle");
+    HP_SERIALISE(a);
     return enqueue_polyak(a);
 }
 
-int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_t rows, float *actions_host) {
-    HP_REQUIRE(a && x_host && actions_host, HP_ERR_INVALID, "hp_agent_actor_forward: null argument");
-    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_ACTOR_TARGET, HP_ERR_INVALID, "hp_agent_actor_forward: net must be an actor");
-    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_actor_forward: rows out of range");
-    const int H = a->H, ldx = a->ldx, xd = a->xdim, ad = a->cfg.act_dim;
+}  // extern "C" (re-opened below)
+
+// actor rows on the device.  Scratch layout: [head_bytes of caller data] | X rows | h1 | h2 | h3 | tanh | actions; `fill`
+// enqueues whatever turns the caller data into X (zeroed beforehand).
+template <typename Fill>
+static int actor_rows(hp_agent *a, int32_t net, int64_t rows, size_t head_bytes, float *actions_host, Fill fill) {
+    const int H = a->H, ldx = a->ldx, ad = a->cfg.act_dim;
     const int Mp = roundup((int)rows, 32);
     hipStream_t s = a->ctx->stream;
-    // scratch: raw x | X rows | h1 | h2 | h3 | tanh | actions
-    const size_t n_raw = (size_t)rows * xd, nX = (size_t)Mp * ldx, nH = (size_t)Mp * H, nT = (size_t)Mp * 16;
-    HP_TRY(a->fwd_ws.ensure((n_raw + nX + 3 * nH + nT + (size_t)rows * ad) * 4));
-    float *raw = a->fwd_ws.as<float>(), *X = raw + n_raw, *h1 = X + nX, *h2 = h1 + nH, *h3 = h2 + nH, *tp = h3 + nH,
+    const size_t nX = (size_t)Mp * ldx, nH = (size_t)Mp * H, nT = (size_t)Mp * 16;
+    head_bytes = (head_bytes + 15) & ~(size_t)15;
+    HP_TRY(a->fwd_ws.ensure(head_bytes + (nX + 3 * nH + nT + (size_t)rows * ad) * 4));
+    char *head = a->fwd_ws.as<char>();
+    float *X = reinterpret_cast<float *>(head + head_bytes), *h1 = X + nX, *h2 = h1 + nH, *h3 = h2 + nH, *tp = h3 + nH,
           *outp = tp + nT;
     HP_CHECK_HIP(hipMemsetAsync(X, 0, nX * 4, s));
-    HP_CHECK_HIP(hipMemcpyAsync(raw, x_host, n_raw * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, s, raw, (int)rows, xd, X, ldx, 0);
+    HP_TRY(fill(head, X, s));
     const NetLayout &l = a->la;
     const float *P = (net == HP_NET_ACTOR) ? a->params : a->targets;
     { Launch L; add_fwd(L, X, ldx, l.K1, P + l.w1, P + l.b1, h1, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
@@ -1477,6 +1515,48 @@ int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_
     HP_CHECK_HIP(hipMemcpyAsync(actions_host, outp, (size_t)rows * ad * 4, hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
     return HP_OK;
+}
+
+extern "C" {
+
+int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_t rows, float *actions_host) {
+    HP_REQUIRE(a && x_host && actions_host, HP_ERR_INVALID, "hp_agent_actor_forward: null argument");
+    HP_SERIALISE(a);
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_ACTOR_TARGET, HP_ERR_INVALID, "hp_agent_actor_forward: net must be an actor");
+    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_actor_forward: rows out of range");
+    const int xd = a->xdim, ldx = a->ldx;
+    const size_t n_raw = (size_t)rows * xd;
+    return actor_rows(a, net, rows, n_raw * 4, actions_host, [&](char *head, float *X, hipStream_t s) -> int {
+        float *raw = reinterpret_cast<float *>(head);
+        HP_CHECK_HIP(hipMemcpyAsync(raw, x_host, n_raw * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, s, raw, (int)rows, xd, X, ldx, 0);
+        HP_CHECK_HIP(hipGetLastError());
+        return (int)HP_OK;
+    });
+}
+
+int hp_agent_act(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, const double *obs_host, const double *g_host,
+                 int64_t rows, double clip_obs, float *actions_host) {
+    HP_REQUIRE(a && on && gn && obs_host && g_host && actions_host, HP_ERR_INVALID, "hp_agent_act: null argument");
+    HP_SERIALISE(a);
+    HP_REQUIRE(on->ctx == a->ctx && gn->ctx == a->ctx, HP_ERR_INVALID, "hp_agent_act: handles belong to different contexts");
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_ACTOR_TARGET, HP_ERR_INVALID, "hp_agent_act: net must be an actor");
+    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_act: rows out of range");
+    const int od = on->size, gd = gn->size;
+    HP_REQUIRE(od + gd == a->xdim, HP_ERR_INVALID, "hp_agent_act: normalizer sizes %d+%d do not match the actor input %d", od,
+               gd, a->xdim);
+    const size_t nb_o = (size_t)rows * od * 8, nb_g = (size_t)rows * gd * 8;
+    const double co = clip_obs > 0 ? clip_obs : INFINITY;
+    return actor_rows(a, net, rows, nb_o + nb_g, actions_host, [&](char *head, float *X, hipStream_t s) -> int {
+        double *d_obs = reinterpret_cast<double *>(head), *d_g = reinterpret_cast<double *>(head + nb_o);
+        HP_CHECK_HIP(hipMemcpyAsync(d_obs, obs_host, nb_o, hipMemcpyHostToDevice, s));
+        HP_CHECK_HIP(hipMemcpyAsync(d_g, g_host, nb_g, hipMemcpyHostToDevice, s));
+        const long long n = (long long)rows * (od + gd);
+        hipLaunchKernelGGL(k_policy_inputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_obs, d_g, (int)rows, od, gd,
+                           on->d, gn->d, co, on->clip, gn->clip, X, a->ldx);
+        HP_CHECK_HIP(hipGetLastError());
+        return (int)HP_OK;
+    });
 }
 
 }  // extern "C"
@@ -1508,6 +1588,7 @@ extern "C" {
 
 int hp_agent_set_grad_reduce(hp_agent *a, int32_t mean) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_grad_reduce: null handle");
+    HP_SERIALISE(a);
     if (a->grad_mean != (mean != 0)) drop_graph(a);
     a->grad_mean = mean != 0;
     return HP_OK;
@@ -1517,12 +1598,14 @@ int hp_agent_set_grad_reduce(hp_agent *a, int32_t mean) {
 // (a capture containing collectives was refused)
 int hp_agent_cycle_mode(hp_agent *a, int32_t *mode) {
     HP_REQUIRE(a && mode, HP_ERR_INVALID, "hp_agent_cycle_mode: null argument");
+    HP_SERIALISE(a);
     *mode = a->graph_refused ? 2 : (a->graph ? 1 : 0);
     return HP_OK;
 }
 
 int hp_agent_set_comm(hp_agent *a, hp_comm *comm) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_comm: null handle");
+    HP_SERIALISE(a);
     HP_REQUIRE(!comm || comm->ctx == a->ctx, HP_ERR_INVALID, "hp_agent_set_comm: communicator belongs to another context");
     drop_graph(a);
     a->graph_refused = false;
@@ -1535,6 +1618,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
                          const double *ag_host, const double *g, const double *actions, int64_t n_new,
                          double future_p, double sq_threshold, int32_t n_batches) {
     HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_train_cycle"));
+    HP_SERIALISE(a);
     HP_REQUIRE(obs && ag_host && g && actions, HP_ERR_INVALID, "hp_agent_train_cycle: null episode array");
     HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "hp_agent_train_cycle: n_new and n_batches must be positive");
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
@@ -1605,6 +1689,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
 //   available here (needs a buffer); 8: k_polyak
 int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_launch) {
     HP_REQUIRE(a && us_per_launch && n > 0, HP_ERR_INVALID, "hp_agent_debug_chain: bad argument");
+    HP_SERIALISE(a);
     hipStream_t s = a->ctx->stream;
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
@@ -1680,6 +1765,7 @@ int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_la
 // kernels: out[chain * 32 + k] for the forward kernel, out[96 + chain * 32 + k] for the backward kernel
 int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
     HP_REQUIRE(a && out192, HP_ERR_INVALID, "hp_agent_debug_timeline: bad argument");
+    HP_SERIALISE(a);
     HP_CHECK_HIP(hipMemcpyAsync(out192, a->timeline, 192 * 8, hipMemcpyDeviceToHost, a->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
 #ifdef SLAB_TIMELINE   // weight-gradient GEMM stamps: first workgroup at [160..175], last at [176..191]
@@ -1690,6 +1776,7 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
 
 int hp_agent_profile(hp_agent *a, int32_t enable) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_profile: null handle");
+    HP_SERIALISE(a);
     a->prof = enable != 0;
     for (int i = 0; i < PROF_N; ++i) {
         a->prof_ms[i] = 0;
@@ -1702,6 +1789,7 @@ int hp_agent_profile(hp_agent *a, int32_t enable) {
 // adam(+polyak), index plan, weight-gradient GEMM (slab engine)
 int hp_agent_profile_read(hp_agent *a, double *ms_out, int32_t n) {
     HP_REQUIRE(a && ms_out, HP_ERR_INVALID, "hp_agent_profile_read: null argument");
+    HP_SERIALISE(a);
     for (int i = 0; i < PROF_N && 2 * i + 1 < n; ++i) {
         ms_out[2 * i] = a->prof_ms[i];
         ms_out[2 * i + 1] = (double)a->prof_cnt[i];

@@ -167,6 +167,7 @@ int hp_buffer_create(hp_ctx *ctx, int64_t size_episodes, int32_t T, int32_t obs_
 int hp_buffer_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
                     const double *actions, int64_t n_new) {
     HP_REQUIRE(b && rng && obs && ag && g && actions, HP_ERR_INVALID, "hp_buffer_store: null argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(n_new > 0, HP_ERR_INVALID, "hp_buffer_store: n_new must be positive");
     // replay_buffer.py:64 with current_size == 0 and inc > size: np.random.randint(0, 0, k) raises
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
@@ -175,6 +176,7 @@ int hp_buffer_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *
 
 int hp_buffer_info(hp_buffer *b, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored, int32_t *T) {
     HP_REQUIRE(b, HP_ERR_INVALID, "hp_buffer_info: null handle");
+    HP_SERIALISE(b);
     if (size) *size = b->size;
     if (current_size) *current_size = b->current_size;
     if (n_transitions_stored) *n_transitions_stored = b->n_transitions_stored;
@@ -184,6 +186,7 @@ int hp_buffer_info(hp_buffer *b, int64_t *size, int64_t *current_size, int64_t *
 
 int hp_buffer_last_slots(hp_buffer *b, int64_t *host_out, int64_t n) {
     HP_REQUIRE(b && host_out, HP_ERR_INVALID, "hp_buffer_last_slots: null argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(n >= 0 && n <= b->staged_n, HP_ERR_INVALID, "hp_buffer_last_slots: n=%lld exceeds last store (%lld)",
                (long long)n, (long long)b->staged_n);
     HP_CHECK_HIP(hipMemcpyAsync(host_out, b->st_slots.p, n * 8, hipMemcpyDeviceToHost, b->ctx->stream));
@@ -193,6 +196,7 @@ int hp_buffer_last_slots(hp_buffer *b, int64_t *host_out, int64_t n) {
 
 int hp_buffer_read(hp_buffer *b, int32_t which, int64_t first, int64_t n, double *host_out) {
     HP_REQUIRE(b && host_out, HP_ERR_INVALID, "hp_buffer_read: null argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(first >= 0 && n >= 0 && first + n <= b->size, HP_ERR_INVALID, "hp_buffer_read: range out of bounds");
     const double *src;
     size_t ep;
@@ -215,6 +219,7 @@ int hp_buffer_read(hp_buffer *b, int32_t which, int64_t first, int64_t n, double
 int hp_buffer_sample_device_us(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                                int32_t reps, double *draw_us, double *gather_us) {
     HP_REQUIRE(b && rng && draw_us && gather_us && batch > 0 && reps > 0, HP_ERR_INVALID, "hp_buffer_sample_device_us: bad argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     hipStream_t s = b->ctx->stream;
     const size_t row = (size_t)(2 * b->obs_dim + 3 * b->goal_dim + b->act_dim);
@@ -249,6 +254,7 @@ int hp_buffer_sample_device_us(hp_buffer *b, hp_rng *rng, int64_t batch, double 
 int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *o) {
     HP_REQUIRE(b && rng && o, HP_ERR_INVALID, "hp_buffer_sample: null argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(batch > 0, HP_ERR_INVALID, "hp_buffer_sample: batch must be positive");
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");  // np.random.randint(0, 0, B), her.py:24
     hipStream_t s = b->ctx->stream;

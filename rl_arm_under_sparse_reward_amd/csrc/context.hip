@@ -65,13 +65,19 @@ int hp_ctx_create(int device_id, hp_ctx **out) {
 
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream) {
     HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_set_stream: null ctx");
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return HP_OK;
 }
 
 int hp_ctx_synchronize(hp_ctx *ctx) {
     HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_synchronize: null ctx");
-    HP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t s;
+    {   // wait outside the lock: a feeder thread may keep storing while this thread waits for a cycle
+        std::lock_guard<std::recursive_mutex> guard(ctx->mu);
+        s = ctx->stream;
+    }
+    HP_CHECK_HIP(hipStreamSynchronize(s));
     return HP_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,7 +45,17 @@ struct hp_ctx {
     hipStream_t own_stream = nullptr;  // created by the context
     int cu_count = 0;
     char name[128] = {0};
+    // Every entry point that enqueues on the stream or touches a handle's host mirror holds this for the duration of the
+    // call: the counterpart of the reference's per-object locks (replay_buffer.py:29,34,48; normalizer.py:22,27,42), so a
+    // host feeder thread may call hp_buffer_store while another thread drives hp_agent_train_cycle.  Recursive because
+    // entry points call each other.
+    std::recursive_mutex mu;
 };
+struct CtxGuard {   // + the calling thread's current device: HIP keeps that per thread and a feeder thread starts on device 0
+    std::lock_guard<std::recursive_mutex> g;
+    explicit CtxGuard(hp_ctx *c) : g(c->mu) { (void)hipSetDevice(c->device); }
+};
+#define HP_SERIALISE(handle) CtxGuard hp_serialise_guard_((handle)->ctx)
 
 // small RAII-less device buffer helper (grow-only)
 struct DevBuf {

@@ -245,6 +245,7 @@ int hp_norm_create(hp_ctx *ctx, int32_t size, double eps, double default_clip_ra
 
 int hp_norm_update(hp_norm *nz, const double *v_host, int64_t rows) {
     HP_REQUIRE(nz && v_host, HP_ERR_INVALID, "hp_norm_update: null argument");
+    HP_SERIALISE(nz);
     HP_REQUIRE(rows >= 0, HP_ERR_INVALID, "hp_norm_update: negative rows");
     hipStream_t s = nz->ctx->stream;
     const size_t bytes = (size_t)rows * nz->size * 8;
@@ -263,6 +264,7 @@ int hp_norm_update(hp_norm *nz, const double *v_host, int64_t rows) {
 
 int hp_norm_recompute_begin(hp_norm *nz, void **dev_sync, int64_t *n_floats) {
     HP_REQUIRE(nz, HP_ERR_INVALID, "hp_norm_recompute_begin: null handle");
+    HP_SERIALISE(nz);
     HP_REQUIRE(!nz->in_recompute, HP_ERR_STATE, "hp_norm_recompute_begin: previous recompute not ended");
     HP_TRY(norm_launch_begin(nz));
     nz->in_recompute = true;
@@ -273,12 +275,15 @@ int hp_norm_recompute_begin(hp_norm *nz, void **dev_sync, int64_t *n_floats) {
 
 int hp_norm_recompute_end(hp_norm *nz) {
     HP_REQUIRE(nz, HP_ERR_INVALID, "hp_norm_recompute_end: null handle");
+    HP_SERIALISE(nz);
     HP_REQUIRE(nz->in_recompute, HP_ERR_STATE, "hp_norm_recompute_end: begin was not called");
     nz->in_recompute = false;
     return norm_launch_end(nz);
 }
 
 int hp_norm_recompute(hp_norm *nz) {
+    HP_REQUIRE(nz, HP_ERR_INVALID, "hp_norm_recompute: null handle");
+    HP_SERIALISE(nz);
     HP_TRY(hp_norm_recompute_begin(nz, nullptr, nullptr));
     return hp_norm_recompute_end(nz);
 }
@@ -286,6 +291,7 @@ int hp_norm_recompute(hp_norm *nz) {
 int hp_norm_get(hp_norm *nz, float *mean, double *std, float *total_sum, float *total_sumsq, float *total_count,
                 float *local_sum, float *local_sumsq, float *local_count) {
     HP_REQUIRE(nz, HP_ERR_INVALID, "hp_norm_get: null handle");
+    HP_SERIALISE(nz);
     NormDev h;
     HP_CHECK_HIP(hipMemcpyAsync(&h, nz->d, sizeof(h), hipMemcpyDeviceToHost, nz->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(nz->ctx->stream));
@@ -303,6 +309,7 @@ int hp_norm_get(hp_norm *nz, float *mean, double *std, float *total_sum, float *
 
 int hp_norm_set_stats(hp_norm *nz, const float *mean, const double *std) {
     HP_REQUIRE(nz && mean && std, HP_ERR_INVALID, "hp_norm_set_stats: null argument");
+    HP_SERIALISE(nz);
     hipStream_t s = nz->ctx->stream;
     const int n = nz->size;
     HP_TRY(nz->scratch2.ensure(64 * 4 + 64 * 8));
@@ -320,6 +327,7 @@ int hp_norm_set_stats(hp_norm *nz, const float *mean, const double *std) {
 
 int hp_norm_normalize(hp_norm *nz, const double *v_host, int64_t rows, double clip_range, double *out_host) {
     HP_REQUIRE(nz && v_host && out_host, HP_ERR_INVALID, "hp_norm_normalize: null argument");
+    HP_SERIALISE(nz);
     HP_REQUIRE(rows >= 0, HP_ERR_INVALID, "hp_norm_normalize: negative rows");
     if (rows == 0) return HP_OK;
     hipStream_t s = nz->ctx->stream;
@@ -339,6 +347,7 @@ int hp_norm_normalize(hp_norm *nz, const double *v_host, int64_t rows, double cl
 int hp_norm_update_from_staged(hp_buffer *b, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, double future_p,
                                double clip_obs) {
     HP_REQUIRE(b && rng && o_norm && g_norm, HP_ERR_INVALID, "hp_norm_update_from_staged: null argument");
+    HP_SERIALISE(b);
     HP_REQUIRE(b->staged_n > 0, HP_ERR_STATE, "hp_norm_update_from_staged: no staged episodes (call hp_buffer_store first)");
     HP_REQUIRE(o_norm->size == b->obs_dim && g_norm->size == b->goal_dim, HP_ERR_INVALID,
                "hp_norm_update_from_staged: normalizer sizes do not match the buffer");

@@ -97,6 +97,7 @@ int hp_rng_create(hp_ctx *ctx, hp_rng **out) {
 // numpy _legacy_seeding(int) -> mt19937_seed(): init_genrand, pos = 624.
 int hp_rng_seed(hp_rng *rng, uint32_t seed) {
     HP_REQUIRE(rng, HP_ERR_INVALID, "hp_rng_seed: null handle");
+    HP_SERIALISE(rng);
     MtState h;
     memset(&h, 0, sizeof(h));
     for (int i = 0; i < MT_N; ++i) {
@@ -112,6 +113,7 @@ int hp_rng_seed(hp_rng *rng, uint32_t seed) {
 
 int hp_rng_set_state(hp_rng *rng, const uint32_t *key624, int32_t pos) {
     HP_REQUIRE(rng && key624, HP_ERR_INVALID, "hp_rng_set_state: null argument");
+    HP_SERIALISE(rng);
     HP_REQUIRE(pos >= 0 && pos <= MT_N, HP_ERR_INVALID, "hp_rng_set_state: pos %d outside [0, 624]", pos);
     MtState h;
     memset(&h, 0, sizeof(h));
@@ -124,6 +126,7 @@ int hp_rng_set_state(hp_rng *rng, const uint32_t *key624, int32_t pos) {
 
 int hp_rng_get_state(hp_rng *rng, uint32_t *key624, int32_t *pos) {
     HP_REQUIRE(rng && key624 && pos, HP_ERR_INVALID, "hp_rng_get_state: null argument");
+    HP_SERIALISE(rng);
     MtState h;
     HP_CHECK_HIP(hipMemcpyAsync(&h, rng->d_state, sizeof(h), hipMemcpyDeviceToHost, rng->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(rng->ctx->stream));
@@ -134,6 +137,7 @@ int hp_rng_get_state(hp_rng *rng, uint32_t *key624, int32_t *pos) {
 
 int hp_rng_randint(hp_rng *rng, int64_t low, int64_t high, int64_t count, int64_t *host_out) {
     HP_REQUIRE(rng && host_out, HP_ERR_INVALID, "hp_rng_randint: null argument");
+    HP_SERIALISE(rng);
     HP_REQUIRE(high > low, HP_ERR_INVALID, "high <= 0");  // numpy's message for randint(0, 0)
     HP_REQUIRE(high - low - 1 < 0xFFFFFFFFll, HP_ERR_INVALID, "hp_rng_randint: range needs more than 32 bits");
     HP_REQUIRE(count >= 0, HP_ERR_INVALID, "hp_rng_randint: negative count");
@@ -149,6 +153,7 @@ int hp_rng_randint(hp_rng *rng, int64_t low, int64_t high, int64_t count, int64_
 
 int hp_rng_uniform(hp_rng *rng, int64_t count, double *host_out) {
     HP_REQUIRE(rng && host_out, HP_ERR_INVALID, "hp_rng_uniform: null argument");
+    HP_SERIALISE(rng);
     HP_REQUIRE(count >= 0, HP_ERR_INVALID, "hp_rng_uniform: negative count");
     if (count == 0) return HP_OK;
     HP_TRY(rng->scratch.ensure((size_t)count * 8));

@@ -43,7 +43,10 @@ class ddpg_agent:
     def __init__(self, args, env, env_params, comm: Communicator | None = None, ctx=None, rng=None):
         self.savetime = 0
         self.args = args
-        self.env = env
+        # one environment, or a list of them: the rollout / evaluation loops step a list in lockstep with one batched
+        # policy call per timestep (the host feeder of SURVEY 8f N1)
+        self.envs = list(env) if isinstance(env, (list, tuple)) else [env]
+        self.env = self.envs[0]
         self.env_params = env_params
         self.ctx = ctx or _lib.Context.default()
         self.lib = self.ctx.lib
@@ -80,7 +83,7 @@ class ddpg_agent:
         self._broadcast_params(self.comm)                       # sync_networks x2 (ddpg_agent.py:27-28)
         _lib.check(self.lib.hp_agent_sync_targets(self.h))      # targets := online (ddpg_agent.py:33-34)
         # her sampler + replay buffer (ddpg_agent.py:45-47)
-        reward_func = getattr(env, "compute_reward", None)
+        reward_func = getattr(self.env, "compute_reward", None)
         self.her_module = her_sampler(args.replay_strategy, args.replay_k, reward_func,
                                       distance_threshold=None if reward_func is not None and hasattr(
                                           getattr(reward_func, "__self__", None), "distance_threshold")
@@ -268,10 +271,23 @@ class ddpg_agent:
         inputs = np.concatenate([self.o_norm.normalize(obs), self.g_norm.normalize(g)])
         return torch.tensor(inputs, dtype=torch.float32).unsqueeze(0)
 
+    def act(self, obs, g, target=False):
+        """_preproc_inputs (:163-171) + actor (:114-116) for a stack of environments in ONE device call: obs [n, obs] and
+        g [n, goal] float64 (or single rows) -> actions [n, action] float32."""
+        obs, g = _lib.as_f64(obs), _lib.as_f64(g)
+        o2, g2 = obs.reshape(-1, obs.shape[-1]), g.reshape(-1, g.shape[-1])
+        if o2.shape[0] != g2.shape[0]:
+            raise ValueError("act: observation and goal stacks differ in length")
+        out = np.empty((o2.shape[0], self.env_params['action']), np.float32)
+        d = C.c_double
+        _lib.check(self.lib.hp_agent_act(self.h, self.o_norm.h, self.g_norm.h, NET_ACTOR_TARGET if target else NET_ACTOR,
+                                         _lib.ptr(o2, d), _lib.ptr(g2, d), o2.shape[0], 0.0, _lib.ptr(out, C.c_float)))
+        return out.reshape(obs.shape[:-1] + (out.shape[-1],))
+
     def _select_actions(self, pi):
         """ddpg_agent.py:174-184: Gaussian noise, clip, epsilon-random (numpy global RNG, like the reference)."""
         amax = self.env_params['action_max']
-        action = pi.cpu().numpy().squeeze()
+        action = (pi.cpu().numpy() if isinstance(pi, torch.Tensor) else np.asarray(pi, dtype=np.float32)).squeeze()
         action = action + self.args.noise_eps * amax * np.random.randn(*action.shape)
         action = np.clip(action, -amax, amax)
         random_actions = np.random.uniform(low=-amax, high=amax, size=self.env_params['action'])
@@ -279,24 +295,35 @@ class ddpg_agent:
         return action
 
     def collect_episodes(self, n_rollouts, epoch=0, explore=True):
-        """Roll the policy out in self.env (gym GoalEnv dict API) and return the four episode arrays."""
+        """Rollout half of learn() (:101-137) for `n_rollouts` episodes; returns the four episode arrays.  The
+        environments in self.envs are stepped in lockstep, one batched policy call per timestep; with a single
+        environment this is the reference's loop, including the order of its draws from numpy's global stream."""
         T = int(self.env_params['max_timesteps'])
         mb = ([], [], [], [])
-        for _ in range(n_rollouts):
-            ep_obs, ep_ag, ep_g, ep_act = [], [], [], []
-            observation = self.env.reset()
-            obs, ag, g = observation['observation'], observation['achieved_goal'], observation['desired_goal']
+        done = 0
+        while done < n_rollouts:
+            envs = self.envs[:n_rollouts - done]
+            k = len(envs)
+            first = [env.reset() for env in envs]
+            obs = [o['observation'] for o in first]
+            ag = [o['achieved_goal'] for o in first]
+            g = [o['desired_goal'] for o in first]
+            ep = [([], [], [], []) for _ in envs]
             for _t in range(T):
-                pi = self.actor_network(self._preproc_inputs(obs, g))
-                action = self._select_actions(pi) if explore else pi.numpy().squeeze()
-                if epoch >= 100:
-                    action = np.clip(action, -0.15, 0.15)            # ddpg_agent.py:118-119
-                observation_new, _, _, info = self.env.step(action)
-                ep_obs.append(obs.copy()); ep_ag.append(ag.copy()); ep_g.append(g.copy()); ep_act.append(action.copy())
-                obs, ag = observation_new['observation'], observation_new['achieved_goal']
-            ep_obs.append(obs.copy()); ep_ag.append(ag.copy())
-            for dst, src in zip(mb, (ep_obs, ep_ag, ep_g, ep_act)):
-                dst.append(src)
+                pi = self.act(np.stack(obs), np.stack(g))
+                for i, env in enumerate(envs):
+                    action = self._select_actions(pi[i]) if explore else pi[i].astype(np.float64)
+                    if epoch >= 100:
+                        action = np.clip(action, -0.15, 0.15)            # ddpg_agent.py:118-119
+                    observation_new, _, _, info = env.step(action)
+                    for dst, v in zip(ep[i], (obs[i], ag[i], g[i], action)):
+                        dst.append(np.array(v, dtype=np.float64))
+                    obs[i], ag[i] = observation_new['observation'], observation_new['achieved_goal']
+            for i in range(k):
+                ep[i][0].append(np.array(obs[i], dtype=np.float64)); ep[i][1].append(np.array(ag[i], dtype=np.float64))
+                for dst, src in zip(mb, ep[i]):
+                    dst.append(src)
+            done += k
         return [np.array(a) for a in mb]
 
     def learn(self):
@@ -316,18 +343,24 @@ class ddpg_agent:
                 self.save_checkpoint()
 
     def _eval_agent(self):
-        """ddpg_agent.py:280-304."""
+        """ddpg_agent.py:280-304: success at the last step of n_test_rollouts noise-free episodes, averaged over ranks;
+        the environments in self.envs run in lockstep with one batched policy call per timestep."""
         wins = []
-        for _ in range(self.args.n_test_rollouts):
-            observation = self.env.reset()
-            obs, g = observation['observation'], observation['desired_goal']
-            last = 0.0
+        remaining = int(self.args.n_test_rollouts)
+        while remaining > 0:
+            envs = self.envs[:remaining]
+            first = [env.reset() for env in envs]
+            obs = [o['observation'] for o in first]
+            g = [o['desired_goal'] for o in first]
+            last = [0.0] * len(envs)
             for _t in range(int(self.env_params['max_timesteps'])):
-                actions = self.actor_network(self._preproc_inputs(obs, g)).numpy().squeeze()
-                observation_new, _, _, info = self.env.step(actions)
-                obs, g = observation_new['observation'], observation_new['desired_goal']
-                last = float(info.get('is_success', last))
-            wins.append(last)
+                actions = self.act(np.stack(obs), np.stack(g))
+                for i, env in enumerate(envs):
+                    observation_new, _, _, info = env.step(actions[i])
+                    obs[i], g[i] = observation_new['observation'], observation_new['desired_goal']
+                    last[i] = float(info.get('is_success', last[i]))
+            wins.extend(last)
+            remaining -= len(envs)
         local = torch.tensor([float(np.mean(wins))], dtype=torch.float64)
         if self.comm.world_size > 1:
             local = local.to(f"cuda:{self.ctx.device_id}")

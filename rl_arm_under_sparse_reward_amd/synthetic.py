@@ -61,3 +61,60 @@ def write_demo_npz(path, n_episodes=8, seed=7, T=100):
             info[e, t] = {"is_success": np.float32(d < 0.05)}
     np.savez_compressed(path, acs=actions, obs=obs, info=info, g=g, ag=ag)
     return obs, ag, g, actions
+
+
+class PointMassGoalEnv:
+    """Stand-in for the PyBullet arm environments (the real ones need pybullet + gym, absent here): the
+    gym GoalEnv surface the learner's rollout loop uses -- reset() / step(action) returning the dict observation
+    {'observation', 'achieved_goal', 'desired_goal'} (bmirobot_env_push_F.py:233-237), step's 4-tuple with
+    info['is_success'] (:103-108) and a compute_reward vectorised over leading dims (:84-90) -- around a point mass
+    that the first three action components push through a 0.5 m box.  The observation keeps the bmirobot layout
+    (27 = 9 blocks of 3, achieved goal = block 4, :214,228).  It has its own RandomState so it never draws from
+    numpy's global stream, which belongs to the exploration noise."""
+
+    def __init__(self, seed=0, max_timesteps=100, distance_threshold=0.05, reward_type='sparse', step_scale=0.1):
+        self.rs = np.random.RandomState(seed)
+        self.max_timesteps = int(max_timesteps)
+        self.distance_threshold = float(distance_threshold)
+        self.reward_type = reward_type
+        self.step_scale = float(step_scale)
+        self.pos = np.zeros(3)
+        self.vel = np.zeros(3)
+        self.goal = np.zeros(3)
+
+    @property
+    def env_params(self):
+        return {'obs': 27, 'goal': 3, 'action': 4, 'action_max': 0.5, 'max_timesteps': self.max_timesteps}
+
+    def _observation(self):
+        obs = np.zeros(27)
+        obs[0:3] = self.pos                  # "gripper" block
+        obs[3:6] = self.vel
+        obs[12:15] = self.pos                # the block whose position is the achieved goal
+        return {'observation': obs, 'achieved_goal': self.pos.copy(), 'desired_goal': self.goal.copy()}
+
+    def reset(self):
+        self.pos = self.rs.uniform(0.0, 0.5, 3)
+        self.goal = self.rs.uniform(0.0, 0.5, 3)
+        self.vel = np.zeros(3)
+        return self._observation()
+
+    def compute_reward(self, achieved_goal, goal, info):
+        diff = np.asarray(achieved_goal) - np.asarray(goal)
+        d = np.linalg.norm(diff, axis=-1)
+        if self.reward_type == 'sparse':
+            return -(d > self.distance_threshold).astype(np.float32)
+        return -d
+
+    def _is_success(self, achieved_goal, desired_goal):
+        return (np.linalg.norm(achieved_goal - desired_goal, axis=-1) < self.distance_threshold).astype(np.float32)
+
+    def step(self, action):
+        action = np.clip(np.asarray(action, dtype=np.float64), -0.5, 0.5)
+        new = np.clip(self.pos + self.step_scale * action[:3], 0.0, 0.5)
+        self.vel = new - self.pos
+        self.pos = new
+        observation = self._observation()
+        info = {'is_success': self._is_success(observation['achieved_goal'], self.goal)}
+        reward = self.compute_reward(observation['achieved_goal'], self.goal, info)
+        return observation, reward, False, info

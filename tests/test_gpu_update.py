@@ -351,3 +351,42 @@ def test_dense_reward_updates_track_oracle():
         assert abs(got[i, 0] - res["actor_loss"]) <= 1e-4 * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
         assert abs(got[i, 1] - res["critic_loss"]) <= 1e-4 * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
     assert state_equal(rng, *rs.get_state()[1:3])
+
+
+def test_feeder_thread_stores_while_cycles_run():
+    """Threading row of the boundary (config 5's host feeder): a second thread calls store_episode while the
+    main thread drives train_cycle.  The per-context lock makes every call atomic, so whatever the interleaving every
+    episode lands in exactly one slot (no overflow here: slots are append order and draw nothing), the counters add up and
+    the learner state stays finite."""
+    import threading
+    agent, rng = make_agent(batch=256, n_eps=256, seed=3)
+    n_feed, per_feed, n_cycles = 24, 4, 12
+    fed = [make_episodes(per_feed, seed=1000 + i, mode="walk") for i in range(n_feed)]
+    own = [make_episodes(2, seed=2000 + i, mode="walk") for i in range(n_cycles)]
+    agent.buffer.store_episode(make_episodes(8, seed=5, mode="walk"))
+    errors = []
+
+    def feeder():
+        try:
+            for eps in fed:
+                agent.buffer.store_episode(eps)
+        except Exception as exc:                                    # surfaced in the main thread below
+            errors.append(exc)
+
+    th = threading.Thread(target=feeder)
+    th.start()
+    for eps in own:
+        agent.train_cycle(eps, n_batches=6)
+    th.join()
+    agent.ctx.synchronize()
+    assert not errors, errors
+    total = 8 + n_feed * per_feed + n_cycles * 2
+    assert agent.buffer.current_size == total
+    assert agent.buffer.n_transitions_stored == total * 100
+    stored = agent.buffer.buffers["obs"][:total]
+    want = np.concatenate([make_episodes(8, seed=5, mode="walk")[0]] + [e[0] for e in fed] + [e[0] for e in own])
+    key = lambda ep: ep[:2].tobytes()                               # first two observations identify an episode
+    assert sorted(key(e) for e in stored) == sorted(key(e) for e in want)
+    by_key = {key(e): e for e in want}
+    assert all(np.array_equal(e, by_key[key(e)]) for e in stored)   # whole episodes intact (no torn staging)
+    assert np.all(np.isfinite(agent.last_losses(6))) and np.all(np.isfinite(agent._get_flat(NET_CRITIC)))

@@ -76,3 +76,23 @@ def test_empty_buffer_raises_like_reference():
     import pytest
     with pytest.raises(ValueError):
         st.sample(4, 0.8, np.random.RandomState(0))
+
+
+def test_point_mass_env_follows_the_goalenv_contract():
+    """The stand-in GoalEnv's reward / success are the bmirobot ones (bmirobot_env_push_F.py:84-90,243-245), so the
+    device reward (pinned to the oracle elsewhere) relabels its episodes consistently."""
+    from rl_arm_under_sparse_reward_amd.synthetic import PointMassGoalEnv
+    env = PointMassGoalEnv(seed=3, max_timesteps=20)
+    first = env.reset()
+    assert first['observation'].shape == (27,) and np.array_equal(first['observation'][12:15], first['achieved_goal'])
+    glob = np.random.get_state()[1].copy()
+    rs = np.random.RandomState(0)
+    ag, g = rs.uniform(0, 0.5, (64, 3)), rs.uniform(0, 0.5, (64, 3))
+    g[:8] = ag[:8] + 0.01
+    assert np.array_equal(bits(env.compute_reward(ag, g, None)), bits(compute_reward(ag, g)))
+    dense = PointMassGoalEnv(reward_type='dense')
+    assert np.array_equal(dense.compute_reward(ag, g, None), compute_reward(ag, g, reward_type="dense"))
+    obs, r, done, info = env.step(np.array([0.5, -0.5, 0.1, 0.0]))
+    assert done is False and info['is_success'] in (0.0, 1.0) and r in (-0.0, -1.0)
+    assert np.all(obs['achieved_goal'] >= 0) and np.all(obs['achieved_goal'] <= 0.5)
+    assert np.array_equal(np.random.get_state()[1], glob)          # never touches the global stream
