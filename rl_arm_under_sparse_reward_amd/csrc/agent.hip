@@ -59,6 +59,9 @@ struct GemmProb {
 #define MAX_PROBS 8
 struct GemmGroup {
     int n;
+    int pipe;   // ring of reduction chunks for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: off, for A/B)
+    int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
+    int pad_;
     GemmProb p[MAX_PROBS];
 };
 
@@ -676,7 +679,25 @@ static int roundup(int v, int m) { return (v + m - 1) / m * m; }
 struct Launch {  // builds one grouped launch
     GemmGroup g;
     int tiles = 0;
-    Launch() { g.n = 0; }
+    Launch() {
+        g.n = 0;
+        const char *e = getenv("RLARM_GEMM_PIPE");
+        g.pipe = !(e && e[0] == '0');
+        g.xcd = 0;
+        g.pad_ = 0;
+    }
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and everything a weight-gradient tile reads
+    // was written by the previous kernel on other XCDs: it comes through the fabric once per XCD that touches it.  In
+    // row-major tile order every XCD reads 9 of the 16 operand panels of every problem (6.75 x the unique bytes in
+    // total); with one 256 x 256 problem per pair of XCDs (half of the row panels each) the fabric carries 1.5 x.
+    void place_on_xcds() {
+        const char *e = getenv("RLARM_GEMM_XCD");
+        if (e && e[0] == '0') return;
+        if (g.n < 4) return;
+        for (int i = 0; i < 4; ++i)
+            if (g.p[i].tiles_n != 8 || g.p[i].M != 256 || g.p[i].tile0 != 64 * i) return;
+        g.xcd = 1;
+    }
     GemmProb &add(int M, int N, int K) {
         GemmProb &p = g.p[g.n++];
         memset(&p, 0, sizeof(p));
@@ -1046,14 +1067,16 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     {   // all weight gradients: the only products that reduce over the batch
         float *Ga = a->grads, *Gc = a->grads + la.total;
         Launch L;
-        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+        // the four 256 x 256 problems first: Launch::place_on_xcds gives each of them one pair of XCDs
         add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
         add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
-        add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
-        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
         add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
         add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+        add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
         add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        L.place_on_xcds();
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
@@ -1292,7 +1315,10 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the
         // 256 CUs with room for the spare workgroups.
         // 8 vs 16 rows: 60.6 vs 87.4 at 768, 89.3 vs 91.1 at 1024, 111.0 vs 99.6 at 1536 (16-row slabs are MFMA-bound).
-        a->s8_rows = (a->B <= 448) ? 4 : (a->B <= 1280 ? 8 : 16);
+        // The kernel's LDS footprint allows one workgroup per CU, so a launch with more workgroups than CUs runs in two
+        // waves: 8 rows while the 2 * B / 8 chains fit (98.3 vs 90.9 at 1280, where they no longer do).
+        const int cus = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
+        a->s8_rows = (a->B <= 448) ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;
@@ -1302,6 +1328,10 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->fuse_adam_ok = !(fa && fa[0] == '0');
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
+        // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
+        // 1024 (256 chains) they ran after them, 87.6 vs 76.1 us/update
+        const int chains = 2 * (a->Mp / a->s8_rows);
+        if (!ah && chains + 1 + S8_AHEAD_WGS > cus) a->gather_ahead = false;
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);

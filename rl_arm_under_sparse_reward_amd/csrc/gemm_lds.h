@@ -75,6 +75,50 @@ __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag,
     return make_float4(p[((k0 + 0) ^ x) * 32], p[((k0 + 1) ^ x) * 32], p[((k0 + 2) ^ x) * 32], p[((k0 + 3) ^ x) * 32]);
 }
 
+// k-major staging of gl_stage with the transfer written as inline assembly.  The compiler tracks the builtin's LDS write
+// and, alias scopes or not, puts s_waitcnt vmcnt(0) in front of the first LDS read that follows it -- which would drain
+// the chunk in flight before the products of the previous one start.  The pipeline below orders the two itself: a
+// chunk is only read after the vmcnt(0) + barrier at the top of the step that consumes it.  (M0 holds the LDS base of
+// the transfer; hipcc reloads M0 in front of every instruction of its own that reads it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void gl_stage_kmajor_async(float *lds, const float *base, long long s_k, int valid, int kc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunk = valid >> 2;
+    for (int R = 8 * wave; R < kc; R += 8 * GL_WAVES) {
+        const int rowp = R + (lane >> 3);
+        const int k = rowp ^ ((rowp >> 3) & 1);
+        int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
+        gch = gch < nchunk ? gch : nchunk - 1;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + R * 32));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
+                     : "memory", "m0");
+    }
+}
+#pragma clang diagnostic pop
+
+// products of one staged chunk: wave w takes the 16-row blocks w, w + 8, ... of the chunk
+__device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB, bool a_rowk, bool b_rowk, int kc, int wave,
+                                            int i, int q, f32x4 &c00, f32x4 &c01, f32x4 &c10, f32x4 &c11, float &as0,
+                                            float &as1) {
+    const int nS = kc >> 4;
+    for (int S = wave; S < nS; S += GL_WAVES) {
+        const float4 a0 = gl_frag(ldsA, a_rowk, 0, S, i, q), a1 = gl_frag(ldsA, a_rowk, 1, S, i, q);
+        const float4 b0 = gl_frag(ldsB, b_rowk, 0, S, i, q), b1 = gl_frag(ldsB, b_rowk, 1, S, i, q);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv0[c], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv1[c], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv0[c], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv1[c], c11, 0, 0, 0);
+            as0 += av0[c];
+            as1 += av1[c];
+        }
+    }
+}
+
 // ADAM = true (single-rank weight-gradient launch of the slab engines): the epilogue applies the optimizer step to
 // the tile it just produced (gradient still written out for inspection), and workgroup 0 finishes the loss log --
 // one launch and one cold pass over p/m/v less per update.  Data-parallel runs use ADAM = false + k_adam_frag so the
@@ -87,9 +131,16 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
 #pragma unroll
     for (int i = 1; i < MAX_PROBS; ++i)
         if (i < grp.n && (int)blockIdx.x >= grp.p[i].tile0) pi = i;
+    const bool placed = grp.xcd && blockIdx.x < 256;   // Launch::place_on_xcds
+    if (placed) pi = (blockIdx.x & 7) >> 1;
     const GemmProb &p = grp.p[pi];
     const int t = blockIdx.x - p.tile0;
-    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    if (placed) {   // XCD x = blockIdx & 7: problem x / 2, row-panel half x % 2, all 8 column panels
+        const int slot = blockIdx.x >> 3;
+        tm = (blockIdx.x & 1) * 4 + (slot >> 3);
+        tn = slot & 7;
+    }
     const int m0 = tm * 32, n0 = tn * 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
@@ -122,6 +173,32 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
     float as0 = 0.f, as1 = 0.f;
     const float *Abase = p.A + (long long)m0 * p.a_si;
     const float *Bbase = p.B + (long long)n0 * p.b_sj;
+    if (grp.pipe && !a_rowk && !b_rowk && p.K > GL_KC) {
+        // Weight gradients of a large minibatch (reduction = batch rows > 256): 128-row half chunks, double buffered --
+        // the LDS-DMA of chunk c+1 is in flight while chunk c feeds the MFMAs, one barrier per chunk instead of
+        // stage -> barrier -> products -> barrier.  Wave w still owns the 16-row blocks w, w+8, w+16, ... of the
+        // reduction in increasing order: bit-identical to the single-buffer loop.  (A ring of four 64-row stages with
+        // three chunks in flight measured the same: beyond 256 rows the kernel moves ~6.5 TB/s out of the L2s either
+        // way, 74.0 vs 72.8 us/update at batch 1024.)
+        constexpr int KH = GL_KC / 2, IMG = KH * 32;   // 4 images of 16 KB in the 72 KB
+        gl_stage_kmajor_async(lds, Abase, p.a_sk, vm, KH);
+        gl_stage_kmajor_async(lds + IMG, Bbase, p.b_sk, vn, KH);
+        int c = 0;
+        for (int k0 = 0; k0 < p.K; k0 += KH, ++c) {
+            const int kc = (p.K - k0) < KH ? (p.K - k0) : KH;
+            const int k1 = k0 + KH, kn = (p.K - k1) < KH ? (p.K - k1) : KH;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // chunk c has landed (every wave's transfers); chunk c-1's buffer is free again
+            const float *cur = lds + (c & 1) * 2 * IMG;
+            float *nxt = lds + ((c + 1) & 1) * 2 * IMG;
+            if (kn > 0) {
+                gl_stage_kmajor_async(nxt, Abase + (long long)k1 * p.a_sk, p.a_sk, vm, kn);
+                gl_stage_kmajor_async(nxt + IMG, Bbase + (long long)k1 * p.b_sk, p.b_sk, vn, kn);
+            }
+            gl_products(cur, cur + IMG, false, false, kc, wave, i, q, c00, c01, c10, c11, as0, as1);
+        }
+        GL_STAMP(1);
+    } else
     for (int k0 = 0; k0 < p.K; k0 += GL_KC) {
         const int kc = (p.K - k0) < GL_KC ? (p.K - k0) : GL_KC;
         if (k0 > 0) __syncthreads();  // previous chunk fully consumed
@@ -129,22 +206,7 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         gl_stage(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
         __syncthreads();
         GL_STAMP(1);
-        const int nS = kc >> 4;
-        for (int S = wave; S < nS; S += GL_WAVES) {
-            const float4 a0 = gl_frag(ldsA, a_rowk, 0, S, i, q), a1 = gl_frag(ldsA, a_rowk, 1, S, i, q);
-            const float4 b0 = gl_frag(ldsB, b_rowk, 0, S, i, q), b1 = gl_frag(ldsB, b_rowk, 1, S, i, q);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv0[c], c00, 0, 0, 0);
-                c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv1[c], c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv0[c], c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv1[c], c11, 0, 0, 0);
-                as0 += av0[c];
-                as1 += av1[c];
-            }
-        }
+        gl_products(ldsA, ldsB, a_rowk, b_rowk, kc, wave, i, q, c00, c01, c10, c11, as0, as1);
     }
     GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles

@@ -280,18 +280,20 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
 
-@pytest.mark.parametrize("switch", ["RLARM_AHEAD=0", "RLARM_FUSE_ADAM=0"])
-def test_engine_variants_are_bit_identical(switch, monkeypatch):
-    """The default slab8 path (next minibatch gathered one launch ahead, Adam in the weight-gradient epilogue) against
-    the same engine with one of those turned off: same arithmetic, same summation
-    order, same RNG stream -> identical bits after 3 cycles."""
+@pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
+                                          ("RLARM_GEMM_PIPE=0", 1024), ("RLARM_GEMM_PIPE=0", 449), ("RLARM_GEMM_PIPE=0", 1536),
+                                          ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024)])
+def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
+    """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
+    epilogue, a ring of reduction chunks in the weight-gradient GEMM beyond 256 rows, its big problems placed on XCD
+    pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
     torch.manual_seed(0)
-    ref_agent, _ = make_agent(batch=256, n_eps=32, seed=21)
+    ref_agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     want = _run_cycles(ref_agent, graph=True)
     k, v = switch.split("=")
-    monkeypatch.setenv(k, v)          # read by hp_agent_create
+    monkeypatch.setenv(k, v)          # read by hp_agent_create / at launch
     torch.manual_seed(0)
-    agent, _ = make_agent(batch=256, n_eps=32, seed=21)
+    agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     got = _run_cycles(agent, graph=True)
     for a, b in zip(want, got):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))

@@ -26,7 +26,7 @@ buf = DeviceEpisodeBuffer(5000, 100, 27, 3, 4, ctx=ctx)
 buf.store(rng, make_episodes(5000, seed=1))
 floor("after 150MB buffer + store")
 on, gn = normalizer(27, default_clip_range=5, ctx=ctx), normalizer(3, default_clip_range=5, ctx=ctx)
-cfg = _lib.AgentCfg(obs_dim=27, goal_dim=3, act_dim=4, hidden=256, batch=256, grad_world_size=1, max_action=0.5, gamma=0.98,
+cfg = _lib.AgentCfg(obs_dim=27, goal_dim=3, act_dim=4, hidden=256, batch=int(os.environ.get("BATCH", "256")), grad_world_size=1, max_action=0.5, gamma=0.98,
                     action_l2=1.0, lr_actor=1e-3, lr_critic=1e-3, polyak=0.95, clip_obs=200.0, clip_range=5.0,
                     adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
 h = C.c_void_p(); _lib.check(lib.hp_agent_create(ctx.h, C.byref(cfg), C.byref(h)))

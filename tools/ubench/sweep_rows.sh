@@ -1,6 +1,6 @@
 #!/bin/bash
-# ms/step of bench.py for a few batch sizes with 4- and 8-row slabs (picks the height threshold in agent.hip)
-for b in 384 512 768; do for r in 4 8; do
-  v=$(RLARM_SLAB_ROWS=$r python bench.py --batch $b --steps 2000 --warmup 200 --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
-  echo "batch $b rows $r: $v"
-done; done
+# us/step of the cycle graph for batch x slab height x gather-ahead (picks the thresholds in agent.hip)
+for b in ${BATCHES:-512 768 1024 1280 1536 2048}; do for r in ${ROWS:-8 16}; do for a in ${AHEADS:-1 0}; do
+  v=$(BATCH=$b RLARM_SLAB_ROWS=$r RLARM_AHEAD=$a python tools/ubench/notorch_cycle.py 2>&1 | grep "n_batches=40")
+  echo "batch $b rows $r ahead $a: $v"
+done; done; done
