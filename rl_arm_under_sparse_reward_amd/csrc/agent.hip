@@ -1036,6 +1036,12 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         ProfScope ps(a, PROF_GEMM_FWD);
         P.n_plan = ride ? 1 : 0;
         P.n_ahead = 0;
+        {
+            const char *xs8 = getenv("RLARM_FB_XCD");
+            // measured (us/update, split vs not): 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256, 46.6 vs 46.6 at 384,
+            // 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
+            P.xcd_split = (nslab % 4 == 0) && (xs8 ? xs8[0] != '0' : 4 * nslab <= a->ctx->cu_count);
+        }
         P.ahead = P.f.gs;
         P.aXT = P.aXA = P.aXP = nullptr;
         if (gc && gc->ahead_plan) {   // next update's inputs into the other set

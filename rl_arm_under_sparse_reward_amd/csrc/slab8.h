@@ -73,6 +73,7 @@ struct FbSlabArgs {
     // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
     // (plan record -> replay-buffer rows).  The plan they read was finished by an EARLIER launch: no in-kernel handshake.
     int n_plan, n_ahead;
+    int xcd_split;   // chain = XCD half (needs nslab % 4 == 0)
     GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
     float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
 };
@@ -562,7 +563,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ s8_mask_t msk[5][256];       // ReLU masks: critic h1, h2 | actor h1, h2, h3
     __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
     const int nslab = A.Mp / S8_ROWS;
-    const int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
+    int chain = blockIdx.x / nslab, slab = blockIdx.x - chain * nslab;
+    if (P.xcd_split && (int)blockIdx.x < 2 * nslab) {
+        // workgroups are dealt round-robin to the 8 XCDs: critic-side chains on XCDs 0-3, actor-side chains on 4-7, so
+        // that an XCD's L2 pulls 4 of the 6 weight-fragment sets through the fabric instead of all of them
+        const int x = blockIdx.x & 7;
+        chain = x >> 2;
+        slab = (blockIdx.x >> 3) * 4 + (x & 3);
+    }
     const size_t row0 = (size_t)slab * S8_ROWS;
     const int tid = threadIdx.x, H = A.H;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
