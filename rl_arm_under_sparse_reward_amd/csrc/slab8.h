@@ -74,6 +74,7 @@ struct FbSlabArgs {
     // (plan record -> replay-buffer rows).  The plan they read was finished by an EARLIER launch: no in-kernel handshake.
     int n_plan, n_ahead;
     int xcd_split;   // chain = XCD half (needs nslab % 4 == 0)
+    int n_pref;      // L2-warmer workgroups (a multiple of 8: the same number on every XCD)
     GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
     float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
 };
@@ -589,8 +590,37 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (tid >= MT_THREADS) return;
             mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
                         reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
-        } else {
+        } else if (extra < P.n_plan + P.n_ahead) {
             s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, extra - P.n_plan, P.n_ahead);
+        } else {
+            // L2 warmer of this workgroup's XCD: touches the weight fragments the XCD's chains will stream, in the order
+            // they use them, one dword per 128-byte line, so that the chains find them in their L2 instead of behind the fabric
+            const int side = P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2;
+            const int na = A.la.total, nall = na + A.lc.total;
+            const float *r0 = side == 1 ? A.online.wf : A.target.wf;
+            const int n0 = nall;
+            const float *r1 = side == 1 ? A.online.wd + na : A.online.wf + (side == 0 ? na : 0);
+            const int n1 = side == 2 ? nall : A.lc.total;
+            const float *r2 = side == 1 ? A.online.wd : A.online.wd + (side == 0 ? na : 0);
+            const int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
+            const float *rs[3] = {r0, r1, r2};
+            const int ns[3] = {n0, n1, n2};
+            const int per = P.n_pref >> 3, mine = (extra - P.n_plan - P.n_ahead) >> 3;   // warmers per XCD, my index
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int step = per * S8_THREADS * 32;
+                int off = (mine * S8_THREADS + tid) * 32;
+                for (; off + 7 * step < ns[r]; off += 8 * step) {   // 8 lines in flight per lane
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = rs[r][off + u * step];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u];
+                }
+                for (; off < ns[r]; off += step) acc += rs[r][off];
+            }
+            if (acc == 1.2345678e-33f) dq[0] = acc;   // keeps the loads; never true in practice, harmless if it is
         }
         return;
     }

@@ -283,7 +283,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
 @pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
                                           ("RLARM_GEMM_PIPE=0", 1024), ("RLARM_GEMM_PIPE=0", 449), ("RLARM_GEMM_PIPE=0", 1536),
                                           ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
-                                          ("RLARM_FB_XCD=1", 512)])
+                                          ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, a ring of reduction chunks in the weight-gradient GEMM beyond 256 rows, its big problems placed on XCD
