@@ -42,7 +42,20 @@ def update_agrees(p, ref, init, rel_l2, median_abs):
     assert rel <= rel_l2 and med <= median_abs, (rel, med)
 
 
-def test_one_update_on_identical_minibatch_golden():
+# the engines kept in the tree for A/B runs compute the same update with other tilings / launch structures: the
+# reference-generated golden holds for each of them
+ENGINES = ["", "RLARM_SLAB_ROWS=8", "RLARM_SLAB_ROWS=16", "RLARM_ENGINE=slab16", "RLARM_ENGINE=layers"]
+
+
+def _select_engine(switch, monkeypatch):
+    if switch:
+        k, v = switch.split("=")
+        monkeypatch.setenv(k, v)          # read by hp_agent_create
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_one_update_on_identical_minibatch_golden(engine, monkeypatch):
+    _select_engine(engine, monkeypatch)
     g = load_golden("ddpg_update.npz")
     agent, _ = make_agent()
     agent._set_flat(NET_ACTOR, g["init_actor"]); agent._set_flat(NET_CRITIC, g["init_critic"])
@@ -88,8 +101,10 @@ def _golden_pipeline(agent, rng, g):
     agent.o_norm.recompute_stats(); agent.g_norm.recompute_stats()
 
 
-def test_three_sampled_updates_from_seed_golden():
+@pytest.mark.parametrize("engine", ENGINES)
+def test_three_sampled_updates_from_seed_golden(engine, monkeypatch):
     """End to end from the numpy seed: store -> normalizer -> 3 x (sample + update) -> polyak."""
+    _select_engine(engine, monkeypatch)
     g = load_golden("ddpg_update.npz")
     agent, rng = make_agent()
     _golden_pipeline(agent, rng, g)
@@ -110,7 +125,8 @@ def test_three_sampled_updates_from_seed_golden():
     assert state_equal(rng, g["key"], g["pos"])            # sampler consumed exactly the reference's words
 
 
-@pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (1024, 4), (7, 4), (449, 4), (1281, 4)])   # 4-, 8-, 16-row slabs, ragged
+@pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (512, 8), (1024, 4), (7, 4), (449, 4), (1281, 4),
+                                     (2048, 4)])   # 4-, 8-, 16-row slabs, ragged sizes, the slab16 engine (> 1792)
 def test_updates_track_oracle_over_a_cycle(batch, k):
     """40 updates + polyak against the torch-CPU oracle fed the same (bit-identical) minibatches."""
     torch.set_num_threads(4)
