@@ -607,6 +607,19 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const int ns[3] = {n0, n1, n2};
             const int per = P.n_pref >> 3, mine = (extra - P.n_plan - P.n_ahead) >> 3;   // warmers per XCD, my index
             float acc = 0.f;
+            if (tid < 256) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
+                const int grp = tid >> 6, i = tid & 63;
+                const float *canon = (grp >> 1) ? A.online.canon : A.target.canon;
+                const NetLayout &l = (grp & 1) ? A.lc : A.la;
+                const float *net = canon + ((grp & 1) ? na : 0);
+                const int tail = (l.total - l.w4 + 31) >> 5;
+                int o = -1;
+                if (i < 8) o = l.b1 + 32 * i;
+                else if (i < 16) o = l.b2 + 32 * (i - 8);
+                else if (i < 24) o = l.b3 + 32 * (i - 16);
+                else if (i - 24 < tail) o = l.w4 + 32 * (i - 24);
+                if (o >= 0 && o < l.total) acc += net[o];
+            }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int step = per * S8_THREADS * 32;

@@ -1,3 +1,4 @@
-python tools/ubench/dp_path.py cycle 2>&1 | grep "dp path\|cycle mode"
-python tools/ubench/dp_path.py eager 2>&1 | grep "dp path\|cycle mode"
-RLARM_BENCH_FORCE_DP=1 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-profile 2>&1 | tail -1 | cut -c1-300
+for rep in 1 2 3; do
+  v=$(BATCH=256 python tools/ubench/notorch_cycle.py 2>&1 | grep "n_batches=40")
+  echo "batch 256: $v"
+done
