@@ -1562,6 +1562,42 @@ static int actor_rows(hp_agent *a, int32_t net, int64_t rows, size_t head_bytes,
     return HP_OK;
 }
 
+// slab engines: the whole policy call is one launch (k_policy_slab8).  `head` = float32 inputs (x != null) or the float64
+// observation rows followed by the goal rows.
+static int policy_rows_slab(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, int64_t rows, const void *host_a,
+                            size_t bytes_a, const void *host_b, size_t bytes_b, bool f32_inputs, double clip_obs,
+                            float *actions_host) {
+    hipStream_t s = a->ctx->stream;
+    const int ad = a->cfg.act_dim;
+    const size_t head = (bytes_a + bytes_b + 15) & ~(size_t)15;
+    HP_TRY(a->fwd_ws.ensure(head + (size_t)rows * ad * 4));
+    char *d = a->fwd_ws.as<char>();
+    float *d_act = reinterpret_cast<float *>(d + head);
+    HP_CHECK_HIP(hipMemcpyAsync(d, host_a, bytes_a, hipMemcpyHostToDevice, s));
+    if (bytes_b) HP_CHECK_HIP(hipMemcpyAsync(d + bytes_a, host_b, bytes_b, hipMemcpyHostToDevice, s));
+    PolicyArgs P;
+    memset(&P, 0, sizeof(P));
+    if (f32_inputs) {
+        P.x = reinterpret_cast<const float *>(d);
+        P.od = a->xdim; P.gd = 0;
+    } else {
+        P.obs = reinterpret_cast<const double *>(d);
+        P.g = reinterpret_cast<const double *>(d + bytes_a);
+        P.od = on->size; P.gd = gn->size;
+        P.onz = on->d; P.gnz = gn->d;
+        P.clip_obs = clip_obs; P.clip_o = on->clip; P.clip_g = gn->clip;
+    }
+    P.rows = (int)rows;
+    P.net = (net == HP_NET_ACTOR) ? SlabNetPtrs{a->fragF, a->fragD, a->params} : SlabNetPtrs{a->fragFT, nullptr, a->targets};
+    P.la = a->la; P.H = a->H; P.act_dim = ad; P.max_action = (float)a->cfg.max_action;
+    P.actions = d_act;
+    hipLaunchKernelGGL(s8r4::k_policy_slab8, dim3((unsigned)((rows + 3) / 4)), dim3(S8_THREADS), 0, s, P);
+    HP_CHECK_HIP(hipGetLastError());
+    HP_CHECK_HIP(hipMemcpyAsync(actions_host, d_act, (size_t)rows * ad * 4, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    return HP_OK;
+}
+
 extern "C" {
 
 int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_t rows, float *actions_host) {
@@ -1571,6 +1607,7 @@ int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_
     HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_actor_forward: rows out of range");
     const int xd = a->xdim, ldx = a->ldx;
     const size_t n_raw = (size_t)rows * xd;
+    if (a->slab8) return policy_rows_slab(a, nullptr, nullptr, net, rows, x_host, n_raw * 4, nullptr, 0, true, 0.0, actions_host);
     return actor_rows(a, net, rows, n_raw * 4, actions_host, [&](char *head, float *X, hipStream_t s) -> int {
         float *raw = reinterpret_cast<float *>(head);
         HP_CHECK_HIP(hipMemcpyAsync(raw, x_host, n_raw * 4, hipMemcpyHostToDevice, s));
@@ -1592,6 +1629,7 @@ int hp_agent_act(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, const doubl
                gd, a->xdim);
     const size_t nb_o = (size_t)rows * od * 8, nb_g = (size_t)rows * gd * 8;
     const double co = clip_obs > 0 ? clip_obs : INFINITY;
+    if (a->slab8) return policy_rows_slab(a, on, gn, net, rows, obs_host, nb_o, g_host, nb_g, false, co, actions_host);
     return actor_rows(a, net, rows, nb_o + nb_g, actions_host, [&](char *head, float *X, hipStream_t s) -> int {
         double *d_obs = reinterpret_cast<double *>(head), *d_g = reinterpret_cast<double *>(head + nb_o);
         HP_CHECK_HIP(hipMemcpyAsync(d_obs, obs_host, nb_o, hipMemcpyHostToDevice, s));

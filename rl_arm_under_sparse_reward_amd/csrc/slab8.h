@@ -79,6 +79,20 @@ struct FbSlabArgs {
     float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
 };
 
+// Rollout-side policy call (hp_agent_act / hp_agent_actor_forward): one 4-row slab per workgroup through the actor
+struct PolicyArgs {
+    const double *obs, *g;        // raw float64 rows (hp_agent_act) ...
+    const float *x;               // ... or already normalised float32 rows [rows][od + gd] (hp_agent_actor_forward)
+    int rows, od, gd;
+    const NormDev *onz, *gnz;
+    double clip_obs, clip_o, clip_g;
+    SlabNetPtrs net;              // forward fragments + canonical arena of the actor to evaluate
+    NetLayout la;
+    int H, act_dim;
+    float max_action;
+    float *actions;               // [rows][act_dim]
+};
+
 #endif  // RLARM_SLAB8_SHARED
 
 // ---- everything below is compiled once per slab height: S8_NRG row groups of 4 (S8_NRG = 1: 4-row slabs, the
@@ -889,5 +903,60 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     S8_TSTAMP(tl, 21);
 }
+
+#if S8_NRG == 1
+// actions = max_action * tanh(actor(normalise(obs | g)))  (ddpg_agent._preproc_inputs :163-171, models.py:19-26): the actor
+// half of the chain kernel above as its own launch -- same device functions, so the same bits as the training forward
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_policy_slab8(const PolicyArgs P) {
+    __shared__ __attribute__((aligned(16))) float xin[S8_ROWS * S8_LDX];
+    __shared__ __attribute__((aligned(16))) float bufA[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float bufB[S8_ROWS * S8_LD];
+    __shared__ __attribute__((aligned(16))) float pbuf[S8_ROWS * 256];
+    __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t row0 = (size_t)blockIdx.x * S8_ROWS;
+    const NetLayout &la = P.la;
+    const int ad = P.act_dim, H = P.H, w = P.od + P.gd;
+    RingSlot *ring = wring[wave];
+    int rbase = 0;
+    float4 wba[6], wh[4];
+    s8_small_prefetch(P.net.wf + la.w1, la.K1, wba);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        wh[j] = *reinterpret_cast<const float4 *>(P.net.canon + la.w4 + (j < ad ? j : ad - 1) * H + 4 * lane);
+    const float bh = P.net.canon[la.b4 + (lane < ad ? lane : 0)];
+    for (int idx = tid; idx < S8_ROWS * S8_LDX; idx += S8_THREADS) {
+        const int r = idx / S8_LDX, c = idx - r * S8_LDX;
+        const size_t m = row0 + r;
+        float v = 0.f;
+        if ((int)m < P.rows && c < w) {
+            if (P.x) {
+                v = P.x[m * w + c];
+            } else if (c < P.od) {
+                double t = fmin(fmax(P.obs[m * P.od + c], -P.clip_obs), P.clip_obs);
+                t = __ddiv_rn(__dsub_rn(t, (double)P.onz->mean[c]), P.onz->std[c]);
+                v = (float)fmin(fmax(t, -P.clip_o), P.clip_o);
+            } else {
+                const int j = c - P.od;
+                double t = fmin(fmax(P.g[m * P.gd + j], -P.clip_obs), P.clip_obs);
+                t = __ddiv_rn(__dsub_rn(t, (double)P.gnz->mean[j]), P.gnz->std[j]);
+                v = (float)fmin(fmax(t, -P.clip_g), P.clip_g);
+            }
+        }
+        xin[idx] = v;
+    }
+    s8_ring_prologue(ring, rbase, P.net.wf + la.w2);
+    s8_sync();
+    s8_trunk(xin, la, wba, P.net.wf, P.net.canon, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase, nullptr,
+             nullptr, 0);
+#pragma unroll
+    for (int i = 0; i < S8_RPW; ++i) {
+        const int rr = wave + S8_WAVES * i;
+        const float z = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, wh);
+        if (lane < ad && rr < S8_ROWS && (int)(row0 + rr) < P.rows)
+            P.actions[(row0 + rr) * ad + lane] = P.max_action * tanhf(z + bh);
+    }
+}
+#endif
 
 }  // namespace S8_NS

@@ -28,10 +28,13 @@ def primed(agent, seed=0):
     return rs
 
 
+@pytest.mark.parametrize("engine", ["", "RLARM_ENGINE=layers"])       # fused policy kernel | layer-per-launch fallback
 @pytest.mark.parametrize("rows", [1, 5, 64, 100])
-def test_act_equals_preproc_plus_actor_and_tracks_oracle(rows):
+def test_act_equals_preproc_plus_actor_and_tracks_oracle(rows, engine, monkeypatch):
     """hp_agent_act = _preproc_inputs (:163-171) + actor forward: bit-identical to the two-step device path, and within
     float32 rounding of the oracle's normalise + forward."""
+    if engine:
+        monkeypatch.setenv(*engine.split("="))
     torch.manual_seed(0)
     agent = make([])
     rs = primed(agent)
