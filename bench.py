@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--episodes", type=int, default=5000, help="episodes resident per GPU (buffer 5e5)")
     ap.add_argument("--replay-k", type=int, default=4)
+    ap.add_argument("--feeder-episodes", type=int, default=0,
+                    help="config 5 of BASELINE.json: a host feeder thread stores this many extra episodes per cycle while "
+                         "the cycles run (not part of the default bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -83,6 +86,27 @@ class Runner:
         self.pool = [make_episodes(ROLLOUTS_PER_CYCLE, seed=10_000 + 977 * rank + i) for i in range(16)]
         self.cycle = 0
         self.in_cycle = 0                    # steps done in the current cycle
+        self.feeder = None
+        if a.feeder_episodes > 0:
+            # host feeder: one batch of episodes per cycle from a second thread; the library's
+            # per-context lock orders its stores with the cycles on the stream
+            import threading
+            self.feed_pool = [make_episodes(a.feeder_episodes, seed=20_000 + 31 * rank + i) for i in range(4)]
+            self.feed_sem = threading.Semaphore(0)
+            self.feed_stop = False
+            self.fed = 0
+            self._releases = 0
+
+            def feed():
+                while True:
+                    self.feed_sem.acquire()
+                    if self.feed_stop:
+                        return
+                    self.agent.buffer.store_episode(self.feed_pool[self.fed % len(self.feed_pool)])
+                    self.fed += 1
+
+            self.feeder = threading.Thread(target=feed, daemon=True)
+            self.feeder.start()
         self.ctx.synchronize()
 
     def _open_cycle_eager(self):
@@ -94,6 +118,9 @@ class Runner:
         """Advance exactly k steps, including every cycle boundary crossed."""
         ag = self.agent
         while k > 0:
+            if self.in_cycle == 0 and self.feeder is not None:
+                self.feed_sem.release()      # one feeder batch per cycle, concurrent with it
+                self._releases += 1
             if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
                 self.cycle += 1
@@ -111,6 +138,10 @@ class Runner:
                 self.cycle += 1
 
     def sync(self):
+        if self.feeder is not None:          # the feeder's stores belong to the cycles that released them
+            import time
+            while self.fed < self._releases:
+                time.sleep(0.0002)
         self.ctx.synchronize()
         self.torch.cuda.synchronize()
 
@@ -274,6 +305,7 @@ def main():
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
                    "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
+                   **({"feeder_episodes_per_cycle": a.feeder_episodes} if a.feeder_episodes else {}),
                    "parallelism": f"dp{world}" + (
                        " (RCCL grad SUM all-reduce per update [reference semantics, utils.py:47] + normalizer MEAN per cycle, " +
                        ("issued by the library inside the cycle hipGraph)" if dp_native
