@@ -256,6 +256,10 @@ struct hp_agent {
     bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
     int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
+    // A/B switches, read once in hp_agent_create: RLARM_GEMM_PIPE, RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD,
+    // RLARM_FB_PREFETCH (-1 = by size, 0 = off, 1 = on)
+    bool gemm_pipe = true, gemm_xcd = true;
+    int fb_xcd = -1, fb_prefetch = -1;
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
@@ -681,8 +685,7 @@ struct Launch {  // builds one grouped launch
     int tiles = 0;
     Launch() {
         g.n = 0;
-        const char *e = getenv("RLARM_GEMM_PIPE");
-        g.pipe = !(e && e[0] == '0');
+        g.pipe = 1;   // the agent's switches are applied at launch (apply_switches)
         g.xcd = 0;
         g.pad_ = 0;
     }
@@ -691,8 +694,6 @@ struct Launch {  // builds one grouped launch
     // row-major tile order every XCD reads 9 of the 16 operand panels of every problem (6.75 x the unique bytes in
     // total); with one 256 x 256 problem per pair of XCDs (half of the row panels each) the fabric carries 1.5 x.
     void place_on_xcds() {
-        const char *e = getenv("RLARM_GEMM_XCD");
-        if (e && e[0] == '0') return;
         if (g.n < 4) return;
         for (int i = 0; i < 4; ++i)
             if (g.p[i].tiles_n != 8 || g.p[i].M != 256 || g.p[i].tile0 != 64 * i) return;
@@ -1036,29 +1037,13 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         ProfScope ps(a, PROF_GEMM_FWD);
         P.n_plan = ride ? 1 : 0;
         P.n_ahead = 0;
-        {
-            const char *xs8 = getenv("RLARM_FB_XCD");
-            // measured (us/update, split vs not): 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256, 46.6 vs 46.6 at 384,
-            // 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
-            P.xcd_split = (nslab % 4 == 0) && (xs8 ? xs8[0] != '0' : 4 * nslab <= a->ctx->cu_count);
-        }
-        P.ahead = P.f.gs;
-        P.aXT = P.aXA = P.aXP = nullptr;
-        if (gc && gc->ahead_plan) {   // next update's inputs into the other set
-            P.n_ahead = S8_AHEAD_WGS;
-            P.ahead.plan = gc->ahead_plan;
-            P.ahead.plan_any = gc->ahead_plan;
-            P.ahead.R = xs ? a->R : a->R2;
-            P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
-        }
-        {
-            // L2 warmers (k_fb_slab8): one spare workgroup per XCD while the launch still fits the CUs.  Measured
-            // (us/update, with vs without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs
-            // 54.2 at 512, 56.6 vs 57.1 at 768.  RLARM_FB_PREFETCH=0|1 forces it off / on.
-            const char *pf = getenv("RLARM_FB_PREFETCH");
-            const bool fits = 2 * nslab + P.n_plan + P.n_ahead + 8 <= a->ctx->cu_count;
-            P.n_pref = (pf ? pf[0] != '0' : fits) ? 8 : 0;
-        }
+        // chains split across XCD halves: measured (us/update, split vs not) 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256,
+        // 46.6 vs 46.6 at 384, 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
+        P.xcd_split = (nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count);
+        // L2 warmers: one spare workgroup per XCD while the launch still fits the CUs.  Measured (us/update, with vs
+        // without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs 54.2 at 512, 56.6 vs 57.1 at 768
+        P.n_pref = (a->fb_prefetch >= 0 ? a->fb_prefetch == 1
+                                        : 2 * nslab + P.n_plan + P.n_ahead + 8 <= a->ctx->cu_count) ? 8 : 0;
         const unsigned grid = 2 * nslab + P.n_plan + P.n_ahead + P.n_pref;
         if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
@@ -1091,7 +1076,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
         add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
         add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
-        L.place_on_xcds();
+        if (a->gemm_xcd) L.place_on_xcds();
+        L.g.pipe = a->gemm_pipe ? 1 : 0;
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
@@ -1341,6 +1327,11 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         }
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');
+        auto tri = [](const char *name) { const char *e = getenv(name); return e ? (e[0] != '0' ? 1 : 0) : -1; };
+        a->gemm_pipe = tri("RLARM_GEMM_PIPE") != 0;
+        a->gemm_xcd = tri("RLARM_GEMM_XCD") != 0;
+        a->fb_xcd = tri("RLARM_FB_XCD");
+        a->fb_prefetch = tri("RLARM_FB_PREFETCH");
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
         // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch

@@ -308,7 +308,7 @@ def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     ref_agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     want = _run_cycles(ref_agent, graph=True)
     k, v = switch.split("=")
-    monkeypatch.setenv(k, v)          # read by hp_agent_create / at launch
+    monkeypatch.setenv(k, v)          # read by hp_agent_create
     torch.manual_seed(0)
     agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     got = _run_cycles(agent, graph=True)
