@@ -1040,6 +1040,15 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         // chains split across XCD halves: measured (us/update, split vs not) 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256,
         // 46.6 vs 46.6 at 384, 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
         P.xcd_split = (nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count);
+        P.ahead = P.f.gs;
+        P.aXT = P.aXA = P.aXP = nullptr;
+        if (gc && gc->ahead_plan) {   // next update's inputs into the other set
+            P.n_ahead = S8_AHEAD_WGS;
+            P.ahead.plan = gc->ahead_plan;
+            P.ahead.plan_any = gc->ahead_plan;
+            P.ahead.R = xs ? a->R : a->R2;
+            P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
+        }
         // L2 warmers: one spare workgroup per XCD while the launch still fits the CUs.  Measured (us/update, with vs
         // without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs 54.2 at 512, 56.6 vs 57.1 at 768
         P.n_pref = (a->fb_prefetch >= 0 ? a->fb_prefetch == 1
