@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/pytest_gpu.log
+python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_full.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu_full.log > gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 python bench.py --steps 4000 --warmup 400 > gpurun_out/bench.log 2>&1
 tail -1 gpurun_out/bench.log > gpurun_out/bench.json
