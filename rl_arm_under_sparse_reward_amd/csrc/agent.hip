@@ -1316,7 +1316,10 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     {
         // RLARM_ENGINE = slab8 (default) | slab16 | layers: the alternatives stay for A/B runs and debugging
         const char *e = getenv("RLARM_ENGINE");
-        a->slab = !(e && strcmp(e, "layers") == 0) && a->H == 256;
+        // the slab engines are specialised: 256-wide hidden layers, network inputs of at most 48 columns (obs + goal +
+        // action, padded to 16) and at most 4 action components; any other shape takes the layer-per-launch engine
+        const bool slab_shape = a->H == 256 && a->ldx <= 48 && cfg->act_dim <= 4;
+        a->slab = !(e && strcmp(e, "layers") == 0) && slab_shape;
         // thin slabs (4x4x1 MFMA) up to batch 1792, 16-row slabs (16x16x4 MFMA, a quarter of the weight traffic per row)
         // beyond: measured 110.9 vs 117.2 us/update at batch 1536, 167.0 vs 135.5 at 2048, 318.8 vs 250.1 at 4096
         a->slab8 = a->slab && (e ? strcmp(e, "slab16") != 0 : a->B <= 1792);

@@ -409,3 +409,41 @@ def test_feeder_thread_stores_while_cycles_run():
     by_key = {key(e): e for e in want}
     assert all(np.array_equal(e, by_key[key(e)]) for e in stored)   # whole episodes intact (no torn staging)
     assert np.all(np.isfinite(agent.last_losses(6))) and np.all(np.isfinite(agent._get_flat(NET_CRITIC)))
+
+
+@pytest.mark.parametrize("obs_dim,goal_dim,act_dim,T", [(10, 3, 4, 50), (60, 3, 7, 20), (25, 2, 2, 100)])
+def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
+    """Other GoalEnv shapes than bmirobot's 27/3/4 ('so other GoalEnvs can plug in'): small ones run on the
+    slab engine, anything wider than 48 input columns or 4 actions on the layer-per-launch engine; same oracle, same bar."""
+    torch.set_num_threads(4)
+    env_params = {"obs": obs_dim, "goal": goal_dim, "action": act_dim, "action_max": 0.5, "max_timesteps": T}
+    n_eps, batch = 24, 256
+    rs0 = np.random.RandomState(4)
+    obs = rs0.uniform(-1, 1, (n_eps, T + 1, obs_dim))
+    obs[:, :, :goal_dim] = rs0.uniform(0, 0.5, (n_eps, 1, goal_dim)) + np.cumsum(rs0.normal(0, 0.012, (n_eps, T + 1, goal_dim)), 1)
+    eps = [obs, obs[:, :, :goal_dim].copy(), np.repeat(rs0.uniform(0, 0.5, (n_eps, 1, goal_dim)), T, 1),
+           rs0.uniform(-0.5, 0.5, (n_eps, T, act_dim))]
+    torch.manual_seed(0)
+    rng = fresh_rng(7)
+    agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * T), None, env_params, rng=rng)
+    a0 = {kk: v.detach().clone() for kk, v in agent.actor_network.state_dict().items()}
+    c0 = {kk: v.detach().clone() for kk, v in agent.critic_network.state_dict().items()}
+    learner = oupd.DDPGLearner(a0, c0)
+    rs = np.random.RandomState(7)
+    st = EpisodeStore(T, obs_dim, goal_dim, act_dim, n_eps * T)
+    fp = future_probability("future", 4)
+    on, gn = RunningNorm(obs_dim, default_clip_range=5), RunningNorm(goal_dim, default_clip_range=5)
+    st.store_episode(eps, rs)
+    agent.train_cycle(eps, n_batches=6)             # store + normalizer (on the staged episodes) + 6 updates + polyak
+    update_normalizers(on, gn, eps, fp, rs)
+    got = agent.last_losses(6)
+    for i in range(6):
+        tr, _ = st.sample(batch, fp, rs)
+        res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
+        assert abs(got[i, 0] - res["actor_loss"]) <= 1e-4 * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
+        assert abs(got[i, 1] - res["critic_loss"]) <= 1e-4 * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
+    assert state_equal(rng, *rs.get_state()[1:3])
+    assert np.array_equal(bits(agent.o_norm.mean), bits(on.mean)) and np.array_equal(bits(agent.g_norm.std), bits(gn.std))
+    x = np.random.RandomState(1).normal(size=(9, obs_dim + goal_dim)).astype(np.float32)
+    want = oupd.actor_forward({k: v.detach() for k, v in learner.actor.items()}, torch.from_numpy(x), 0.5).numpy()
+    assert np.allclose(agent.actor_network(x), want, rtol=1e-4, atol=2e-5)
