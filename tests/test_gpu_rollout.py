@@ -102,13 +102,15 @@ def test_learn_reaches_goals_on_the_point_mass(tmp_path):
     np.random.seed(0)
     torch.manual_seed(0)
     envs = [PointMassGoalEnv(seed=1 + i, max_timesteps=50) for i in range(2)]
-    args = Args(batch_size=256, buffer_size=400 * 50, n_epochs=10, n_cycles=10, n_test_rollouts=10, noise_eps=0.2,
+    args = Args(batch_size=256, buffer_size=400 * 50, n_epochs=14, n_cycles=10, n_test_rollouts=20, noise_eps=0.2,
                 save_dir=str(tmp_path), env_name="point_mass")
     agent = ddpg_agent(args, envs, envs[0].env_params, rng=fresh_rng(5))
     before = agent._eval_agent()
     agent.learn()
-    assert len(agent.success_rates) == 10
-    assert max(agent.success_rates[-3:]) >= 0.8 > before, (before, agent.success_rates)
-    assert agent.buffer.current_size == 10 * 10 * 2
+    assert len(agent.success_rates) == 14
+    # three seeds of this recipe (tools/ubench/learn_probe.py) are at >= 0.9 from epoch 8 on; the bar leaves room for
+    # the run-to-run differences any change of float32 summation order brings
+    assert max(agent.success_rates[-3:]) >= 0.8 and before <= 0.4, (before, agent.success_rates)
+    assert agent.buffer.current_size == 14 * 10 * 2
     saved = sorted(p.name for p in (tmp_path / "point_mass").iterdir())
-    assert len(saved) == 10 and all(name.endswith("_model.pt") for name in saved)
+    assert len(saved) == 14 and all(name.endswith("_model.pt") for name in saved)
