@@ -98,31 +98,29 @@ int buffer_launch_gather_dict(hp_buffer *b, const PlanRec *d_plan, int64_t batch
 int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
                            const double *actions, int64_t n_new) {
     hipStream_t s = b->ctx->stream;
-    HP_TRY(b->st_obs.ensure(n_new * b->ep_obs() * 8));
-    HP_TRY(b->st_ag.ensure(n_new * b->ep_ag() * 8));
-    HP_TRY(b->st_g.ensure(n_new * b->ep_g() * 8));
-    HP_TRY(b->st_act.ensure(n_new * b->ep_act() * 8));
     HP_TRY(b->st_slots.ensure(n_new * 8));
     // copy-in semantics (replay_buffer.py:39-42): the caller's arrays are read by the CPU memcpy
     // below and never again; the DMA reads our pinned staging.
     const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
                  n3 = n_new * b->ep_act() * 8;
+    HP_TRY(b->st_obs.ensure(n0 + n1 + n2 + n3));
+    char *dst = b->st_obs.as<char>();
+    b->st_ag = reinterpret_cast<double *>(dst + n0);
+    b->st_g = reinterpret_cast<double *>(dst + n0 + n1);
+    b->st_act = reinterpret_cast<double *>(dst + n0 + n1 + n2);
     HP_TRY(b->pin.ensure(n0 + n1 + n2 + n3));
     char *h = static_cast<char *>(b->pin.p);
     memcpy(h, obs, n0);
     memcpy(h + n0, ag, n1);
     memcpy(h + n0 + n1, g, n2);
     memcpy(h + n0 + n1 + n2, actions, n3);
-    HP_CHECK_HIP(hipMemcpyAsync(b->st_obs.p, h, n0, hipMemcpyHostToDevice, s));
-    HP_CHECK_HIP(hipMemcpyAsync(b->st_ag.p, h + n0, n1, hipMemcpyHostToDevice, s));
-    HP_CHECK_HIP(hipMemcpyAsync(b->st_g.p, h + n0 + n1, n2, hipMemcpyHostToDevice, s));
-    HP_CHECK_HIP(hipMemcpyAsync(b->st_act.p, h + n0 + n1 + n2, n3, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(dst, h, n0 + n1 + n2 + n3, hipMemcpyHostToDevice, s));
     HP_TRY(b->pin.mark(s));
     b->staged_n = n_new;
     HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
     hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)n_new), dim3(256), 0, s, b->st_slots.as<long long>(),
-                       (long long)n_new, b->st_obs.as<double>(), b->st_ag.as<double>(), b->st_g.as<double>(),
-                       b->st_act.as<double>(), b->d_obs, b->d_ag, b->d_g, b->d_act, (long long)b->ep_obs(),
+                       (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g,
+                       b->st_act, b->d_obs, b->d_ag, b->d_g, b->d_act, (long long)b->ep_obs(),
                        (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
     HP_CHECK_HIP(hipGetLastError());
     // host mirror of replay_buffer.py:68 and :43
@@ -303,9 +301,6 @@ void hp_buffer_destroy(hp_buffer *b) {
     if (b->d_act) (void)hipFree(b->d_act);
     if (b->d_meta) (void)hipFree(b->d_meta);
     b->st_obs.release();
-    b->st_ag.release();
-    b->st_g.release();
-    b->st_act.release();
     b->st_slots.release();
     b->pin.release();
     b->plan.release();

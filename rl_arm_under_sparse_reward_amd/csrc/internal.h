@@ -152,7 +152,9 @@ struct hp_buffer {
     // host mirror (slot policy is deterministic given n_new, so the host can track it)
     int64_t current_size = 0, n_transitions_stored = 0;
     // staging of the most recent store_episode batch (also the source of _update_normalizer)
-    DevBuf st_obs, st_ag, st_g, st_act, st_slots;
+    // one allocation (st_obs) holds obs | ag | g | actions of the staged batch, so the upload is ONE copy
+    DevBuf st_obs, st_slots;
+    double *st_ag = nullptr, *st_g = nullptr, *st_act = nullptr;
     PinnedBuf pin;
     int64_t staged_n = 0;
     // sampling scratch

@@ -200,7 +200,7 @@ __global__ void k_norm_set(NormDev *nz, const float *mean, const double *std, in
 int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,
                                  double clip_obs, bool recompute) {
     hipLaunchKernelGGL(k_norm_update_from_plan, dim3(1), dim3(128), 0, o->ctx->stream, o->d, g->d, d_plan,
-                       (long long)rows, b->st_obs.as<double>(), b->st_ag.as<double>(), b->st_g.as<double>(), (int)b->T,
+                       (long long)rows, b->st_obs.as<double>(), b->st_ag, b->st_g, (int)b->T,
                        (int)b->obs_dim, (int)b->goal_dim, clip_obs, recompute ? 1 : 0, o->eps * o->eps, o->std_f32,
                        g->eps * g->eps, g->std_f32);
     HP_CHECK_HIP(hipGetLastError());
