@@ -58,20 +58,25 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
 
 // scatter the staged episodes into their slots.  numpy's `buffers[idxs] = mb` lets the LAST
 // occurrence of a repeated slot win, so an episode is dropped when a later one has its slot.
+#define STORE_PARTS 8
 __global__ __launch_bounds__(256) void k_store_scatter(const long long *__restrict__ slots, long long n_new,
                                                        const double *s_obs, const double *s_ag, const double *s_g,
                                                        const double *s_act, double *obs, double *ag, double *g,
                                                        double *act, long long ep_obs, long long ep_ag,
                                                        long long ep_g, long long ep_act) {
-    const long long i = blockIdx.x;
+    // STORE_PARTS workgroups per episode, each a strided share of its values: one or two copies per thread instead of a
+    // loop of fifteen dependent-latency iterations (the copy of 2 episodes was 9.6 us of every cycle)
+    const long long i = blockIdx.x / STORE_PARTS;
+    const int part = blockIdx.x % STORE_PARTS;
     const long long slot = slots[i];
     int dup = 0;
     for (long long j = i + 1 + threadIdx.x; j < n_new; j += blockDim.x) dup |= (slots[j] == slot);
     if (__syncthreads_or(dup)) return;
-    for (long long k = threadIdx.x; k < ep_obs; k += blockDim.x) obs[slot * ep_obs + k] = s_obs[i * ep_obs + k];
-    for (long long k = threadIdx.x; k < ep_ag; k += blockDim.x) ag[slot * ep_ag + k] = s_ag[i * ep_ag + k];
-    for (long long k = threadIdx.x; k < ep_g; k += blockDim.x) g[slot * ep_g + k] = s_g[i * ep_g + k];
-    for (long long k = threadIdx.x; k < ep_act; k += blockDim.x) act[slot * ep_act + k] = s_act[i * ep_act + k];
+    const long long t0 = (long long)part * blockDim.x + threadIdx.x, step = (long long)STORE_PARTS * blockDim.x;
+    for (long long k = t0; k < ep_obs; k += step) obs[slot * ep_obs + k] = s_obs[i * ep_obs + k];
+    for (long long k = t0; k < ep_ag; k += step) ag[slot * ep_ag + k] = s_ag[i * ep_ag + k];
+    for (long long k = t0; k < ep_g; k += step) g[slot * ep_g + k] = s_g[i * ep_g + k];
+    for (long long k = t0; k < ep_act; k += step) act[slot * ep_act + k] = s_act[i * ep_act + k];
 }
 
 // ------------------------------------------------------------------------------ launchers
@@ -118,7 +123,7 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
     HP_TRY(b->pin.mark(s));
     b->staged_n = n_new;
     HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
-    hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)n_new), dim3(256), 0, s, b->st_slots.as<long long>(),
+    hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)(n_new * STORE_PARTS)), dim3(256), 0, s, b->st_slots.as<long long>(),
                        (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g,
                        b->st_act, b->d_obs, b->d_ag, b->d_g, b->d_act, (long long)b->ep_obs(),
                        (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
