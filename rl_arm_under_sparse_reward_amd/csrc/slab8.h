@@ -27,7 +27,9 @@
 #define S8_WAVES 8
 #define S8_LD 260
 #define S8_LDX 52
-#define S8_AHEAD_WGS 4   // spare workgroups that gather the next update's inputs
+#ifndef S8_AHEAD_WGS
+#define S8_AHEAD_WGS 4   // spare workgroups that gather the next update's inputs (2 and 8 measured the same or slower)
+#endif
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
 #define S8_TSTAMP(tl, k) do { if ((tl) && threadIdx.x == 0) (tl)[k] = wall_clock64(); } while (0)
@@ -101,7 +103,10 @@ struct PolicyArgs {
 #undef S8_ROWS
 #define S8_ROWS (4 * S8_NRG)
 #undef S8_RING
-#define S8_RING (S8_NRG >= 4 ? 10 : 12)   // 16-row slabs need the LDS for their activation buffers
+#ifndef S8_RING1
+#define S8_RING1 12   // ring depth of the 4-row build (-DS8_RING1=14|16 for experiments)
+#endif
+#define S8_RING (S8_NRG >= 4 ? 10 : (S8_NRG == 1 ? S8_RING1 : 12))   // 16-row slabs need the LDS for their activation buffers
 #undef S8_RPW
 #define S8_RPW ((S8_ROWS + S8_WAVES - 1) / S8_WAVES)   // rows per wavefront in the one-wavefront-per-row stages
 namespace S8_NS {
