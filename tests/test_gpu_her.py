@@ -171,3 +171,36 @@ def test_dense_reward_matches_compute_reward_bitwise():
     assert tr["r"].dtype == np.float64 and tr["r"].shape == (512, 1)
     assert np.array_equal(tr["r"].view(np.uint64), want.view(np.uint64))
     assert (tr["r"] <= 0).all() and (tr["r"] < 0).any()
+
+
+def _random_shapes():
+    rs = np.random.RandomState(2024)
+    cases = [(1, 1, 1, 3, 1, 1, 4), (1, 2, 7, 5, 2, 3, 0), (3, 1, 64, 9, 3, 4, 8)]      # degenerate N / T / B, no relabelling
+    for _ in range(9):
+        cases.append((int(rs.randint(1, 40)), int(rs.randint(1, 60)), int(rs.randint(1, 700)), int(rs.randint(1, 65)),
+                      int(rs.randint(1, 8)), int(rs.randint(1, 9)), int(rs.choice([0, 1, 4, 8, 100]))))
+    return cases
+
+
+@pytest.mark.parametrize("n,T,B,od,gd,ad,k", _random_shapes())
+def test_sampler_matches_oracle_on_random_shapes(n, T, B, od, gd, ad, k):
+    """Seeded sweep over buffer / episode / batch / row shapes, incl. one episode, one timestep, one transition, no
+    relabelling (k = 0) and almost-always relabelling (k = 100): whole sample dict, indices and RNG position bit for bit."""
+    rs0 = np.random.RandomState(n * 1000 + T)
+    eps = [rs0.normal(size=(n, T + 1, od)), rs0.normal(0, 0.05, size=(n, T + 1, gd)), rs0.normal(0, 0.05, size=(n, T, gd)),
+           rs0.uniform(-1, 1, size=(n, T, ad))]
+    fp = future_probability("future", k) if k else 0.0
+    st = EpisodeStore(T, od, gd, ad, n * T)
+    rs = np.random.RandomState(77)
+    st.store_episode(eps, rs)
+    dev = fresh_rng(77)
+    buf = DeviceEpisodeBuffer(n, T, od, gd, ad)
+    buf.store(dev, eps)
+    for _ in range(2):
+        ref, ridx = st.sample(B, fp, rs)
+        tr, idx = buf.sample(dev, B, fp, squared_threshold(0.05), with_indices=True)
+        for key in KEYS:
+            assert tr[key].shape == ref[key].shape and np.array_equal(bits(tr[key]), bits(ref[key])), key
+        for key in ("e", "t", "future_t", "her"):
+            assert np.array_equal(idx[key], ridx[key]), key
+    assert state_equal(dev, *rs.get_state()[1:3])
