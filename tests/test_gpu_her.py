@@ -204,3 +204,31 @@ def test_sampler_matches_oracle_on_random_shapes(n, T, B, od, gd, ad, k):
         for key in ("e", "t", "future_t", "her"):
             assert np.array_equal(idx[key], ridx[key]), key
     assert state_equal(dev, *rs.get_state()[1:3])
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_storage_policy_matches_oracle_on_random_store_sequences(case):
+    """_get_storage_idx (replay_buffer.py:57-71) through all three branches -- append, tail + random overflow, all random
+    (incl. batches larger than the buffer and repeated slots) -- on random buffer sizes and store sequences: buffer
+    contents, counters and the position of the shared random stream after every store."""
+    rs0 = np.random.RandomState(900 + case)
+    size = int(rs0.randint(1, 24))
+    T, od, gd, ad = int(rs0.randint(1, 6)), int(rs0.randint(1, 5)), int(rs0.randint(1, 4)), int(rs0.randint(1, 4))
+    dev, rs = fresh_rng(31 + case), np.random.RandomState(31 + case)
+    buf = DeviceEpisodeBuffer(size, T, od, gd, ad)
+    st = EpisodeStore(T, od, gd, ad, size * T)
+    first = True
+    for _ in range(int(rs0.randint(3, 12))):
+        inc = int(rs0.randint(1, 2 * size + 2))
+        if first and inc > size:
+            inc = size                  # an empty buffer cannot take more than it holds (randint(0, 0) raises in both)
+        first = False
+        eps = [rs0.normal(size=(inc, T + 1, od)), rs0.normal(size=(inc, T + 1, gd)), rs0.normal(size=(inc, T, gd)),
+               rs0.normal(size=(inc, T, ad))]
+        buf.store(dev, eps)
+        st.store_episode(eps, rs)
+        assert buf.info()[1] == st.current_size and buf.info()[2] == st.n_transitions_stored
+        assert state_equal(dev, *rs.get_state()[1:3])
+        cur = st.current_size
+        for key in ("obs", "ag", "g", "actions"):
+            assert np.array_equal(buf.read(key, 0, cur), st.buffers[key][:cur]), key
