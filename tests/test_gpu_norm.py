@@ -117,3 +117,27 @@ def test_set_stats_roundtrip():
     nz.set_stats(np.array([1, 2, 3], np.float32), np.array([0.5, 2.0, 4.0]))
     assert np.array_equal(nz.mean, [1, 2, 3]) and np.array_equal(nz.std, [0.5, 2.0, 4.0])
     assert np.array_equal(nz.normalize(np.array([[2.0, 2.0, 43.0]])), [[2.0, 0.0, 5.0]])
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_normalizer_matches_oracle_on_random_sequences(case):
+    """Random widths (1..64), random update / recompute_stats sequences with batches of 1..300 rows at very different
+    scales, both `std` dtypes: accumulators, mean and std bit for bit, and normalize() -- with and without clipping --
+    on fresh inputs after every recompute."""
+    rs = np.random.RandomState(4000 + case)
+    size = int(rs.randint(1, 65))
+    f32 = bool(case & 1)
+    clip = [np.inf, 5.0, 0.5][case % 3]
+    dev = normalizer(size, default_clip_range=clip, std_dtype=np.float32 if f32 else np.float64)
+    ref = RunningNorm(size, default_clip_range=clip, std_dtype=np.float32 if f32 else np.float64)
+    for step in range(int(rs.randint(4, 14))):
+        v = rs.normal(rs.uniform(-3, 3), 10.0 ** rs.uniform(-3, 2.5), size=(int(rs.randint(1, 301)), size))
+        dev.update(v); ref.update(v)
+        if rs.rand() < 0.5:
+            dev.recompute_stats(); ref.recompute_stats()
+            for name in NAMES:
+                assert np.array_equal(bits(np.asarray(getattr(dev, name))), bits(np.asarray(getattr(ref, name)))), (step, name)
+            x = rs.normal(0, 50.0, size=(int(rs.randint(1, 40)), size))
+            assert np.array_equal(bits(dev.normalize(x)), bits(ref.normalize(x))), step
+            assert np.array_equal(bits(dev.normalize(x, 1.5)), bits(ref.normalize(x, 1.5))), step
+            assert np.array_equal(bits(dev.normalize(x[0])), bits(ref.normalize(x[0]))), step
