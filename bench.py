@@ -263,6 +263,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     r = Runner(a, rank, world, force_dp)
+    # one-time initialisation, not warm-up: the first full cycle captures and instantiates the cycle hipGraph (and, at
+    # N > 1, sets up the RCCL channels); without it a short --warmup would leave that inside the timed region
+    r.run_steps(N_BATCHES)
+    r.sync()
     r.run_steps(a.warmup)
     r.sync()
     barrier(world)
@@ -301,6 +305,7 @@ def main():
         "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "init": "one untimed training cycle before the warm-up steps (hipGraph capture / RCCL channel set-up)",
         "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
