@@ -199,6 +199,10 @@ int hp_agent_get_losses(hp_agent *ag, float *out_host, int32_t n_last);
 int hp_agent_soft_update(hp_agent *ag);
 /* actor forward on host inputs (rollout side, ddpg_agent.py:114-116): x [rows, obs+goal] -> actions [rows, act] */
 int hp_agent_actor_forward(hp_agent *ag, int32_t net, const float *x_host, int64_t rows, float *actions_host);
+/* critic forward on host inputs (models.py:28-44: the critic scales the actions by 1/max_action itself):
+ * x [rows, obs+goal] float32 (normalised), actions [rows, act] float32 -> q [rows] */
+int hp_agent_critic_forward(hp_agent *ag, int32_t net, const float *x_host, const float *actions_host, int64_t rows,
+                            float *q_host);
 /* rollout side in one call (ddpg_agent._preproc_inputs :163-171 + actor, :114-116 / :288-292): float64 observation
  * and goal rows -> normalise with the two normalizers (clip at each normalizer's default_clip_range), float32, actor
  * forward -> actions [rows, act].  clip_obs > 0 additionally clips the raw values first (_preproc_og); the reference's

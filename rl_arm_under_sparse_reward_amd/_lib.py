@@ -90,6 +90,7 @@ PROTOTYPES = {
     "hp_agent_get_losses": (C.c_int, [C.c_void_p, f32p, C.c_int32]),
     "hp_agent_soft_update": (C.c_int, [C.c_void_p]),
     "hp_agent_actor_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64, f32p]),
+    "hp_agent_critic_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int64, f32p]),
     "hp_agent_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, f64p, f64p, C.c_int64, C.c_double, f32p]),
     "hp_agent_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_double]),

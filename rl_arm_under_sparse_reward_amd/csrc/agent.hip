@@ -649,6 +649,15 @@ __global__ void k_policy_inputs(const double *__restrict__ obs, const double *__
     X[(long long)r * ld + c] = (float)v;
 }
 
+// critic input: action block = actions / max_action (models.py:38)
+__global__ void k_pack_scaled_actions(const float *__restrict__ src, int rows, int act_dim, float *dst, int ld, int act_off,
+                                      float max_action) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * act_dim) return;
+    const int r = idx / act_dim, c = idx - r * act_dim;
+    dst[(long long)r * ld + act_off + c] = src[idx] / max_action;
+}
+
 __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, int act_off, int act_dim,
                                  float max_action, float *out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1565,6 +1574,44 @@ static int actor_rows(hp_agent *a, int32_t net, int64_t rows, size_t head_bytes,
     return HP_OK;
 }
 
+// stand-alone critic rows (models.py:28-44): Q(x, a) for host inputs, on the layer-per-launch GEMMs
+static int critic_rows(hp_agent *a, int32_t net, int64_t rows, const float *x_host, const float *act_host, float *q_host) {
+    const int H = a->H, ldx = a->ldx, xd = a->xdim, ad = a->cfg.act_dim;
+    const int Mp = roundup((int)rows, 32);
+    hipStream_t s = a->ctx->stream;
+    const size_t n_x = (size_t)rows * xd, n_a = (size_t)rows * ad, nX = (size_t)Mp * ldx, nH = (size_t)Mp * H,
+                 nT = (size_t)Mp * 16;
+    const size_t head = ((n_x + n_a) * 4 + 15) & ~(size_t)15;
+    HP_TRY(a->fwd_ws.ensure(head + (nX + 3 * nH + nT + (size_t)rows) * 4));
+    char *base = a->fwd_ws.as<char>();
+    float *raw_x = reinterpret_cast<float *>(base), *raw_a = raw_x + n_x;
+    float *X = reinterpret_cast<float *>(base + head), *h1 = X + nX, *h2 = h1 + nH, *h3 = h2 + nH, *q16 = h3 + nH,
+          *outp = q16 + nT;
+    HP_CHECK_HIP(hipMemsetAsync(X, 0, nX * 4, s));
+    HP_CHECK_HIP(hipMemcpyAsync(raw_x, x_host, n_x * 4, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(raw_a, act_host, n_a * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n_x + 255) / 256)), dim3(256), 0, s, raw_x, (int)rows, xd, X, ldx, 0);
+    hipLaunchKernelGGL(k_pack_scaled_actions, dim3((unsigned)((n_a + 255) / 256)), dim3(256), 0, s, raw_a, (int)rows, ad, X,
+                       ldx, a->act_off, (float)a->cfg.max_action);
+    HP_CHECK_HIP(hipGetLastError());
+    const NetLayout &l = a->lc;
+    const float *P = ((net == HP_NET_CRITIC) ? a->params : a->targets) + a->la.total;
+    { Launch L; add_fwd(L, X, ldx, l.K1, P + l.w1, P + l.b1, h1, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    { Launch L; add_fwd(L, h1, H, H, P + l.w2, P + l.b2, h2, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    { Launch L; add_fwd(L, h2, H, H, P + l.w3, P + l.b3, h3, H, Mp, H, EPI_BIAS_RELU); HP_TRY(launch_group(a, L, PROF_GEMM_FWD)); }
+    {
+        Launch L;
+        add_fwd(L, h3, H, H, P + l.w4, P + l.b4, q16, 16, Mp, 16, EPI_BIAS);
+        L.g.p[0].n_store = 1;
+        HP_TRY(launch_group(a, L, PROF_GEMM_FWD));
+    }
+    hipLaunchKernelGGL(k_unpack_actions, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, q16, (int)rows, 16, 0, 1, 1.0f, outp);
+    HP_CHECK_HIP(hipGetLastError());
+    HP_CHECK_HIP(hipMemcpyAsync(q_host, outp, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    return HP_OK;
+}
+
 // slab engines: the whole policy call is one launch (k_policy_slab8).  `head` = float32 inputs (x != null) or the float64
 // observation rows followed by the goal rows.
 static int policy_rows_slab(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, int64_t rows, const void *host_a,
@@ -1618,6 +1665,15 @@ int hp_agent_actor_forward(hp_agent *a, int32_t net, const float *x_host, int64_
         HP_CHECK_HIP(hipGetLastError());
         return (int)HP_OK;
     });
+}
+
+int hp_agent_critic_forward(hp_agent *a, int32_t net, const float *x_host, const float *actions_host, int64_t rows,
+                            float *q_host) {
+    HP_REQUIRE(a && x_host && actions_host && q_host, HP_ERR_INVALID, "hp_agent_critic_forward: null argument");
+    HP_SERIALISE(a);
+    HP_REQUIRE(net == HP_NET_CRITIC || net == HP_NET_CRITIC_TARGET, HP_ERR_INVALID, "hp_agent_critic_forward: net must be a critic");
+    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_critic_forward: rows out of range");
+    return critic_rows(a, net, rows, x_host, actions_host, q_host);
 }
 
 int hp_agent_act(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, const double *obs_host, const double *g_host,

@@ -164,6 +164,16 @@ class ddpg_agent:
                                                    _lib.ptr(out, C.c_float)))
         return out.reshape(x.shape[:-1] + (out.shape[-1],))
 
+    def _critic_forward(self, slot, x, actions):
+        x, actions = _lib.as_f32(x), _lib.as_f32(actions)
+        x2, a2 = x.reshape(-1, x.shape[-1]), actions.reshape(-1, actions.shape[-1])
+        if x2.shape[0] != a2.shape[0]:
+            raise ValueError("critic forward: inputs and actions differ in length")
+        out = np.empty((x2.shape[0], 1), np.float32)
+        _lib.check(self.lib.hp_agent_critic_forward(self.h, slot, _lib.ptr(x2, C.c_float), _lib.ptr(a2, C.c_float),
+                                                    x2.shape[0], _lib.ptr(out, C.c_float)))
+        return out.reshape(x.shape[:-1] + (1,))
+
     # ------------------------------------------------------------------ hot path
     def _handles(self):
         return (self.h, self.buffer._dev.h, self.o_norm.h, self.g_norm.h, self.rng.h)

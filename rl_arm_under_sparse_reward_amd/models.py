@@ -102,7 +102,10 @@ class critic(_DeviceMLP):
         super().__init__(env_params, env_params['obs'] + env_params['goal'] + env_params['action'], 1)
 
     def forward(self, x, actions):
-        self._require_learner()
-        raise NotImplementedError(
-            "a stand-alone critic forward is not part of the hot path: Q-values are produced and consumed inside "
-            "the fused update (csrc/agent.hip, levels 4-9)")
+        """models.py:36-44 on the device: x [rows, obs+goal] float32, actions [rows, action] -> q [rows, 1].  (Inside the
+        update the Q-values are produced and consumed by the fused kernels; this stand-alone forward serves callers that
+        evaluate the critic themselves.)"""
+        learner = self._require_learner()
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        out = learner._critic_forward(self._slot, to_np(x), to_np(actions))
+        return torch.from_numpy(out) if isinstance(x, torch.Tensor) else out

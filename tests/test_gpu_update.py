@@ -205,6 +205,23 @@ def test_actor_forward_matches_oracle():
     assert np.allclose(one.numpy(), want[:1], rtol=1e-5, atol=1e-6)
 
 
+def test_critic_forward_matches_oracle():
+    """models.critic.forward stand-alone (Q(x, a) with the action scaling of models.py:38), online and target nets."""
+    torch.manual_seed(0)
+    agent, _ = make_agent()
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.normal(size=(41, 30)).astype(np.float32))
+    a = torch.from_numpy(rs.uniform(-0.5, 0.5, size=(41, 4)).astype(np.float32))
+    for net in (agent.critic_network, agent.critic_target_network):
+        params = {k: v.detach() for k, v in net.state_dict().items()}
+        want = oupd.critic_forward(params, x, a, 0.5).numpy()
+        got = net(x, a)
+        assert got.shape == (41, 1) and np.allclose(got.numpy(), want, rtol=1e-5, atol=1e-6)
+    assert np.allclose(agent.critic_target_network(x[:1].numpy(), a[:1].numpy()), want[:1], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        agent.critic_network(x, a[:-1])
+
+
 def test_checkpoint_format_roundtrip(tmp_path):
     """ddpg_agent.py:158-161 format: [o_mean, o_std, g_mean, g_std, actor.state_dict()]."""
     agent, _ = make_agent()
