@@ -55,6 +55,22 @@ class normalizer:
         self.comm.allreduce_mean_device(p.value, n.value)               # normalizer.py:60-64
         _lib.check(self.lib.hp_norm_recompute_end(self.h))
 
+    def sync(self, local_sum, local_sumsq, local_count):
+        """normalizer.py:34-38: the cross-rank average of three host arrays (recompute_stats does this on the device
+        vectors; kept for callers of the reference's helper)."""
+        local_sum[...] = self._mpi_average(local_sum)
+        local_sumsq[...] = self._mpi_average(local_sumsq)
+        local_count[...] = self._mpi_average(local_count)
+        return local_sum, local_sumsq, local_count
+
+    def _mpi_average(self, x):
+        """normalizer.py:60-64: Allreduce(SUM) / world size."""
+        import torch
+        buf = torch.from_numpy(np.array(x, dtype=np.float32, copy=True))
+        if self.comm is not None and self.comm.active:
+            self.comm.allreduce_mean_(buf)
+        return buf.numpy()
+
     def normalize(self, v, clip_range=None):
         if clip_range is None:
             clip_range = self.default_clip_range

@@ -95,6 +95,10 @@ class Communicator:
                 h = t.cpu()
                 self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM)
                 t.copy_(h)
+            elif not t.is_cuda and self._dist.get_backend() == "nccl":
+                d = t.to(f"cuda:{self.device_id if self.device_id is not None else torch.cuda.current_device()}")
+                self._dist.all_reduce(d, op=self._dist.ReduceOp.SUM)      # RCCL moves device memory: host scalars go up and back
+                t.copy_(d.cpu())
             else:
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return t

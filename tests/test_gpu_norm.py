@@ -141,3 +141,13 @@ def test_normalizer_matches_oracle_on_random_sequences(case):
             assert np.array_equal(bits(dev.normalize(x)), bits(ref.normalize(x))), step
             assert np.array_equal(bits(dev.normalize(x, 1.5)), bits(ref.normalize(x, 1.5))), step
             assert np.array_equal(bits(dev.normalize(x[0])), bits(ref.normalize(x[0]))), step
+
+
+def test_sync_and_mpi_average_helpers_single_rank():
+    """normalizer.sync / _mpi_average (normalizer.py:34-38,60-64) exist for callers of the reference's helpers; with one
+    rank they return their inputs (as float32, like the reference's buffers)."""
+    nz = normalizer(5)
+    a, b, c = np.arange(5, dtype=np.float32), np.arange(5, dtype=np.float32) ** 2, np.array([7.0], np.float32)
+    s0, s1, s2 = nz.sync(a.copy(), b.copy(), c.copy())
+    assert np.array_equal(s0, a) and np.array_equal(s1, b) and np.array_equal(s2, c)
+    assert nz._mpi_average(np.float64([1.5, 2.5])).dtype == np.float32
