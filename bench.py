@@ -71,7 +71,7 @@ class Runner:
 
         self.torch = torch
         self.world = world
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("RLARM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(local)
         self.ctx = _lib.Context(local)
         args = Args(batch_size=a.batch, buffer_size=a.episodes * 100, replay_k=a.replay_k, seed=125 + rank)
@@ -86,6 +86,7 @@ class Runner:
         self.pool = [make_episodes(ROLLOUTS_PER_CYCLE, seed=10_000 + 977 * rank + i) for i in range(16)]
         self.cycle = 0
         self.in_cycle = 0                    # steps done in the current cycle
+        self.opens = self.closes = 0         # cycle boundaries issued: store + normalizer refresh / polyak
         self.feeder = None
         if a.feeder_episodes > 0:
             # host feeder: one batch of episodes per cycle from a second thread; the library's
@@ -124,10 +125,13 @@ class Runner:
             if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
                 self.cycle += 1
+                self.opens += 1
+                self.closes += 1
                 k -= N_BATCHES
                 continue
             if self.in_cycle == 0:
                 self._open_cycle_eager()
+                self.opens += 1
             n = min(k, N_BATCHES - self.in_cycle)
             ag._update_network(n)
             self.in_cycle += n
@@ -136,6 +140,7 @@ class Runner:
                 ag._soft_update_target_network()
                 self.in_cycle = 0
                 self.cycle += 1
+                self.closes += 1
 
     def sync(self):
         if self.feeder is not None:          # the feeder's stores belong to the cycles that released them
@@ -241,15 +246,42 @@ def cpu_baseline(a, seconds):
     }
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` from a plain shell: re-exec under torch.distributed.run, one rank per GPU (the form
+    the contract names: --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1).  Rank 0 of the child job prints the
+    JSON line; this parent only relays the exit status."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (RCCL / peer memory across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
     import torch
+
+    # Fewer visible GPUs than ranks (a 1-GPU box rehearsing the N-rank code path): ranks share devices round-robin.
+    # RCCL refuses two ranks on one device, so the process group is gloo and the exchange goes through the library's
+    # peer-memory all-reduce or, failing that, through torch.distributed on host copies.  Never a bench line to quote.
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev
+    if "LOCAL_RANK" in os.environ and n_dev > 0:
+        os.environ["RLARM_DEVICE"] = str(int(os.environ["LOCAL_RANK"]) % n_dev)
 
     # RLARM_BENCH_FORCE_DP=1 (diagnostic): run the data-parallel code path -- process group, library-side RCCL
     # communicator, collectives inside the cycle graph -- in a 1-rank group, e.g. to check it on a single-GPU box
@@ -259,26 +291,42 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        dev = int(os.environ.get("RLARM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     r = Runner(a, rank, world, force_dp)
-    # one-time initialisation, not warm-up: the first full cycle captures and instantiates the cycle hipGraph (and, at
-    # N > 1, sets up the RCCL channels); without it a short --warmup would leave that inside the timed region
+    # One-time initialisation, not warm-up.  (1) The first full cycle captures and instantiates the cycle hipGraph (and,
+    # at N > 1, sets up the exchange channels).  (2) A rehearsal of the exact warm-up + timed step pattern lets the
+    # library capture the partial-cycle graphs that pattern needs (hp_agent_sample_and_update caches one graph per
+    # chunk length), then the cycle is completed so that the measured pass starts at the same cycle position and
+    # replays the same graphs.  Without it a short --steps would time graph instantiation instead of the hot path.
     r.run_steps(N_BATCHES)
     r.sync()
+    r.run_steps(a.warmup)
+    r.run_steps(a.steps)
+    r.run_steps((-r.in_cycle) % N_BATCHES)
+    r.sync()
+    barrier(world)
     r.run_steps(a.warmup)
     r.sync()
     barrier(world)
     r.sync()
+    opens0, closes0 = r.opens, r.closes
     t0 = time.perf_counter()
     r.run_steps(a.steps)
     r.sync()
     barrier(world)
     r.sync()
     dt = time.perf_counter() - t0
+    # cycle-boundary work inside the timed region: [store 2 episodes + normalizer refresh, polyak]; a steady state has
+    # one of each per 40 steps
+    boundaries = {"store_and_normalizer": r.opens - opens0, "polyak": r.closes - closes0,
+                  "steady_state_would_have": round(a.steps / N_BATCHES, 3)}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = r.agent.last_losses(1)[0]
@@ -305,7 +353,9 @@ def main():
         "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "init": "one untimed training cycle before the warm-up steps (hipGraph capture / RCCL channel set-up)",
+        "init": "untimed before the warm-up: one training cycle (cycle hipGraph capture / exchange set-up) and one rehearsal "
+                "of the warm-up + timed step pattern (partial-cycle graph captures), ending on a cycle boundary",
+        "cycle_boundaries_in_timed_region": boundaries,
         "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",

@@ -96,6 +96,11 @@ int hp_buffer_create(hp_ctx *ctx, int64_t size_episodes, int32_t T, int32_t obs_
  * Slot selection runs on the device and draws from `rng` exactly when the reference does. */
 int hp_buffer_store(hp_buffer *buf, hp_rng *rng, const double *obs, const double *ag, const double *g,
                     const double *actions, int64_t n_new);
+/* Upload n_new episodes into the buffer's device staging area WITHOUT storing them (no slot draw, counters untouched):
+ * the temporary dict ddpg_agent._update_normalizer builds from the episodes it is handed (ddpg_agent.py:187-203).
+ * hp_norm_update_from_staged then samples from exactly these episodes.  n_new == 0 -> "high <= 0" like numpy. */
+int hp_buffer_stage(hp_buffer *buf, const double *obs, const double *ag, const double *g, const double *actions,
+                    int64_t n_new);
 int hp_buffer_info(hp_buffer *buf, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored,
                    int32_t *T);
 /* slots chosen by the most recent hp_buffer_store (parity tests); synchronises */
@@ -116,6 +121,8 @@ typedef struct {
     float *r;                                            /* [B] */
     int64_t *e, *t, *future_t;                           /* [B] */
     uint8_t *her;                                        /* [B] */
+    double *r64;                                         /* [B] what compute_reward itself returns: the float32 reward
+                                                            widened (sparse) or -d in float64 (dense, :89-90) */
 } hp_sample_out;
 int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *host_out);
@@ -123,6 +130,25 @@ int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p
  * reference's dict layout), `reps` back-to-back launches each, no host copies.  Consumes 1 + reps index draws. */
 int hp_buffer_sample_device_us(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                                int32_t reps, double *draw_us, double *gather_us);
+
+/* ---- GoalEnv reward / success as batched device ops --------------------------------------------
+ * compute_reward (bmirobot_env_push_F.py:84-90 -> goal_distance :20-23; byte-identical in
+ * bmirobot_env_pickandplace_v2.py:84-90) and _is_success (:243-245) for n goal pairs [n][goal_dim] float64.
+ *   dense == 0: sparse reward -(d > distance_threshold).astype(float32) -> sparse_out (bits 0x80000000 / 0xBF800000)
+ *   dense != 0: -d in float64 -> dense_out
+ *   hp_is_success: (d < distance_threshold).astype(float32)
+ * The predicates are evaluated on the squared distance against the smallest double whose correctly rounded square
+ * root passes the comparison, so they agree with numpy's sqrt-then-compare for every input (bit-exact for
+ * goal_dim < 8, where numpy's add.reduce is a left-to-right sum).  *_dev: device pointers, asynchronous on the context's
+ * stream; the plain forms take host arrays and synchronise. */
+int hp_compute_reward_dev(hp_ctx *ctx, const double *ag_dev, const double *g_dev, int64_t n, int32_t goal_dim,
+                          double distance_threshold, int32_t dense, float *sparse_out_dev, double *dense_out_dev);
+int hp_is_success_dev(hp_ctx *ctx, const double *ag_dev, const double *g_dev, int64_t n, int32_t goal_dim,
+                      double distance_threshold, float *out_dev);
+int hp_compute_reward(hp_ctx *ctx, const double *ag_host, const double *g_host, int64_t n, int32_t goal_dim,
+                      double distance_threshold, int32_t dense, float *sparse_out_host, double *dense_out_host);
+int hp_is_success(hp_ctx *ctx, const double *ag_host, const double *g_host, int64_t n, int32_t goal_dim,
+                  double distance_threshold, float *out_host);
 
 /* ---- running normalizer ----------------------------------------------------------------
  * normalizer.py:5-70.  float32 accumulators/totals/mean; std is float64 when std_f32 == 0

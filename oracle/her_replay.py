@@ -34,6 +34,12 @@ def compute_reward(achieved_goal, goal, distance_threshold=0.05, reward_type="sp
     return -d
 
 
+def is_success(achieved_goal, desired_goal, distance_threshold=0.05):
+    """bmirobot_env_push_F.py:243-245 -- (d < thr) as float32."""
+    d = goal_distance(achieved_goal, desired_goal)
+    return (d < distance_threshold).astype(np.float32)
+
+
 def squared_distance_threshold(distance_threshold: float) -> float:
     """Smallest float64 s with sqrt(s) > distance_threshold (sqrt correctly rounded).
 

@@ -28,7 +28,7 @@ class HpError(RuntimeError):
 
 class SampleOut(C.Structure):
     _fields_ = [("obs", f64p), ("ag", f64p), ("g", f64p), ("actions", f64p), ("obs_next", f64p), ("ag_next", f64p),
-                ("r", f32p), ("e", i64p), ("t", i64p), ("future_t", i64p), ("her", u8p)]
+                ("r", f32p), ("e", i64p), ("t", i64p), ("future_t", i64p), ("her", u8p), ("r64", f64p)]
 
 
 class AgentCfg(C.Structure):
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "hp_rng_destroy": (None, [C.c_void_p]),
     "hp_buffer_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_void_pp]),
     "hp_buffer_store": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p, C.c_int64]),
+    "hp_buffer_stage": (C.c_int, [C.c_void_p, f64p, f64p, f64p, f64p, C.c_int64]),
     "hp_buffer_info": (C.c_int, [C.c_void_p, i64p, i64p, i64p, C.POINTER(C.c_int32)]),
     "hp_buffer_last_slots": (C.c_int, [C.c_void_p, i64p, C.c_int64]),
     "hp_buffer_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, f64p]),
@@ -68,6 +69,11 @@ PROTOTYPES = {
     "hp_buffer_sample_device_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int32, f64p,
                                              f64p]),
     "hp_buffer_destroy": (None, [C.c_void_p]),
+    "hp_compute_reward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
+    "hp_is_success_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p]),
+    "hp_compute_reward": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int64, C.c_int32, C.c_double, C.c_int32, f32p, f64p]),
+    "hp_is_success": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int64, C.c_int32, C.c_double, f32p]),
     "hp_norm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, c_void_pp]),
     "hp_norm_update": (C.c_int, [C.c_void_p, f64p, C.c_int64]),
     "hp_norm_recompute_begin": (C.c_int, [C.c_void_p, c_void_pp, i64p]),

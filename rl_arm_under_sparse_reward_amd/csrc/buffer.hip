@@ -12,6 +12,8 @@
 // (x0*x0 + x1*x1) + x2*x2 in float64, so no multiply-add may be fused.
 #include "internal.h"
 
+#include <cmath>
+
 // ----------------------------------------------------------------------------- kernels
 // One wavefront per transition; lanes stride over the row elements (coalesced 8-byte loads).
 // dict-mode output = the arrays her_sampler.sample_her_transitions returns (her.py:39).
@@ -20,7 +22,8 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
                                                      const PlanRec *__restrict__ plan, long long batch, int T,
                                                      int obs_dim, int goal_dim, int act_dim, double sq_threshold,
                                                      double *o_obs, double *o_ag, double *o_g, double *o_act,
-                                                     double *o_obs_next, double *o_ag_next, float *o_r) {
+                                                     double *o_obs_next, double *o_ag_next, float *o_r,
+                                                     double *o_r64) {
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= batch) return;
@@ -53,7 +56,29 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
             s = (c == 0) ? sq : __dadd_rn(s, sq);
         }
         o_r[i] = hp_reward(s, sq_threshold);  // -(d > thr).astype(float32), or float32(-d)
+        // what compute_reward itself returns (:87-90): the float32 above widened (sparse) or -d in float64 (dense)
+        if (o_r64) o_r64[i] = hp_reward64(s, sq_threshold);
     }
+}
+
+// Batched compute_reward / _is_success of the bmirobot GoalEnvs (bmirobot_env_push_F.py:84-90, :243-245; identical in
+// bmirobot_env_pickandplace_v2.py) on device arrays [n][goal_dim] float64.  mode 0: sparse reward -(d > thr) as float32
+// (bits 0x80000000 / 0xBF800000); mode 1: dense reward -d as float64; mode 2: success (d < thr) as float32.
+// thr_sq = the squared-domain threshold of the predicate (see hp_compute_reward); no square root in modes 0 and 2.
+__global__ __launch_bounds__(256) void k_goal_reward(const double *__restrict__ ag, const double *__restrict__ g,
+                                                     long long n, int goal_dim, double thr_sq, int mode, float *out32,
+                                                     double *out64) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < goal_dim; ++c) {   // numpy add.reduce over < 8 contiguous elements: left to right
+        const double d = __dsub_rn(ag[i * goal_dim + c], g[i * goal_dim + c]);
+        const double sq = __dmul_rn(d, d);
+        s = (c == 0) ? sq : __dadd_rn(s, sq);
+    }
+    if (mode == 0) out32[i] = (s >= thr_sq) ? -1.0f : -0.0f;
+    else if (mode == 1) out64[i] = -__dsqrt_rn(s);
+    else out32[i] = (s < thr_sq) ? 1.0f : 0.0f;
 }
 
 // scatter the staged episodes into their slots.  numpy's `buffers[idxs] = mb` lets the LAST
@@ -81,7 +106,7 @@ __global__ __launch_bounds__(256) void k_store_scatter(const long long *__restri
 
 // ------------------------------------------------------------------------------ launchers
 int buffer_launch_gather_dict(hp_buffer *b, const PlanRec *d_plan, int64_t batch, double sq_threshold, double *d_out,
-                              float *d_r) {
+                              float *d_r, double *d_r64) {
     const int od = b->obs_dim, gd = b->goal_dim, ad = b->act_dim;
     double *o_obs = d_out;
     double *o_ag = o_obs + batch * od;
@@ -93,19 +118,16 @@ int buffer_launch_gather_dict(hp_buffer *b, const PlanRec *d_plan, int64_t batch
     dim3 grid((unsigned)((batch + waves_per_block - 1) / waves_per_block));
     hipLaunchKernelGGL(k_gather_dict, grid, dim3(256), 0, b->ctx->stream, b->d_obs, b->d_ag, b->d_g, b->d_act, d_plan,
                        (long long)batch, (int)b->T, od, gd, ad, sq_threshold, o_obs, o_ag, o_g, o_act, o_obs_next,
-                       o_ag_next, d_r);
+                       o_ag_next, d_r, d_r64);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
 
-// stage host episodes on the device (st_*), pick slots, scatter.  Shared by hp_buffer_store and
-// the train-cycle path.
-int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
-                           const double *actions, int64_t n_new) {
+// stage host episodes on the device (st_*): one pinned copy, one H2D.  copy-in semantics (replay_buffer.py:39-42): the
+// caller's arrays are read by the CPU memcpy below and never again; the DMA reads our pinned staging.
+static int buffer_stage(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
+                        int64_t n_new) {
     hipStream_t s = b->ctx->stream;
-    HP_TRY(b->st_slots.ensure(n_new * 8));
-    // copy-in semantics (replay_buffer.py:39-42): the caller's arrays are read by the CPU memcpy
-    // below and never again; the DMA reads our pinned staging.
     const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
                  n3 = n_new * b->ep_act() * 8;
     HP_TRY(b->st_obs.ensure(n0 + n1 + n2 + n3));
@@ -122,6 +144,15 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
     HP_CHECK_HIP(hipMemcpyAsync(dst, h, n0 + n1 + n2 + n3, hipMemcpyHostToDevice, s));
     HP_TRY(b->pin.mark(s));
     b->staged_n = n_new;
+    return HP_OK;
+}
+
+// stage, pick slots, scatter.  Shared by hp_buffer_store and the train-cycle path.
+int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
+                           const double *actions, int64_t n_new) {
+    hipStream_t s = b->ctx->stream;
+    HP_TRY(b->st_slots.ensure(n_new * 8));
+    HP_TRY(buffer_stage(b, obs, ag, g, actions, n_new));
     HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
     hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)(n_new * STORE_PARTS)), dim3(256), 0, s, b->st_slots.as<long long>(),
                        (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g,
@@ -175,6 +206,14 @@ int hp_buffer_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *
     // replay_buffer.py:64 with current_size == 0 and inc > size: np.random.randint(0, 0, k) raises
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
     return buffer_stage_and_store(b, rng, obs, ag, g, actions, n_new);
+}
+
+int hp_buffer_stage(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
+                    int64_t n_new) {
+    HP_REQUIRE(b && obs && ag && g && actions, HP_ERR_INVALID, "hp_buffer_stage: null argument");
+    HP_SERIALISE(b);
+    HP_REQUIRE(n_new > 0, HP_ERR_INVALID, "high <= 0");   // sample_her_transitions on an empty dict: randint(0, 0, T)
+    return buffer_stage(b, obs, ag, g, actions, n_new);
 }
 
 int hp_buffer_info(hp_buffer *b, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored, int32_t *T) {
@@ -236,11 +275,11 @@ int hp_buffer_sample_device_us(hp_buffer *b, hp_rng *rng, int64_t batch, double 
     HP_CHECK_HIP(hipEventCreate(&e1));
     HP_CHECK_HIP(hipEventCreate(&e2));
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
-    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));   // warm
+    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r, nullptr));   // warm
     HP_CHECK_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
     HP_CHECK_HIP(hipEventRecord(e1, s));
-    for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));
+    for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r, nullptr));
     HP_CHECK_HIP(hipEventRecord(e2, s));
     HP_CHECK_HIP(hipEventSynchronize(e2));
     float ms01 = 0.f, ms12 = 0.f;
@@ -264,12 +303,13 @@ int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, 
     const int od = b->obs_dim, gd = b->goal_dim, ad = b->act_dim;
     const size_t row = (size_t)(2 * od + 3 * gd + ad);
     HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
-    HP_TRY(b->out.ensure(batch * row * 8 + batch * 4));
+    HP_TRY(b->out.ensure(batch * row * 8 + batch * 8 + batch * 4));
     PlanRec *d_plan = b->plan.as<PlanRec>();
     double *d_out = b->out.as<double>();
-    float *d_r = reinterpret_cast<float *>(d_out + batch * row);
+    double *d_r64 = d_out + batch * row;
+    float *d_r = reinterpret_cast<float *>(d_r64 + batch);
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
-    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r));
+    HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r, o->r64 ? d_r64 : nullptr));
     double *p = d_out;
     auto pull = [&](double *dst, size_t n) -> hipError_t {
         hipError_t e = dst ? hipMemcpyAsync(dst, p, n * 8, hipMemcpyDeviceToHost, s) : hipSuccess;
@@ -283,6 +323,7 @@ int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, 
     HP_CHECK_HIP(pull(o->obs_next, batch * od));
     HP_CHECK_HIP(pull(o->ag_next, batch * gd));
     if (o->r) HP_CHECK_HIP(hipMemcpyAsync(o->r, d_r, batch * 4, hipMemcpyDeviceToHost, s));
+    if (o->r64) HP_CHECK_HIP(hipMemcpyAsync(o->r64, d_r64, batch * 8, hipMemcpyDeviceToHost, s));
     std::vector<PlanRec> hplan;
     if (o->e || o->t || o->future_t || o->her) {
         hplan.resize(batch);
@@ -296,6 +337,86 @@ int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, 
         if (o->her) o->her[i] = (uint8_t)hplan[i].her;
     }
     return HP_OK;
+}
+
+// ---- compute_reward / _is_success (bmirobot_env_push_F.py:84-90, :243-245) as batched device ops ------------------
+static int goal_reward_launch(hp_ctx *ctx, const double *ag, const double *g, int64_t n, int32_t goal_dim, double thr_sq,
+                              int mode, float *out32, double *out64) {
+    hipLaunchKernelGGL(k_goal_reward, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ag, g, (long long)n,
+                       (int)goal_dim, thr_sq, mode, out32, out64);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// smallest double s whose correctly rounded square root is > thr (strict) or >= thr: the predicates d > thr and
+// !(d < thr) in the squared domain (sqrt_rn is monotone), so no device square root and no rounding mismatch
+static double squared_bound(double thr, bool strict) {
+    if (!(thr >= 0.0)) return 0.0;
+    double s = thr * thr;
+    auto hit = [&](double v) { const double r = std::sqrt(v); return strict ? r > thr : r >= thr; };
+    while (s > 0.0 && hit(s)) s = std::nextafter(s, -INFINITY);
+    while (!hit(s)) s = std::nextafter(s, INFINITY);
+    return s;
+}
+
+int hp_compute_reward_dev(hp_ctx *ctx, const double *ag_dev, const double *g_dev, int64_t n, int32_t goal_dim,
+                          double distance_threshold, int32_t dense, float *sparse_out_dev, double *dense_out_dev) {
+    HP_REQUIRE(ctx && ag_dev && g_dev, HP_ERR_INVALID, "hp_compute_reward_dev: null argument");
+    CtxGuard guard(ctx);
+    HP_REQUIRE(n >= 0 && goal_dim > 0, HP_ERR_INVALID, "hp_compute_reward_dev: bad shape");
+    HP_REQUIRE(dense ? dense_out_dev != nullptr : sparse_out_dev != nullptr, HP_ERR_INVALID,
+               "hp_compute_reward_dev: the output of the selected reward type is null");
+    if (n == 0) return HP_OK;
+    return goal_reward_launch(ctx, ag_dev, g_dev, n, goal_dim, dense ? 0.0 : squared_bound(distance_threshold, true),
+                              dense ? 1 : 0, sparse_out_dev, dense_out_dev);
+}
+
+int hp_is_success_dev(hp_ctx *ctx, const double *ag_dev, const double *g_dev, int64_t n, int32_t goal_dim,
+                      double distance_threshold, float *out_dev) {
+    HP_REQUIRE(ctx && ag_dev && g_dev && out_dev, HP_ERR_INVALID, "hp_is_success_dev: null argument");
+    CtxGuard guard(ctx);
+    HP_REQUIRE(n >= 0 && goal_dim > 0, HP_ERR_INVALID, "hp_is_success_dev: bad shape");
+    if (n == 0) return HP_OK;
+    return goal_reward_launch(ctx, ag_dev, g_dev, n, goal_dim, squared_bound(distance_threshold, false), 2, out_dev,
+                              nullptr);
+}
+
+// host-array forms (the GoalEnv API hands numpy arrays over): staged through the device, same kernels
+static int goal_reward_host(hp_ctx *ctx, const double *ag, const double *g, int64_t n, int32_t goal_dim, double thr_sq,
+                            int mode, void *out_host) {
+    DevBuf &ws = ctx->reward_ws;     // guarded by the context lock the callers hold
+    const size_t nb = (size_t)n * goal_dim * 8, ob = (size_t)n * (mode == 1 ? 8 : 4);
+    HP_TRY(ws.ensure(2 * nb + ob));
+    char *d = ws.as<char>();
+    hipStream_t s = ctx->stream;
+    HP_CHECK_HIP(hipMemcpyAsync(d, ag, nb, hipMemcpyHostToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(d + nb, g, nb, hipMemcpyHostToDevice, s));
+    HP_TRY(goal_reward_launch(ctx, reinterpret_cast<double *>(d), reinterpret_cast<double *>(d + nb), n, goal_dim, thr_sq,
+                              mode, reinterpret_cast<float *>(d + 2 * nb), reinterpret_cast<double *>(d + 2 * nb)));
+    HP_CHECK_HIP(hipMemcpyAsync(out_host, d + 2 * nb, ob, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    return HP_OK;
+}
+
+int hp_compute_reward(hp_ctx *ctx, const double *ag_host, const double *g_host, int64_t n, int32_t goal_dim,
+                      double distance_threshold, int32_t dense, float *sparse_out_host, double *dense_out_host) {
+    HP_REQUIRE(ctx && ag_host && g_host, HP_ERR_INVALID, "hp_compute_reward: null argument");
+    CtxGuard guard(ctx);
+    HP_REQUIRE(n >= 0 && goal_dim > 0, HP_ERR_INVALID, "hp_compute_reward: bad shape");
+    HP_REQUIRE(dense ? dense_out_host != nullptr : sparse_out_host != nullptr, HP_ERR_INVALID,
+               "hp_compute_reward: the output of the selected reward type is null");
+    if (n == 0) return HP_OK;
+    return goal_reward_host(ctx, ag_host, g_host, n, goal_dim, dense ? 0.0 : squared_bound(distance_threshold, true),
+                            dense ? 1 : 0, dense ? (void *)dense_out_host : (void *)sparse_out_host);
+}
+
+int hp_is_success(hp_ctx *ctx, const double *ag_host, const double *g_host, int64_t n, int32_t goal_dim,
+                  double distance_threshold, float *out_host) {
+    HP_REQUIRE(ctx && ag_host && g_host && out_host, HP_ERR_INVALID, "hp_is_success: null argument");
+    CtxGuard guard(ctx);
+    HP_REQUIRE(n >= 0 && goal_dim > 0, HP_ERR_INVALID, "hp_is_success: bad shape");
+    if (n == 0) return HP_OK;
+    return goal_reward_host(ctx, ag_host, g_host, n, goal_dim, squared_bound(distance_threshold, false), 2, out_host);
 }
 
 void hp_buffer_destroy(hp_buffer *b) {

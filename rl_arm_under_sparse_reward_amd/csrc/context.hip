@@ -173,6 +173,7 @@ int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz) {
 
 void hp_ctx_destroy(hp_ctx *ctx) {
     if (!ctx) return;
+    ctx->reward_ws.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

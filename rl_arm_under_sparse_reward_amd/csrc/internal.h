@@ -38,25 +38,6 @@ void hp_set_error(const char *fmt, ...);
         if (_s != HP_OK) return _s; \
     } while (0)
 
-// ------------------------------------------------------------------ context
-struct hp_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;      // stream kernels are enqueued on
-    hipStream_t own_stream = nullptr;  // created by the context
-    int cu_count = 0;
-    char name[128] = {0};
-    // Every entry point that enqueues on the stream or touches a handle's host mirror holds this for the duration of the
-    // call: the counterpart of the reference's per-object locks (replay_buffer.py:29,34,48; normalizer.py:22,27,42), so a
-    // host feeder thread may call hp_buffer_store while another thread drives hp_agent_train_cycle.  Recursive because
-    // entry points call each other.
-    std::recursive_mutex mu;
-};
-struct CtxGuard {   // + the calling thread's current device: HIP keeps that per thread and a feeder thread starts on device 0
-    std::lock_guard<std::recursive_mutex> g;
-    explicit CtxGuard(hp_ctx *c) : g(c->mu) { (void)hipSetDevice(c->device); }
-};
-#define HP_SERIALISE(handle) CtxGuard hp_serialise_guard_((handle)->ctx)
-
 // small RAII-less device buffer helper (grow-only)
 struct DevBuf {
     void *p = nullptr;
@@ -77,6 +58,26 @@ struct DevBuf {
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// ------------------------------------------------------------------ context
+struct hp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream kernels are enqueued on
+    hipStream_t own_stream = nullptr;  // created by the context
+    int cu_count = 0;
+    char name[128] = {0};
+    // Every entry point that enqueues on the stream or touches a handle's host mirror holds this for the duration of the
+    // call: the counterpart of the reference's per-object locks (replay_buffer.py:29,34,48; normalizer.py:22,27,42), so a
+    // host feeder thread may call hp_buffer_store while another thread drives hp_agent_train_cycle.  Recursive because
+    // entry points call each other.
+    std::recursive_mutex mu;
+    DevBuf reward_ws;                  // scratch of the host-array forms of hp_compute_reward / hp_is_success
+};
+struct CtxGuard {   // + the calling thread's current device: HIP keeps that per thread and a feeder thread starts on device 0
+    std::lock_guard<std::recursive_mutex> g;
+    explicit CtxGuard(hp_ctx *c) : g(c->mu) { (void)hipSetDevice(c->device); }
+};
+#define HP_SERIALISE(handle) CtxGuard hp_serialise_guard_((handle)->ctx)
 
 // pinned host staging for async H2D copies of caller-owned (pageable) arrays: the caller's memory
 // is only touched by a CPU memcpy during the call; `fence` marks the last DMA that read the buffer.
@@ -194,6 +195,11 @@ __device__ __forceinline__ float hp_reward(double s, double sq_threshold) {
     if (sq_threshold < 0.0) return (float)(-__dsqrt_rn(s));
     return (s >= sq_threshold) ? -1.0f : -0.0f;
 }
+// the value compute_reward itself returns: float32 widened (sparse) or float64 -d (dense)
+__device__ __forceinline__ double hp_reward64(double s, double sq_threshold) {
+    if (sq_threshold < 0.0) return -__dsqrt_rn(s);
+    return (s >= sq_threshold) ? -1.0 : -0.0;
+}
 #endif
 
 // rank exchange (comm.hip): one RCCL communicator bound to the context's stream
@@ -213,7 +219,7 @@ int rng_launch_slots(hp_rng *rng, hp_buffer *buf, int64_t n_new, int64_t *d_slot
 
 // buffer.hip
 int buffer_launch_gather_dict(hp_buffer *buf, const PlanRec *d_plan, int64_t batch, double sq_threshold,
-                              double *d_out, float *d_r);
+                              double *d_out, float *d_r, double *d_r64);
 int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
                            const double *actions, int64_t n_new);
 

@@ -51,7 +51,14 @@ class ddpg_agent:
         self.ctx = ctx or _lib.Context.default()
         self.lib = self.ctx.lib
         self.comm = comm or Communicator(self.ctx.device_id)
-        self.rng = rng or _random.global_state()
+        if rng is None:
+            # the reference draws from the process-global np.random, which train.py:36 seeds with seed + rank before it
+            # builds the agent.  The device twin of that stream is seeded the same way unless the launch script already
+            # did it (random.seed / random.set_state), so ranks never share a sampler stream by accident
+            rng = _random.global_state()
+            if not rng.seeded:
+                rng.seed(int(args.seed) + self.comm.rank)
+        self.rng = rng
         # networks: host containers initialised like the reference (consumes the torch RNG identically)
         self.actor_network = actor(env_params)
         self.critic_network = critic(env_params)
@@ -100,6 +107,7 @@ class ddpg_agent:
                                  comm=self.comm)
         self.g_norm = normalizer(size=env_params['goal'], default_clip_range=self.args.clip_range, ctx=self.ctx,
                                  comm=self.comm)
+        self._norm_stage = None          # staging buffer of _update_normalizer(episode_batch)
         self.success_rates = []
         self.model_path = os.path.join(self.args.save_dir, self.args.env_name)
 
@@ -222,12 +230,24 @@ class ddpg_agent:
         return o, g
 
     def _update_normalizer(self, episode_batch=None):
-        """ddpg_agent.py:187-212 on the episodes most recently stored (they are still staged on the
-        device).  `episode_batch` is accepted for signature compatibility; passing episodes that were
-        not just stored is an error."""
+        """ddpg_agent.py:187-212: HER-sample T transitions out of `episode_batch`, clip, update both normalizers,
+        recompute.  The given episodes are uploaded into a private staging buffer (the reference's `buffer_temp`), so
+        the statistics come from exactly these episodes whatever was stored in between (e.g. by a feeder thread).
+        `episode_batch=None` reuses the episodes the replay buffer staged in its most recent store_episode (no upload;
+        the benchmark's cycle boundary) and raises if nothing was ever stored."""
         fp = float(self.her_module.future_p)
-        _lib.check(self.lib.hp_norm_update_from_staged(self.buffer._dev.h, self.rng.h, self.o_norm.h, self.g_norm.h,
-                                                       fp, float(self.args.clip_obs)))
+        if episode_batch is not None:
+            if self._norm_stage is None:
+                from .replay_buffer import DeviceEpisodeBuffer
+                ep = self.env_params
+                self._norm_stage = DeviceEpisodeBuffer(1, ep['max_timesteps'], ep['obs'], ep['goal'], ep['action'],
+                                                       ctx=self.ctx)
+            self._norm_stage.stage(episode_batch)
+            src = self._norm_stage
+        else:
+            src = self.buffer._dev
+        _lib.check(self.lib.hp_norm_update_from_staged(src.h, self.rng.h, self.o_norm.h, self.g_norm.h, fp,
+                                                       float(self.args.clip_obs)))
         self.o_norm.recompute_stats()
         self.g_norm.recompute_stats()
 
@@ -243,13 +263,30 @@ class ddpg_agent:
             self._update_network(n_batches)
             self._soft_update_target_network()
             return
-        obs, ag, g, act = (_lib.as_f64(a) for a in episode_batch)
+        # same shape validation as store_episode (a wrong T or dimension raises ValueError like numpy's broadcast at
+        # replay_buffer.py:39-42 instead of letting the library read past the arrays)
+        obs, ag, g, act, n_new = self.buffer._dev._checked(episode_batch)
         d = C.c_double
         _lib.check(self.lib.hp_agent_train_cycle(
-            *self._handles(), _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d), _lib.ptr(act, d), obs.shape[0],
+            *self._handles(), _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d), _lib.ptr(act, d), n_new,
             float(self.her_module.future_p), float(self.her_module.sq_threshold), n_batches))
 
     # ------------------------------------------------------------------ demos / checkpoints (formats preserved)
+    def plot_success_rate(self):
+        """ddpg_agent.py:73-80: dump the per-epoch success rates where the reference does; the plot itself needs
+        matplotlib and a display, so it is drawn only when both are there."""
+        saved_dir = 'test_rates/'
+        os.makedirs(saved_dir, exist_ok=True)
+        np.save(saved_dir + str(self.args.seed) + '_' + str(self.args.add_demo) + '_success_rates.npy',
+                np.array(self.success_rates))
+        try:
+            import matplotlib.pyplot as plt
+        except Exception:
+            return
+        plt.plot(self.success_rates)
+        if os.environ.get("DISPLAY") or os.environ.get("MPLBACKEND"):
+            plt.show()
+
     def _init_demo_buffer(self):
         """ddpg_agent.py:82-90: keys obs, acs, ag, g of a get_demo_data_*.py file (info is ignored)."""
         demo = np.load(self.args.demo_name, allow_pickle=True)
@@ -281,9 +318,10 @@ class ddpg_agent:
         inputs = np.concatenate([self.o_norm.normalize(obs), self.g_norm.normalize(g)])
         return torch.tensor(inputs, dtype=torch.float32).unsqueeze(0)
 
-    def act(self, obs, g, target=False):
+    def act(self, obs, g, target=False, clip_obs=0.0):
         """_preproc_inputs (:163-171) + actor (:114-116) for a stack of environments in ONE device call: obs [n, obs] and
-        g [n, goal] float64 (or single rows) -> actions [n, action] float32."""
+        g [n, goal] float64 (or single rows) -> actions [n, action] float32.  clip_obs > 0 also clips the raw values to
+        +-clip_obs first, which is what the checkpoint reader demo_push.py:15-22 does (the rollouts do not)."""
         obs, g = _lib.as_f64(obs), _lib.as_f64(g)
         o2, g2 = obs.reshape(-1, obs.shape[-1]), g.reshape(-1, g.shape[-1])
         if o2.shape[0] != g2.shape[0]:
@@ -291,14 +329,17 @@ class ddpg_agent:
         out = np.empty((o2.shape[0], self.env_params['action']), np.float32)
         d = C.c_double
         _lib.check(self.lib.hp_agent_act(self.h, self.o_norm.h, self.g_norm.h, NET_ACTOR_TARGET if target else NET_ACTOR,
-                                         _lib.ptr(o2, d), _lib.ptr(g2, d), o2.shape[0], 0.0, _lib.ptr(out, C.c_float)))
+                                         _lib.ptr(o2, d), _lib.ptr(g2, d), o2.shape[0], float(clip_obs),
+                                         _lib.ptr(out, C.c_float)))
         return out.reshape(obs.shape[:-1] + (out.shape[-1],))
 
     def _select_actions(self, pi):
-        """ddpg_agent.py:174-184: Gaussian noise, clip, epsilon-random (numpy global RNG, like the reference)."""
+        """ddpg_agent.py:174-184: Gaussian noise, clip, epsilon-random (numpy global RNG, like the reference).  `action`
+        stays the float32 array the policy returned and is updated in place, so every step rounds to float32 exactly
+        where the reference's `action += ...` does."""
         amax = self.env_params['action_max']
-        action = (pi.cpu().numpy() if isinstance(pi, torch.Tensor) else np.asarray(pi, dtype=np.float32)).squeeze()
-        action = action + self.args.noise_eps * amax * np.random.randn(*action.shape)
+        action = (pi.cpu().numpy() if isinstance(pi, torch.Tensor) else np.array(pi, dtype=np.float32)).squeeze()
+        action += self.args.noise_eps * amax * np.random.randn(*action.shape)
         action = np.clip(action, -amax, amax)
         random_actions = np.random.uniform(low=-amax, high=amax, size=self.env_params['action'])
         action += np.random.binomial(1, self.args.random_eps, 1)[0] * (random_actions - action)

@@ -27,6 +27,7 @@ class DeviceRandomState:
         self.lib = self.ctx.lib
         self.h = C.c_void_p()
         _lib.check(self.lib.hp_rng_create(self.ctx.h, C.byref(self.h)))
+        self.seeded = False       # seed() / set_state() called (a fresh stream carries numpy's default key, seed 5489)
         if seed is not None:
             self.seed(seed)
 
@@ -35,6 +36,7 @@ class DeviceRandomState:
         if not 0 <= seed <= 2**32 - 1:
             raise ValueError("Seed must be between 0 and 2**32 - 1")     # numpy's message
         _lib.check(self.lib.hp_rng_seed(self.h, C.c_uint32(seed)))
+        self.seeded = True
 
     def get_state(self):
         key = np.empty(624, np.uint32)
@@ -53,6 +55,7 @@ class DeviceRandomState:
         if key.shape != (624,):
             raise ValueError("state must be 624 longs")
         _lib.check(self.lib.hp_rng_set_state(self.h, _lib.ptr(key, C.c_uint32), C.c_int32(int(pos))))
+        self.seeded = True
 
     # test hooks: the two primitive draws of the hot path, executed on the device
     def randint(self, low, high=None, size=1):

@@ -38,17 +38,34 @@ class DeviceEpisodeBuffer:
         _lib.check(self.lib.hp_buffer_info(self.h, C.byref(s), C.byref(c), C.byref(n), C.byref(t)))
         return s.value, c.value, n.value, t.value
 
-    def store(self, rng, episode_batch):
+    def _checked(self, episode_batch):
+        """float64 C-contiguous views of the four episode arrays, shapes validated like numpy's broadcast would
+        (replay_buffer.py:39-42 raises ValueError on a wrong T or dimension)."""
+        if len(episode_batch) != 4:
+            raise ValueError("episode_batch must be [mb_obs, mb_ag, mb_g, mb_actions]")
         obs, ag, g, act = (_lib.as_f64(a) for a in episode_batch)
-        n = obs.shape[0]
+        n = obs.shape[0] if obs.ndim else 0
         T = self.T
         want = {"obs": (n, T + 1, self.dims["obs"]), "ag": (n, T + 1, self.dims["ag"]),
                 "g": (n, T, self.dims["g"]), "actions": (n, T, self.dims["actions"])}
         for name, a in (("obs", obs), ("ag", ag), ("g", g), ("actions", act)):
             if a.shape != want[name]:
                 raise ValueError(f"could not broadcast input array from shape {a.shape} into shape {want[name]}")
+        return obs, ag, g, act, n
+
+    def store(self, rng, episode_batch):
+        obs, ag, g, act, n = self._checked(episode_batch)
         d = C.c_double
         _lib.check(self.lib.hp_buffer_store(self.h, rng.h, _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d),
+                                            _lib.ptr(act, d), n))
+        return n
+
+    def stage(self, episode_batch):
+        """Upload episodes into the device staging area without storing them (the temporary dict of
+        ddpg_agent._update_normalizer, ddpg_agent.py:187-203)."""
+        obs, ag, g, act, n = self._checked(episode_batch)
+        d = C.c_double
+        _lib.check(self.lib.hp_buffer_stage(self.h, _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d),
                                             _lib.ptr(act, d), n))
         return n
 
@@ -74,6 +91,10 @@ class DeviceEpisodeBuffer:
         for k, a in tr.items():
             setattr(o, k, _lib.ptr(a, C.c_double))
         o.r = _lib.ptr(r, C.c_float)
+        dense = float(sq_threshold) < 0
+        r64 = np.empty((B, 1), np.float64) if dense else None
+        if dense:
+            o.r64 = _lib.ptr(r64, C.c_double)
         idx = None
         if with_indices:
             idx = {"e": np.empty(B, np.int64), "t": np.empty(B, np.int64), "future_t": np.empty(B, np.int64),
@@ -81,12 +102,9 @@ class DeviceEpisodeBuffer:
             o.e, o.t, o.future_t = (_lib.ptr(idx[k], C.c_int64) for k in ("e", "t", "future_t"))
             o.her = _lib.ptr(idx["her"], C.c_uint8)
         _lib.check(self.lib.hp_buffer_sample(self.h, rng.h, B, float(future_p), float(sq_threshold), C.byref(o)))
-        tr["r"] = r                                                   # her.py:38 expand_dims(..., 1)
-        if float(sq_threshold) < 0:
-            # dense reward: the env returns -d in float64 (compute_reward :89-90); same arithmetic on the gathered rows
-            # (the device value above is its float32 narrowing, which is what the learner consumes)
-            diff = tr["ag_next"] - tr["g"]
-            tr["r"] = -np.sqrt((diff * diff).sum(axis=-1))[:, None]
+        # her.py:38 expand_dims(reward_func(...), 1): float32 for the sparse reward; the dense branch of compute_reward
+        # returns -d in float64 (:89-90), computed by the same kernel (r holds its float32 narrowing, the learner's input)
+        tr["r"] = r64 if dense else r
         if with_indices:
             idx["her"] = idx["her"].astype(bool)
             return tr, idx

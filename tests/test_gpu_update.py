@@ -170,16 +170,18 @@ def test_updates_track_oracle_over_a_cycle(batch, k):
 
 
 @pytest.mark.parametrize("n_batches", [5, 1, 2])     # 1 and 2: shorter than the two-update lead of the index plans
-def test_train_cycle_graph_equals_eager_bitwise(n_batches):
-    """The cached hipGraph cycle and the call-by-call path must produce identical bits."""
+def test_train_cycle_graph_equals_eager_bitwise(n_batches, monkeypatch):
+    """The cached hipGraph cycle, the call-by-call path with its cached per-call graphs and the same path on plain
+    eager launches must produce identical bits."""
     outs = []
-    for use_graph in (False, True):
-        torch.manual_seed(0)                                        # same initial weights in both runs
+    for mode in ("eager", "update_graph", "cycle_graph"):
+        monkeypatch.setenv("RLARM_UPDATE_GRAPH", "0" if mode == "eager" else "1")   # read by hp_agent_create
+        torch.manual_seed(0)                                        # same initial weights in every run
         agent, rng = make_agent(batch=256, n_eps=16, seed=11)       # small buffer: cycles overflow it
         agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
         for cycle in range(4):
             eps = make_episodes(2, seed=100 + cycle, mode="walk")
-            if use_graph:
+            if mode == "cycle_graph":
                 agent.train_cycle(eps, n_batches=n_batches)
             else:
                 agent.buffer.store_episode(eps)
@@ -189,8 +191,112 @@ def test_train_cycle_graph_equals_eager_bitwise(n_batches):
         outs.append((agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_ACTOR_TARGET),
                      agent.last_losses(4 * n_batches), agent.o_norm.mean, agent.g_norm.std, rng.get_state()[1], rng.get_state()[2],
                      agent.buffer.buffers["ag"], agent.buffer.current_size))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def test_cycle_graph_survives_a_larger_update_call_in_between():
+    """hp_agent_sample_and_update(n > cached n_batches) reallocates the index plan the cycle graph has baked
+    in; the graph must be rebuilt, not replayed on freed memory.  Mixed sequence == the same sequence call by call."""
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        agent, rng = make_agent(batch=256, n_eps=16, seed=11)
+        agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
+        for cycle, extra in enumerate((0, 13, 0, 29)):
+            eps = make_episodes(2, seed=300 + cycle, mode="walk")
+            if use_graph:
+                agent.train_cycle(eps, n_batches=6)
+            else:
+                agent.buffer.store_episode(eps)
+                agent._update_normalizer(eps)
+                agent._update_network(6)
+                agent._soft_update_target_network()
+            if extra:
+                agent._update_network(extra)                # grows the plan past the 6 the graph was captured with
+        outs.append((agent._get_flat(NET_CRITIC), agent.last_losses(4 * 6 + 42), rng.get_state()[1], rng.get_state()[2]))
     for a, b in zip(*outs):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def test_train_cycle_rejects_malformed_episode_batches():
+    """the reference raises a broadcast ValueError at replay_buffer.py:39-42; the fast path must not read
+    past the caller's arrays instead."""
+    agent, _ = make_agent(batch=64, n_eps=8)
+    obs, ag, g, act = make_episodes(2, seed=1)
+    for bad in ([obs[:, :100], ag, g, act],                 # obs with T rows instead of T + 1
+                [obs, g, ag, act],                          # ag / g swapped
+                [obs, ag, g, act[:1]],                      # arrays disagree on the number of episodes
+                [obs, ag, g[:, :, :2], act],
+                [obs, ag, g]):
+        with pytest.raises(ValueError):
+            agent.train_cycle(bad, n_batches=2)
+    assert agent.buffer.current_size == 0
+    agent.train_cycle([obs, ag, g, act], n_batches=2)
+    assert agent.buffer.current_size == 2
+
+
+def test_update_normalizer_samples_the_episodes_it_is_given():
+    """ddpg_agent.py:187-212: statistics come from `episode_batch`, whatever the buffer staged last."""
+    agent, rng = make_agent(batch=64, n_eps=32, seed=21)
+    stored = make_episodes(5, seed=2, mode="walk")
+    other = make_episodes(3, seed=40, mode="walk")
+    other[0][:] *= 3.0
+    agent.buffer.store_episode(stored)                     # what the buffer has staged
+    agent._update_normalizer(other)                        # ... is not what the normalizer must see
+    rs = np.random.RandomState(21)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    update_normalizers(on, gn, other, agent.her_module.future_p, rs)
+    assert np.array_equal(bits(agent.o_norm.mean), bits(on.mean)) and np.array_equal(bits(agent.o_norm.std), bits(on.std))
+    assert np.array_equal(bits(agent.g_norm.mean), bits(gn.mean))
+    assert state_equal(rng, *rs.get_state()[1:3])
+    agent._update_normalizer()                             # None: the staged store, as before
+    update_normalizers(on, gn, stored, agent.her_module.future_p, rs)
+    assert np.array_equal(bits(agent.o_norm.mean), bits(on.mean)) and state_equal(rng, *rs.get_state()[1:3])
+    with pytest.raises(ValueError):
+        agent._update_normalizer([a[:, :50] for a in other])
+
+
+def test_select_actions_rounds_like_the_reference():
+    """ddpg_agent.py:174-184 updates the float32 policy output in place; same draws, same float32 bits."""
+    agent, _ = make_agent(batch=64, n_eps=8)
+    pi = torch.tensor([[0.31, -0.2, 0.05, 0.49]], dtype=torch.float32)
+    np.random.seed(3)
+    got = [agent._select_actions(pi.clone()) for _ in range(50)]
+    np.random.seed(3)
+    for a in got:
+        ref = pi.clone().cpu().numpy().squeeze()
+        ref += 0.01 * 0.5 * np.random.randn(*ref.shape)
+        ref = np.clip(ref, -0.5, 0.5)
+        ra = np.random.uniform(low=-0.5, high=0.5, size=4)
+        ref += np.random.binomial(1, 0.3, 1)[0] * (ra - ref)
+        assert a.dtype == np.float32 and np.array_equal(bits(a), bits(ref))
+
+
+def test_default_sampler_stream_is_seeded_from_args_seed():
+    """train.py:36 seeds the global stream with seed + rank before building the agent; an agent built without an explicit
+    stream must not run on numpy's default key."""
+    from rl_arm_under_sparse_reward_amd import random as drandom
+    drandom._global = None                                  # a fresh process-global stream
+    try:
+        args = Args(batch_size=64, buffer_size=800, seed=321)
+        agent = ddpg_agent(args, None, dict(ENV_PARAMS))
+        assert state_equal(agent.rng, *np.random.RandomState(321).get_state()[1:3])
+        drandom._global = None
+        drandom.seed(77)                                    # the launch script seeded it: left alone
+        agent2 = ddpg_agent(args, None, dict(ENV_PARAMS))
+        assert state_equal(agent2.rng, *np.random.RandomState(77).get_state()[1:3])
+    finally:
+        drandom._global = None
+
+
+def test_plot_success_rate_writes_the_reference_file(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    agent, _ = make_agent(batch=64, n_eps=8)
+    agent.success_rates = [0.0, 0.25, 1.0]
+    agent.plot_success_rate()
+    assert np.array_equal(np.load(tmp_path / "test_rates" / "125_False_success_rates.npy"), [0.0, 0.25, 1.0])
 
 
 def test_actor_forward_matches_oracle():

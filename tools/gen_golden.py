@@ -529,6 +529,179 @@ def gen_ddpg_update(ref, out):
     print("ddpg_update.npz: losses", losses)
 
 
+
+def _extract_function(path, name, cls=None):
+    """AST node of a top-level function (or a method of class `cls`) of a reference source file."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if cls is None and isinstance(node, ast.FunctionDef) and node.name == name:
+            return node
+        if cls is not None and isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                    return sub
+    raise KeyError(name)
+
+
+def _reference_agent(ref, n_eps=64, dseed=21, np_seed=125, updates=3):
+    """The reference ddpg_agent after store -> _update_normalizer -> `updates` x _update_network."""
+    import torch
+
+    from rl_arm_under_sparse_reward_amd.synthetic import make_episodes
+
+    torch.set_num_threads(1)
+    env = reference_env()
+    env.compute_reward = env.compute_reward.__get__(env)
+    args = ref.arguments.Args()
+    args.add_demo = False
+    args.cuda = False
+    args.buffer_size = n_eps * 100
+    eps = make_episodes(n_eps, seed=dseed, mode="walk")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(0)
+            with quiet():
+                agent = ref.ddpg_agent.ddpg_agent(args, env, dict(ENV_PARAMS))
+        finally:
+            os.chdir(cwd)
+    np.random.seed(np_seed)
+    agent.buffer.store_episode(eps)
+    agent._update_normalizer([a[:2] for a in eps])
+    for _ in range(updates):
+        agent._update_network()
+    return agent, args
+
+
+def gen_checkpoint(ref, out):
+    """A21 / N2: a checkpoint written by the reference's own save statement (ddpg_agent.py:158-161, lifted out of
+    learn() with `ast` and executed unmodified on a reference agent), plus what the reference's reader
+    (demo_push.py:15-22 process_inputs + models.actor) computes from it on probe observations."""
+    import torch
+
+    agent, args = _reference_agent(ref)
+    learn = _extract_function(os.path.join(REF, "ddpg_agent.py"), "learn", cls="ddpg_agent")
+    saves = [n for n in ast.walk(learn) if isinstance(n, ast.Expr) and isinstance(n.value, ast.Call)
+             and isinstance(n.value.func, ast.Attribute) and n.value.func.attr == "save"
+             and getattr(n.value.func.value, "id", "") == "torch"]
+    assert len(saves) == 1, "expected exactly one torch.save in ddpg_agent.learn"
+    with tempfile.TemporaryDirectory() as tmp:
+        agent.model_path = tmp
+        agent.savetime = 1
+        exec(compile(ast.Module(body=[saves[0]], type_ignores=[]), "ddpg_agent.py:158-161", "exec"),
+             {"torch": torch, "self": agent, "str": str})
+        name = str(args.seed) + "_" + str(args.add_demo) + "1_model.pt"
+        src = os.path.join(tmp, name)
+        assert os.path.exists(src), os.listdir(tmp)
+        blob = open(src, "rb").read()
+    dst = os.path.join(out, "ref_checkpoint_model.pt")
+    with open(dst, "wb") as f:
+        f.write(blob)
+    # the reference's reader: demo_push.py:15-22 (process_inputs, executed unmodified) + models.actor
+    proc = _extract_function(os.path.join(REF, "demo_push.py"), "process_inputs")
+    ns = {"np": np, "torch": torch}
+    exec(compile(ast.Module(body=[proc], type_ignores=[]), "demo_push.py:15-22", "exec"), ns)
+    o_mean, o_std, g_mean, g_std, model = torch.load(dst, map_location=lambda storage, loc: storage, weights_only=False)
+    net = ref.models.actor(dict(ENV_PARAMS))
+    net.load_state_dict(model)
+    net.eval()
+    rs = np.random.RandomState(77)
+    probe_o = rs.uniform(-1, 1, (33, 27))
+    probe_o[3] *= 400.0                                   # beyond clip_obs
+    probe_g = rs.uniform(-0.2, 0.7, (33, 3))
+    acts, xs = [], []
+    with torch.no_grad():
+        for o, g in zip(probe_o, probe_g):
+            x = ns["process_inputs"](o, g, o_mean, o_std, g_mean, g_std, args)
+            xs.append(x.numpy())
+            acts.append(net(x).numpy().squeeze())
+    meta = {k: (tuple(v.shape), str(v.dtype)) for k, v in model.items()}
+    np.savez_compressed(os.path.join(out, "ref_checkpoint_probe.npz"), probe_obs=probe_o, probe_g=probe_g,
+                        inputs=np.array(xs), actions=np.array(acts), o_mean=o_mean, o_std=o_std, g_mean=g_mean,
+                        g_std=g_std, keys=np.array(list(model.keys())),
+                        shapes=np.array([str(meta[k][0]) for k in model]),
+                        clip_obs=np.float64(args.clip_obs), clip_range=np.float64(args.clip_range),
+                        torch_version=np.array(torch.__version__))
+    print("ref_checkpoint_model.pt:", len(blob), "bytes; keys", list(model.keys()))
+
+
+def gen_reference_demo(out, demo_num=6):
+    """A12 / N2: a demo file written by the reference's own generator: get_push_demo (get_demo_data_push.py:24-94,
+    executed unmodified; its module cannot be imported because it pulls in gym + pybullet at the top) driving a
+    stand-in GoalEnv.  The episode contents come from the stand-in; the SCHEMA -- keys, nesting, squeeze, dtypes,
+    the object array of info dicts -- is whatever the reference writer produces."""
+    import math
+
+    from rl_arm_under_sparse_reward_amd.synthetic import PointMassGoalEnv
+
+    fn = _extract_function(os.path.join(REF, "get_demo_data_push.py"), "get_push_demo")
+    ns = {"np": np, "math": math, "demo_num": demo_num, "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "get_demo_data_push.py:24-94", "exec"), ns)
+    env = PointMassGoalEnv(seed=4)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            ns["get_push_demo"](env, env.env_params)
+        finally:
+            os.chdir(cwd)
+        files = os.listdir(tmp)
+        assert files == [f"bmirobot_{demo_num}_push_demo.npz"], files
+        blob = open(os.path.join(tmp, files[0]), "rb").read()
+    dst = os.path.join(out, f"ref_written_{demo_num}_push_demo.npz")
+    with open(dst, "wb") as f:
+        f.write(blob)
+    d = np.load(dst, allow_pickle=True)
+    print(os.path.basename(dst), {k: (d[k].shape, str(d[k].dtype)) for k in d.files})
+
+
+def reference_env_full(reward_type="sparse", distance_threshold=0.05):
+    """Dummy env carrying the reference's compute_reward AND _is_success bodies (bmirobot_env_push_F.py:84-90,243-245)."""
+    path = os.path.join(REF, "bmirobot_env", "bmirobot_env_push_F.py")
+    gd = _extract_function(path, "goal_distance")
+    cr = _extract_function(path, "compute_reward", cls="bmirobotGymEnv")
+    su = _extract_function(path, "_is_success", cls="bmirobotGymEnv")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[gd, cr, su], type_ignores=[]), path, "exec"), ns)
+
+    class _Env:
+        pass
+
+    e = _Env()
+    e.reward_type, e.distance_threshold = reward_type, distance_threshold
+    e.compute_reward = ns["compute_reward"].__get__(e)
+    e._is_success = ns["_is_success"].__get__(e)
+    return e
+
+
+def gen_dense_reward(out):
+    """N4: the dense branch of compute_reward (-d, float64) and _is_success (d < thr, float32) on the adversarial pairs
+    of F3 plus random ones, for two thresholds; outputs of the reference functions themselves."""
+    adv = np.load(os.path.join(out, "reward_adversarial.npz"))
+    rs = np.random.RandomState(6)
+    ag = np.concatenate([adv["ag"], rs.uniform(-1, 1, (1024, 3))])
+    g = np.concatenate([adv["g"], rs.uniform(-1, 1, (1024, 3))])
+    payload = {"ag": ag, "g": g}
+    for thr in (0.05, 0.1):
+        dense = reference_env_full("dense", thr)
+        sparse = reference_env_full("sparse", thr)
+        rd = dense.compute_reward(ag, g, None)
+        sp = sparse.compute_reward(ag, g, None)
+        ok = sparse._is_success(ag, g)
+        assert rd.dtype == np.float64 and sp.dtype == np.float32 and ok.dtype == np.float32
+        tag = f"thr{thr}"
+        payload[tag + "_dense"] = rd
+        payload[tag + "_sparse_bits"] = sp.view(np.uint32)
+        payload[tag + "_success"] = ok
+    # leading-dims vectorisation (her.py:38 passes [B, 3]; rollouts pass [3])
+    payload["stack_ag"] = ag[:60].reshape(5, 4, 3, 3)[..., 0, :].copy()
+    payload["stack_g"] = g[:60].reshape(5, 4, 3, 3)[..., 0, :].copy()
+    payload["stack_dense"] = reference_env_full("dense").compute_reward(payload["stack_ag"], payload["stack_g"], None)
+    np.savez_compressed(os.path.join(out, "reward_dense_success.npz"), **payload)
+    print("reward_dense_success.npz:", ag.shape[0], "pairs; successes at 0.05:", int(payload["thr0.05_success"].sum()))
+
 def gen_demo(out):
     from rl_arm_under_sparse_reward_amd.synthetic import write_demo_npz
 
@@ -543,7 +716,8 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     ref = load_reference()
-    todo = a.only.split(",") if a.only else ["rng", "her", "reward", "storage", "norm", "ddpg", "demo"]
+    todo = a.only.split(",") if a.only else ["rng", "her", "reward", "storage", "norm", "ddpg", "demo", "ckpt", "refdemo",
+                                             "dense"]
     if "rng" in todo:
         gen_rng_kat(ref, a.out)
     if "her" in todo:
@@ -558,6 +732,12 @@ def main():
         gen_ddpg_update(ref, a.out)
     if "demo" in todo:
         gen_demo(a.out)
+    if "ckpt" in todo:
+        gen_checkpoint(ref, a.out)
+    if "refdemo" in todo:
+        gen_reference_demo(a.out)
+    if "dense" in todo:
+        gen_dense_reward(a.out)
 
 
 if __name__ == "__main__":
