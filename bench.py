@@ -309,6 +309,14 @@ def main():
     r.run_steps(a.steps)
     r.run_steps((-r.in_cycle) % N_BATCHES)
     r.sync()
+    # The timed loop is a few Python calls per 40 steps; CPython's generational collector, with torch and numpy loaded,
+    # takes 30-50 ms for a full (generation 2) pass and triggers one after ~150 cycle calls of a fresh process -- a stall
+    # of 700+ steps that is the interpreter's, not the hot path's (tools/ubench/cycle_drift.py).  Long-lived objects are
+    # frozen out of the collector and automatic collection is off while the clock runs, as a training loop would do.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     barrier(world)
     r.run_steps(a.warmup)
     r.sync()
@@ -321,6 +329,7 @@ def main():
     barrier(world)
     r.sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     # cycle-boundary work inside the timed region: [store 2 episodes + normalizer refresh, polyak]; a steady state has
     # one of each per 40 steps
     boundaries = {"store_and_normalizer": r.opens - opens0, "polyak": r.closes - closes0,

@@ -88,11 +88,12 @@ def test_exploration_draws_follow_the_reference_order():
     np.random.seed(4)
     got = agent._select_actions(torch.from_numpy(pi).unsqueeze(0))
     np.random.seed(4)
-    a = pi.astype(np.float64) + agent.args.noise_eps * 0.5 * np.random.randn(4)
+    a = pi.copy()                      # float32, updated in place like the reference's `action += ...`
+    a += agent.args.noise_eps * 0.5 * np.random.randn(4)
     a = np.clip(a, -0.5, 0.5)
     ra = np.random.uniform(-0.5, 0.5, 4)
     a += np.random.binomial(1, agent.args.random_eps, 1)[0] * (ra - a)
-    assert np.array_equal(got, a)
+    assert got.dtype == np.float32 and np.array_equal(got, a)
 
 
 def test_learn_reaches_goals_on_the_point_mass(tmp_path):
