@@ -35,4 +35,5 @@ class Args:
     env_name: str = "bmirobot_push seed125"
     distance_threshold: float = 0.05    # bmirobot_push_F.py:20 / bmirobot_pickandplace_v2.py:19
     reward_type: str = "sparse"         # bmirobot_push_F.py:9; "dense" = -distance (compute_reward :89-90)
+    share_numpy_stream: bool = True     # learn(): one random stream for exploration + sampler, like the reference's np.random
     grad_reduce: str = "sum"            # data-parallel gradient exchange: "sum" = utils.py:47 (reference), or "mean"

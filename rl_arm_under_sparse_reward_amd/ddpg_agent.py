@@ -378,13 +378,25 @@ class ddpg_agent:
         return [np.array(a) for a in mb]
 
     def learn(self):
-        """ddpg_agent.py:92-161 with the learner half on the device."""
+        """ddpg_agent.py:92-161 with the learner half on the device.
+
+        The reference draws exploration noise (:177-183), overflow slots (replay_buffer.py:64,67) and HER indices
+        (her.py:24-31) from ONE stream, numpy's global one.  With `args.share_numpy_stream` (default) that single stream
+        is handed to the device for the learner phase of every cycle and taken back before the next rollout, so a run
+        seeded like train.py:34-39 consumes exactly the reference's random words in the reference's order (with one
+        environment; a list of environments is stepped in lockstep, which reorders the exploration draws).  The
+        hand-back synchronises, which the next rollout needs anyway: it evaluates the updated actor."""
+        share = bool(getattr(self.args, "share_numpy_stream", True))
+        print("initial buffer size:", self.buffer.current_size)                  # :97
         for epoch in range(self.args.n_epochs):
             start = time.time()
             for _ in range(self.args.n_cycles):
-                # the exploration noise uses numpy's global stream; the device stream is the sampler's
                 episodes = self.collect_episodes(self.args.num_rollouts_per_mpi, epoch)
+                if share:
+                    self.rng.set_state(np.random.get_state())
                 self.train_cycle(episodes)
+                if share:
+                    np.random.set_state(self.rng.get_state())
             self.ctx.synchronize()
             print(str(time.time() - start))
             rate = self._eval_agent()

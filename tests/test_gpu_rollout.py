@@ -115,3 +115,42 @@ def test_learn_reaches_goals_on_the_point_mass(tmp_path):
     assert agent.buffer.current_size == 14 * 10 * 2
     saved = sorted(p.name for p in (tmp_path / "point_mass").iterdir())
     assert len(saved) == 14 and all(name.endswith("_model.pt") for name in saved)
+
+
+def test_learn_follows_the_reference_run_on_the_stand_in_env(tmp_path):
+    """learn() end to end against tests/golden/rollout.npz = the reference's own learn() on this env (N1 + N3): with the
+    single shared random stream the device run consumes exactly the reference's random words (final MT19937 state
+    bit-identical: every exploration draw, overflow slot and HER index in the reference's order), stores the same
+    episodes and reports the same evaluation success rates.  Episode values carry the float32 rounding differences of
+    the actor forward through the closed loop (point mass: contractive), hence the small absolute tolerances."""
+    from conftest import load_golden
+    from gpu_common import state_equal
+    from rl_arm_under_sparse_reward_amd.ddpg_agent import NET_ACTOR, NET_CRITIC
+    g = load_golden("rollout.npz")
+    c = {k: (float(v) if "." in v else int(v)) for k, v in g["cfg"]}
+    env = PointMassGoalEnv(seed=c["env_seed"], max_timesteps=100, distance_threshold=c["distance_threshold"])
+    args = Args(n_epochs=c["n_epochs"], n_cycles=c["n_cycles"], n_batches=c["n_batches"], n_test_rollouts=c["n_test_rollouts"],
+                noise_eps=c["noise_eps"], random_eps=c["random_eps"], buffer_size=c["buffer_episodes"] * 100,
+                save_dir=str(tmp_path), env_name="stand_in")
+    agent = ddpg_agent(args, env, env.env_params, rng=fresh_rng(0))
+    agent._set_flat(NET_ACTOR, g["init_actor"]); agent._set_flat(NET_CRITIC, g["init_critic"])
+    agent.lib.hp_agent_sync_targets(agent.h)
+    stored = []
+    orig = agent.train_cycle
+    agent.train_cycle = lambda eps, n_batches=None: (stored.append([np.array(a) for a in eps]), orig(eps, n_batches))[1]
+    np.random.seed(c["np_seed"])
+    agent.learn()
+    assert len(stored) == c["n_epochs"] * c["n_cycles"]
+    for i, batch in enumerate(stored):
+        tol = 2e-6 if i == 0 else 2e-4          # cycle 0: untouched initial weights; later cycles: fp32 updates in between
+        for nm, a in zip(("obs", "ag", "g", "actions"), batch):
+            want = g[f"cycle{i}_{nm}"].astype(np.float64)
+            assert a.shape == want.shape and float(np.abs(a - want).max()) <= tol, (i, nm, float(np.abs(a - want).max()))
+    key, pos = np.random.get_state()[1:3]
+    assert np.array_equal(key, g["key"]) and pos == int(g["pos"])            # same words, same order, to the last draw
+    assert state_equal(agent.rng, g["key"], g["pos"])
+    assert np.allclose(agent.success_rates, g["success_rates"], atol=1.0 / c["n_test_rollouts"] + 1e-9)
+    assert np.allclose(agent.o_norm.mean, g["o_mean"], atol=1e-5) and np.allclose(agent.g_norm.std, g["g_std"], atol=1e-5)
+    rel = np.linalg.norm(agent._get_flat(NET_ACTOR) - g["actor_final"]) / np.linalg.norm(g["actor_final"] - g["init_actor"])
+    assert rel <= 0.1, rel
+    assert sorted(p.name for p in (tmp_path / "stand_in").iterdir()) == list(g["checkpoints"])

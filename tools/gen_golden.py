@@ -702,6 +702,80 @@ def gen_dense_reward(out):
     np.savez_compressed(os.path.join(out, "reward_dense_success.npz"), **payload)
     print("reward_dense_success.npz:", ag.shape[0], "pairs; successes at 0.05:", int(payload["thr0.05_success"].sum()))
 
+
+ROLLOUT_CFG = dict(env_seed=11, np_seed=5, torch_seed=0, n_epochs=2, n_cycles=2, n_batches=3, n_test_rollouts=12,
+                   noise_eps=0.05, random_eps=0.3, buffer_episodes=64, distance_threshold=0.25)
+
+
+def gen_rollout(ref, out):
+    """N1 / N3: the reference's own learn() (rollout loop, exploration draws, store, normalizer, updates, polyak,
+    _eval_agent, checkpoint) on the package's stand-in GoalEnv; every episode batch it stores, its success rates, the
+    RNG state it ends in and its final parameters.  Cross-checked bit for bit against oracle/rollout.py."""
+    import torch
+
+    from oracle.rollout import OracleAgent
+    from rl_arm_under_sparse_reward_amd.synthetic import PointMassGoalEnv
+
+    torch.set_num_threads(1)
+    c = ROLLOUT_CFG
+    env = PointMassGoalEnv(seed=c["env_seed"], max_timesteps=100, distance_threshold=c["distance_threshold"])
+    env_params = env.env_params
+    args = ref.arguments.Args()
+    args.n_epochs, args.n_cycles, args.n_batches = c["n_epochs"], c["n_cycles"], c["n_batches"]
+    args.n_test_rollouts, args.noise_eps, args.random_eps = c["n_test_rollouts"], c["noise_eps"], c["random_eps"]
+    args.buffer_size, args.add_demo, args.cuda = c["buffer_episodes"] * 100, False, False
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(c["torch_seed"])
+            with quiet():
+                agent = ref.ddpg_agent.ddpg_agent(args, env, dict(env_params))
+            init_actor = {k: v.detach().clone() for k, v in agent.actor_network.state_dict().items()}
+            init_critic = {k: v.detach().clone() for k, v in agent.critic_network.state_dict().items()}
+            stored = []
+            orig_store = agent.buffer.store_episode
+
+            def spy(batch):
+                stored.append([np.array(a, copy=True) for a in batch])
+                return orig_store(batch)
+
+            agent.buffer.store_episode = spy
+            np.random.seed(c["np_seed"])
+            with quiet():
+                agent.learn()
+            saved = sorted(os.listdir(agent.model_path))
+        finally:
+            os.chdir(cwd)
+    key, pos = np.random.get_state()[1:3]
+    assert len(stored) == c["n_epochs"] * c["n_cycles"] and len(saved) == c["n_epochs"]
+    assert stored[0][3].dtype == np.float32      # the reference stores float32 actions (in-place `action +=`, :177)
+    # ---- oracle cross-check: same seeds, same env, bit for bit
+    env2 = PointMassGoalEnv(seed=c["env_seed"], max_timesteps=100, distance_threshold=c["distance_threshold"])
+    np.random.seed(c["np_seed"])
+    oa = OracleAgent(env2, env_params, init_actor, init_critic, buffer_size=args.buffer_size, batch_size=args.batch_size,
+                     replay_k=args.replay_k, n_batches=args.n_batches, num_rollouts=args.num_rollouts_per_mpi,
+                     n_test_rollouts=args.n_test_rollouts, noise_eps=args.noise_eps, random_eps=args.random_eps)
+    oa.learn_epochs(c["n_epochs"], c["n_cycles"])
+    for a, b in zip(stored, oa.episodes):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    assert [float(r) for r in agent.success_rates] == [float(r) for r in oa.success_rates]
+    assert np.array_equal(np.random.get_state()[1], key) and np.random.get_state()[2] == pos
+    actor_final = ref.utils._get_flat_params(agent.actor_network)[0]
+    assert np.array_equal(actor_final, oa.learner.flat("actor"))
+    from oracle import ddpg_update as oupd
+    payload = dict(cfg=np.array(sorted(c.items()), dtype=object).astype(str), init_actor=oupd.flatten(list(init_actor.values())),
+                   init_critic=oupd.flatten(list(init_critic.values())), success_rates=np.array(agent.success_rates, np.float64),
+                   actor_final=actor_final, critic_final=ref.utils._get_flat_params(agent.critic_network)[0],
+                   o_mean=agent.o_norm.mean, o_std=agent.o_norm.std, g_mean=agent.g_norm.mean, g_std=agent.g_norm.std,
+                   key=key.astype(np.uint32), pos=np.int32(pos), checkpoints=np.array(saved))
+    for i, b in enumerate(stored):
+        for nm, a in zip(("obs", "ag", "g", "actions"), b):
+            payload[f"cycle{i}_{nm}"] = a
+    np.savez_compressed(os.path.join(out, "rollout.npz"), **payload)
+    print("rollout.npz:", len(stored), "stored batches; success rates", [float(r) for r in agent.success_rates], saved)
+
 def gen_demo(out):
     from rl_arm_under_sparse_reward_amd.synthetic import write_demo_npz
 
@@ -717,7 +791,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     ref = load_reference()
     todo = a.only.split(",") if a.only else ["rng", "her", "reward", "storage", "norm", "ddpg", "demo", "ckpt", "refdemo",
-                                             "dense"]
+                                             "dense", "rollout"]
     if "rng" in todo:
         gen_rng_kat(ref, a.out)
     if "her" in todo:
@@ -738,6 +812,8 @@ def main():
         gen_reference_demo(a.out)
     if "dense" in todo:
         gen_dense_reward(a.out)
+    if "rollout" in todo:
+        gen_rollout(ref, a.out)
 
 
 if __name__ == "__main__":
