@@ -292,6 +292,10 @@ int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_l
 /* diagnostic: stage-boundary time stamps (100 MHz ticks) of the slab kernels; only a build with
  * -DSLAB_TIMELINE writes them (tools/ubench/), a production build returns zeros */
 int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);
+/* diagnostic: number of single-launch updates issued so far (chain kernel with the weight-gradient tiles and the
+ * optimizer as its second phase) and the sticky error word of their in-kernel hand-off (0 in a healthy run).
+ * Synchronises. */
+int hp_agent_fused_status(hp_agent *ag, int64_t *fused_launches, uint32_t *error);
 int hp_agent_profile(hp_agent *ag, int32_t enable);
 int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
 

@@ -93,33 +93,19 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #define LOSS_LOG 4096
 
 #include "slab.h"
-// the 4x4x1 slab engine, compiled for two slab heights (see slab8.h)
-#define S8_NRG 1
-#define S8_NS s8r4
-#include "slab8.h"
-#undef S8_NRG
-#undef S8_NS
-#define S8_NRG 2
-#define S8_NS s8r8
-#include "slab8.h"
-#undef S8_NRG
-#undef S8_NS
-#define S8_NRG 4
-#define S8_NS s8r16
-#include "slab8.h"
-#undef S8_NRG
-#undef S8_NS
-#undef S8_ROWS
-#undef S8_RING
-#undef S8_RPW
-
 // Adam (torch.optim.Adam, _single_tensor_adam, no weight decay / amsgrad) on one arena element, plus the
 // fragment-ordered copies of the slab engines.  Shared by k_adam_frag and the weight-gradient GEMM epilogue
 // (single-rank runs fuse the optimizer into the GEMM; data-parallel runs all-reduce the gradients in between).
 struct AdamFuse {
-    float *p, *m, *v, *fragF, *fragD;
+    const float *p;                   // parameters the step starts from (canonical arena)
+    float *p_out;                     // ... and where the stepped parameters go: p itself, or the other set of the fused
+                                      // single-launch update, whose chains still read p / its fragment copies while tiles finish
+    float *m, *v, *fragF, *fragD;     // fragF / fragD: fragment-ordered copies of p_out
     const float *grads_base;          // arena origin of the gradient buffer the GEMM writes
     AgentDevState *st;
+    const float *scal;                // {-lr_actor / bc1, -lr_critic / bc1, sqrt(bc2)} of the step being applied: the three
+                                      // scalars in *st (written by the kernel before), or this update's row of the fused
+                                      // path's per-sequence table (k_seq_begin)
     ArenaMap am;
     int n_actor;
     float w, b2, omb2, eps;
@@ -131,15 +117,15 @@ struct AdamFuse {
 };
 
 __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
-    const float neg_step_size = (idx < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
-    const float bc2_sqrt = F.st->bc2_sqrt;
+    const float neg_step_size = F.scal[idx < F.n_actor ? 0 : 1];
+    const float bc2_sqrt = F.scal[2];
     float mi = F.m[idx], vi = F.v[idx];
     mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
     const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
     const float pn = __fadd_rn(F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
-    F.p[idx] = pn;
+    F.p_out[idx] = pn;
     F.m[idx] = mi;
     F.v[idx] = vi;
     int of, od;
@@ -156,8 +142,8 @@ struct AdamState4 {   // optimizer state of 4 consecutive elements + the step sc
     float neg_step_size, bc2_sqrt;
 };
 __device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, int idx0) {
-    S.neg_step_size = (idx0 < F.n_actor) ? F.st->neg_step_actor : F.st->neg_step_critic;
-    S.bc2_sqrt = F.st->bc2_sqrt;
+    S.neg_step_size = F.scal[idx0 < F.n_actor ? 0 : 1];
+    S.bc2_sqrt = F.scal[2];
     S.p = *reinterpret_cast<const float4 *>(F.p + idx0);
     S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
     S.v = *reinterpret_cast<const float4 *>(F.v + idx0);
@@ -181,7 +167,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
         pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(neg_step_size, mm[j]), denom));
     }
-    *reinterpret_cast<float4 *>(F.p + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     if (F.am.mode == 1) {
@@ -209,10 +195,10 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
 __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
     const int lane = threadIdx.x;
     float tc = 0.f, tq = 0.f, tl = 0.f;
-    for (int s = lane; s < F.nslab; s += 64) {
-        tc += F.part[s];
-        tq += F.part[F.nslab + s];
-        tl += F.part[2 * F.nslab + s];
+    for (int s = lane; s < F.nslab; s += 64) {   // agent-scope loads: in the fused kernel the chains of this launch wrote them
+        tc += __hip_atomic_load(F.part + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tq += __hip_atomic_load(F.part + F.nslab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tl += __hip_atomic_load(F.part + 2 * F.nslab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int o = 32; o > 0; o >>= 1) {
         tc += __shfl_down(tc, o);
@@ -229,6 +215,27 @@ __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
 }
 
 #include "gemm_lds.h"
+
+// the 4x4x1 slab engine, compiled for two slab heights (see slab8.h)
+#define S8_NRG 1
+#define S8_NS s8r4
+#include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
+#define S8_NRG 2
+#define S8_NS s8r8
+#include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
+#define S8_NRG 4
+#define S8_NS s8r16
+#include "slab8.h"
+#undef S8_NRG
+#undef S8_NS
+#undef S8_ROWS
+#undef S8_RING
+#undef S8_RPW
+
 
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
@@ -260,6 +267,16 @@ struct hp_agent {
     // RLARM_FB_PREFETCH (-1 = by size, 0 = off, 1 = on)
     bool gemm_pipe = true, gemm_xcd = true;
     int fb_xcd = -1, fb_prefetch = -1;
+    // fused single-launch update (FuseArgs in slab8.h): second parameter set the optimizer epilogue writes while the chains
+    // of the same launch still read the first, hand-off counters, per-sequence Adam scalars, device copies of the
+    // weight-gradient problem table (one per input set)
+    float *params_b = nullptr, *fragF_b = nullptr, *fragD_b = nullptr;
+    FuseSync *fsync = nullptr;
+    GemmGroup *d_grp = nullptr;          // [2]
+    int dw_tiles = 0;
+    DevBuf adam_tab;                     // float[4] per update of a sequence (sized with the index plan)
+    bool fuse_dw_ok = false;             // RLARM_FUSE_DW=1: single-launch updates (default: chain kernel + tile kernel)
+    long long fused_launches = 0;
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -601,6 +618,31 @@ __global__ void k_polyak(float *__restrict__ tgt, const float *__restrict__ src,
     tgt[idx] = __fadd_rn(__fmul_rn(one_minus, src[idx]), __fmul_rn(polyak, tgt[idx]));
 }
 
+// Fused single-launch updates, once per sequence of n updates: zero the hand-off counters and tabulate the Adam step
+// scalars of every update of the sequence (bias corrections of step + u + 1: torch computes them in Python doubles),
+// so that no workgroup of the fused launches has to wait for a pow().  k_seq_end moves the step counter on.
+__global__ void k_seq_begin(const AgentDevState *st, FuseSync *sync, float *tab, int n, const AdamCfg c) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u == 0) {
+        sync->chains_done = 0ull;
+        // `error` is sticky: hp_agent_fused_status reports it
+    }
+    if (u >= n) return;
+    const double step = (double)(st->step + u + 1);
+    const double bc1 = 1.0 - pow(c.beta1, step);
+    const double bc2 = 1.0 - pow(c.beta2, step);
+    tab[4 * u + 0] = (float)(-(c.lr_actor / bc1));
+    tab[4 * u + 1] = (float)(-(c.lr_critic / bc1));
+    tab[4 * u + 2] = (float)sqrt(bc2);
+    tab[4 * u + 3] = 0.f;
+}
+__global__ void k_seq_end(AgentDevState *st, int n, const AdamCfg c) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->step += n;
+        adam_prepare(st, c);   // keeps the scalars in *st those of the last applied step, as the two-launch path leaves them
+    }
+}
+
 // slab engine: Adam that also refreshes the fragment-ordered copies and finishes the loss log
 __global__ __launch_bounds__(256) void k_adam_frag(const AdamFuse F, const float *__restrict__ g, int n) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -823,6 +865,8 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     int xset = 0;
     bool pregathered = false;
     const PlanRec *ahead_plan = nullptr;
+    // fused single-launch update: index of this update in its sequence (-1: chain kernel + tile kernel as two launches)
+    int fuse_u = -1;
 };
 
 static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam);
@@ -995,6 +1039,26 @@ static int enqueue_relayout(hp_agent *a, bool targets) {
     return HP_OK;
 }
 
+// all weight gradients of one update: the only products that reduce over the batch (input sets sXA / sXP)
+static Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP) {
+    const int H = a->H, Mp = a->Mp, ldx = a->ldx;
+    const NetLayout &la = a->la, &lc = a->lc;
+    float *Ga = a->grads, *Gc = a->grads + la.total;
+    Launch L;
+    // the four 256 x 256 problems first: Launch::place_on_xcds gives each of them one pair of XCDs
+    add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
+    add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
+    add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
+    add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+    add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+    add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+    add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+    add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+    if (a->gemm_xcd) L.place_on_xcds();
+    L.g.pipe = a->gemm_pipe ? 1 : 0;
+    return L;
+}
+
 // slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
 static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
@@ -1004,6 +1068,12 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     FbSlabArgs P;
     const int xs = gc ? gc->xset : 0;
     float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
+    // fused single-launch update: this update's chains read parameter set (u & 1), its optimizer epilogue writes the other
+    const bool fused = a->slab8 && fuse_adam && gc && gc->fuse_u >= 0;
+    const int rset = fused ? (gc->fuse_u & 1) : 0;
+    const SlabNetPtrs online = rset ? SlabNetPtrs{a->fragF_b, a->fragD_b, a->params_b}
+                                    : SlabNetPtrs{a->fragF, a->fragD, a->params};
+    memset(&P.fuse, 0, sizeof(P.fuse));
     {
         FwdSlabArgs &A = P.f;
         A.tl = a->timeline;
@@ -1019,7 +1089,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             A.gs.T = b->T; A.gs.obs_dim = b->obs_dim; A.gs.goal_dim = b->goal_dim; A.gs.B = a->B;
             A.gs.R = sR;
         }
-        A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
+        A.online = online;
         A.target = SlabNetPtrs{a->fragFT, nullptr, a->targets};
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim; A.Mp = Mp;
         A.max_action = (float)a->cfg.max_action;
@@ -1033,7 +1103,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     {
         BwdSlabArgs &A = P.b;
         A.tl = a->timeline + 96;
-        A.online = SlabNetPtrs{a->fragF, a->fragD, a->params};
+        A.online = online;
         A.la = la; A.lc = lc; A.H = H; A.ldx = ldx; A.act_off = a->act_off; A.act_dim = a->cfg.act_dim;
         A.B = a->B; A.Mp = Mp;
         A.max_action = (float)a->cfg.max_action; A.gamma = (float)a->cfg.gamma;
@@ -1074,7 +1144,26 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         // without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs 54.2 at 512, 56.6 vs 57.1 at 768
         P.n_pref = (a->fb_prefetch >= 0 ? a->fb_prefetch == 1
                                         : 2 * nslab + P.n_plan + P.n_ahead + 8 <= a->ctx->cu_count) ? 8 : 0;
-        const unsigned grid = 2 * nslab + P.n_plan + P.n_ahead + P.n_pref;
+        unsigned grid = 2 * nslab + P.n_plan + P.n_ahead + P.n_pref;
+        if (fused) {
+            AdamFuse F = adam_fuse(a);
+            F.p = online.canon;
+            F.p_out = rset ? a->params : a->params_b;
+            F.fragF = rset ? a->fragF : a->fragF_b;
+            F.fragD = rset ? a->fragD : a->fragD_b;
+            F.scal = a->adam_tab.as<float>() + 4 * (size_t)gc->fuse_u;
+            F.keep_grads = 0;            // nobody reads the gradient vector inside a sampled update loop
+            P.fuse.on = 1;
+            P.fuse.u = gc->fuse_u;
+            P.fuse.n_tiles = a->dw_tiles;
+            P.fuse.sync = a->fsync;
+            P.fuse.grp = a->d_grp + xs;
+            P.fuse.adam = F;
+            // idle CUs hold pure tile workers: one workgroup per CU (LDS), chains first in dispatch order
+            const unsigned cus = (unsigned)a->ctx->cu_count;
+            if (grid < cus) grid = cus;
+            a->fused_launches += 1;
+        }
         if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
         else if (a->s8_rows == 8)
@@ -1094,20 +1183,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             HP_CHECK_HIP(hipGetLastError());
         }
     }
-    {   // all weight gradients: the only products that reduce over the batch
-        float *Ga = a->grads, *Gc = a->grads + la.total;
-        Launch L;
-        // the four 256 x 256 problems first: Launch::place_on_xcds gives each of them one pair of XCDs
-        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
-        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
-        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
-        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
-        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
-        add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
-        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
-        add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
-        if (a->gemm_xcd) L.place_on_xcds();
-        L.g.pipe = a->gemm_pipe ? 1 : 0;
+    if (!fused) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
+        Launch L = build_dw_group(a, sXA, sXP);
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
@@ -1125,8 +1202,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
 
 static AdamFuse adam_fuse(hp_agent *a) {
     AdamFuse F;
-    F.p = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
-    F.grads_base = a->grads; F.st = a->d_state; F.am = arena_map(a); F.n_actor = a->la.total;
+    F.p = a->params; F.p_out = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
+    F.grads_base = a->grads; F.st = a->d_state; F.scal = &a->d_state->neg_step_actor; F.am = arena_map(a); F.n_actor = a->la.total;
     F.keep_grads = 1;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
@@ -1177,6 +1254,7 @@ static int ensure_plan(hp_agent *a, int n_batches) {
         // plan frees that memory, so the graph goes with it (rebuilt by the next hp_agent_train_cycle)
         drop_graph(a);
         HP_TRY(a->plan.ensure((size_t)n_batches * a->B * sizeof(PlanRec)));
+        HP_TRY(a->adam_tab.ensure((size_t)n_batches * 4 * sizeof(float)));
         a->plan_batches = n_batches;
     }
     return HP_OK;
@@ -1203,6 +1281,17 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // of update u+1 from a plan that an earlier launch finished (the order of draws in the stream is unchanged)
     const bool ahead = ride && a->slab8 && a->gather_ahead;
     const int lead = ahead ? 2 : 1;
+    // Single-launch updates: the weight-gradient tiles and the optimizer run as a second phase of the chain kernel
+    // (slab8.h FuseArgs).  Needs the optimizer to follow the gradients directly (one rank) and every chain workgroup
+    // resident at once (one per CU: the tile phase starts when ALL chains have published).
+    const int chains = 2 * (a->Mp / a->s8_rows);
+    const bool fuse_dw = a->slab8 && with_adam && !a->comm && a->fuse_adam_ok && a->fuse_dw_ok && a->d_grp &&
+                         chains <= a->ctx->cu_count;
+    if (fuse_dw) {
+        hipLaunchKernelGGL(k_seq_begin, dim3((n_updates + 63) / 64), dim3(64), 0, a->ctx->stream, a->d_state, a->fsync,
+                           a->adam_tab.as<float>(), n_updates, adam_cfg(a));
+        HP_CHECK_HIP(hipGetLastError());
+    }
     {
         ProfScope ps(a, PROF_PLAN);
         HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? (n_updates < lead ? n_updates : lead) : n_updates,
@@ -1220,6 +1309,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             gc.pregathered = u > 0;
             if (u + 1 < n_updates) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
+        if (fuse_dw) gc.fuse_u = u;
         bool fused = false;
         HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm, &fused));
         if (with_adam) {
@@ -1230,6 +1320,19 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
                                     : comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
             if (!fused) HP_TRY(enqueue_adam(a));
         }
+    }
+    if (fuse_dw) {
+        hipStream_t s = a->ctx->stream;
+        if (n_updates & 1) {
+            // update u wrote parameter set (u + 1) & 1: after an odd count the live parameters sit in set b.  Between API
+            // calls they always live in set a (what every other entry point, graph and kernel argument refers to).
+            const size_t nb = sizeof(float) * (size_t)a->n_arena;
+            HP_CHECK_HIP(hipMemcpyAsync(a->params, a->params_b, nb, hipMemcpyDeviceToDevice, s));
+            HP_CHECK_HIP(hipMemcpyAsync(a->fragF, a->fragF_b, nb, hipMemcpyDeviceToDevice, s));
+            HP_CHECK_HIP(hipMemcpyAsync(a->fragD, a->fragD_b, nb, hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(64), 0, s, a->d_state, n_updates, adam_cfg(a));
+        HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;
 }
@@ -1373,6 +1476,9 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->fb_xcd = tri("RLARM_FB_XCD");
         a->fb_prefetch = tri("RLARM_FB_PREFETCH");
         a->upd_graph_ok = tri("RLARM_UPDATE_GRAPH") != 0;
+        // measured slower than two launches (48.2 vs 40.8 us/update at batch 256: the in-kernel hand-off costs ~4 us and a
+        // tile ~7 us warm, profiles/r02_fused_single_launch.txt), so it is opt-in
+        a->fuse_dw_ok = tri("RLARM_FUSE_DW") == 1;
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
         // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
@@ -1382,6 +1488,22 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
+    if (st == HP_OK && a->slab8) {   // fused single-launch update (slab8.h FuseArgs)
+        A(&a->params_b, a->n_arena); A(&a->fragF_b, a->n_arena); A(&a->fragD_b, a->n_arena);
+        if (st == HP_OK) st = dev_alloc(a, &a->fsync, 1);
+        if (st == HP_OK) st = dev_alloc(a, &a->d_grp, 2);
+        if (st == HP_OK) {
+            GemmGroup g2[2];
+            for (int xs = 0; xs < 2; ++xs) {
+                const Launch L = build_dw_group(a, xs ? a->XA2 : a->XA, xs ? a->XP2 : a->XP);
+                g2[xs] = L.g;
+                a->dw_tiles = L.tiles;
+            }
+            if (hipMemcpyAsync(a->d_grp, g2, sizeof(g2), hipMemcpyHostToDevice, a->ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(a->ctx->stream) != hipSuccess)
+                st = HP_ERR_HIP;
+        }
+    }
     if (st == HP_OK && hipEventCreate(&a->ev0) != hipSuccess) st = HP_ERR_HIP;
     if (st == HP_OK && hipEventCreate(&a->ev1) != hipSuccess) st = HP_ERR_HIP;
     if (st == HP_OK) st = ensure_plan(a, 1);
@@ -1979,6 +2101,24 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
     return HP_OK;
 }
 
+// diagnostic: fused single-launch updates issued so far, and the device's sticky hand-off error word (a bounded spin of
+// the tile phase gave up: only possible when the chain workgroups of a launch were not all resident).  Synchronises.
+int hp_agent_fused_status(hp_agent *a, int64_t *fused_launches, uint32_t *error) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_fused_status: null handle");
+    HP_SERIALISE(a);
+    if (fused_launches) *fused_launches = a->fused_launches;
+    if (error) {
+        *error = 0;
+        if (a->fsync) {
+            FuseSync h;
+            HP_CHECK_HIP(hipMemcpyAsync(&h, a->fsync, sizeof(h), hipMemcpyDeviceToHost, a->ctx->stream));
+            HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+            *error = h.error;
+        }
+    }
+    return HP_OK;
+}
+
 int hp_agent_profile(hp_agent *a, int32_t enable) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_profile: null handle");
     HP_SERIALISE(a);
@@ -2008,6 +2148,7 @@ void hp_agent_destroy(hp_agent *a) {
     (void)hipStreamSynchronize(a->ctx->stream);
     for (void *p : a->owned) (void)hipFree(p);
     a->plan.release();
+    a->adam_tab.release();
     a->norm_plan.release();
     a->fwd_ws.release();
     a->pin.release();

@@ -35,6 +35,7 @@ __device__ unsigned long long g_gemm_tl[32];
 #endif
 
 // stage one 32 x kc operand chunk into LDS.  `valid` = number of real rows/cols (16 or 32).
+template <int AUX = 0>
 __device__ __forceinline__ void gl_stage(float *lds, const float *base, long long s_idx, long long s_k, int valid,
                                          int kc, bool rowk) {
     const int tid = threadIdx.x;
@@ -61,7 +62,8 @@ __device__ __forceinline__ void gl_stage(float *lds, const float *base, long lon
             const int k = rowp ^ ((rowp >> 3) & 1);
             int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
             gch = gch < nchunk ? gch : nchunk - 1;
-            __builtin_amdgcn_global_load_lds(base + k * s_k + 4 * gch, lds + R * 32, 16, 0, 0);
+            // AUX = 16 (sc1): operands another workgroup of the SAME launch published write-through (fused update kernel)
+            __builtin_amdgcn_global_load_lds(base + k * s_k + 4 * gch, lds + R * 32, 16, 0, AUX);
         }
     }
 }
@@ -82,6 +84,7 @@ __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag,
 // the transfer; hipcc reloads M0 in front of every instruction of its own that reads it.)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+template <int AUX = 0>
 __device__ __forceinline__ void gl_stage_kmajor_async(float *lds, const float *base, long long s_k, int valid, int kc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nchunk = valid >> 2;
@@ -91,8 +94,12 @@ __device__ __forceinline__ void gl_stage_kmajor_async(float *lds, const float *b
         int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
         gch = gch < nchunk ? gch : nchunk - 1;
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + R * 32));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
-                     : "memory", "m0");
+        if constexpr (AUX == 16)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
+                         : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
+                         : "memory", "m0");
     }
 }
 #pragma clang diagnostic pop
@@ -123,28 +130,32 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 // the tile it just produced (gradient still written out for inspection), and workgroup 0 finishes the loss log --
 // one launch and one cold pass over p/m/v less per update.  Data-parallel runs use ADAM = false + k_adam_frag so the
 // gradients can be all-reduced in between.
-template <bool ADAM>
-__device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * GL_OPERAND_FLOATS];  // A image | B image; reused for the reduction
-    __shared__ float bsum[GL_WAVES][32];
+// One 32 x 32 output tile.  bx = the tile's index in the group's launch order (blockIdx.x of the stand-alone kernels);
+// lds / bsum = GL_LDS_FLOATS / GL_WAVES * 32 floats of workgroup LDS.  AUX = cache policy of the operand staging loads
+// (16 = sc1 for operands published by other workgroups of the same launch); FIRST = this workgroup's first tile
+// (the fused kernel walks several tiles and finalises the loss elsewhere).
+#define GL_LDS_FLOATS (2 * GL_OPERAND_FLOATS)
+template <bool ADAM, int AUX = 0>
+__device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F, int bx, float *lds, float (*bsum)[32],
+                                          bool finalize_loss) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_PROBS; ++i)
-        if (i < grp.n && (int)blockIdx.x >= grp.p[i].tile0) pi = i;
-    const bool placed = grp.xcd && blockIdx.x < 256;   // Launch::place_on_xcds
-    if (placed) pi = (blockIdx.x & 7) >> 1;
+        if (i < grp.n && bx >= grp.p[i].tile0) pi = i;
+    const bool placed = grp.xcd && bx < 256;   // Launch::place_on_xcds
+    if (placed) pi = (bx & 7) >> 1;
     const GemmProb &p = grp.p[pi];
-    const int t = blockIdx.x - p.tile0;
+    const int t = bx - p.tile0;
     int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-    if (placed) {   // XCD x = blockIdx & 7: problem x / 2, row-panel half x % 2, all 8 column panels
-        const int slot = blockIdx.x >> 3;
-        tm = (blockIdx.x & 1) * 4 + (slot >> 3);
+    if (placed) {   // XCD x = bx & 7: problem x / 2, row-panel half x % 2, all 8 column panels
+        const int slot = bx >> 3;
+        tm = (bx & 1) * 4 + (slot >> 3);
         tn = slot & 7;
     }
     const int m0 = tm * 32, n0 = tn * 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
-    if (ADAM && blockIdx.x == 0 && tid < 64) loss_finalize(*F);
+    if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
     float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
@@ -181,8 +192,8 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         // three chunks in flight measured the same: beyond 256 rows the kernel moves ~6.5 TB/s out of the L2s either
         // way, 74.0 vs 72.8 us/update at batch 1024.)
         constexpr int KH = GL_KC / 2, IMG = KH * 32;   // 4 images of 16 KB in the 72 KB
-        gl_stage_kmajor_async(lds, Abase, p.a_sk, vm, KH);
-        gl_stage_kmajor_async(lds + IMG, Bbase, p.b_sk, vn, KH);
+        gl_stage_kmajor_async<AUX>(lds, Abase, p.a_sk, vm, KH);
+        gl_stage_kmajor_async<AUX>(lds + IMG, Bbase, p.b_sk, vn, KH);
         int c = 0;
         for (int k0 = 0; k0 < p.K; k0 += KH, ++c) {
             const int kc = (p.K - k0) < KH ? (p.K - k0) : KH;
@@ -192,8 +203,8 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
             const float *cur = lds + (c & 1) * 2 * IMG;
             float *nxt = lds + ((c + 1) & 1) * 2 * IMG;
             if (kn > 0) {
-                gl_stage_kmajor_async(nxt, Abase + (long long)k1 * p.a_sk, p.a_sk, vm, kn);
-                gl_stage_kmajor_async(nxt + IMG, Bbase + (long long)k1 * p.b_sk, p.b_sk, vn, kn);
+                gl_stage_kmajor_async<AUX>(nxt, Abase + (long long)k1 * p.a_sk, p.a_sk, vm, kn);
+                gl_stage_kmajor_async<AUX>(nxt + IMG, Bbase + (long long)k1 * p.b_sk, p.b_sk, vn, kn);
             }
             gl_products(cur, cur + IMG, false, false, kc, wave, i, q, c00, c01, c10, c11, as0, as1);
         }
@@ -202,8 +213,8 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
     for (int k0 = 0; k0 < p.K; k0 += GL_KC) {
         const int kc = (p.K - k0) < GL_KC ? (p.K - k0) : GL_KC;
         if (k0 > 0) __syncthreads();  // previous chunk fully consumed
-        gl_stage(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
-        gl_stage(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
+        gl_stage<AUX>(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
+        gl_stage<AUX>(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
         __syncthreads();
         GL_STAMP(1);
         gl_products(ldsA, ldsB, a_rowk, b_rowk, kc, wave, i, q, c00, c01, c10, c11, as0, as1);
@@ -296,6 +307,13 @@ __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFu
         }
     }
     GL_STAMP(5);
+}
+
+template <bool ADAM>
+__device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
+    __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
+    __shared__ float bsum[GL_WAVES][32];
+    gemm_tile<ADAM>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }

@@ -66,10 +66,45 @@ __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int i
     if (layer >= 2) off_d = base + w0 + frag8_dx_index(n, k, N);
 }
 
+// ---- fused single-launch update: the weight-gradient tiles (+ Adam) run as a second phase of k_fb_slab8 -------------
+// Every workgroup of the launch turns into a tile worker once ALL chain workgroups have published their outputs; the
+// workgroups that hold no chain (idle CUs at small batches) are already waiting.  What this removes from an update: one
+// kernel boundary, the cold start of the stand-alone tile kernel and the end-of-kernel write-back of the chain kernel.
+// Hand-off (cdna_hip_programming.md Guideline 16, form R1): chain outputs are stored WRITE-THROUGH (sc1), every storing
+// wave drains its stores (vmcnt(0)), one lane bumps a device-scope counter; consumers poll that one word relaxed and
+// read the operands with sc1 loads (LDS-DMA, aux = 16).  No workgroup ever waits for a tile worker, so a launch whose
+// workgroups are not all resident still terminates; every spin is bounded.
+struct FuseSync {                      // zeroed by k_seq_begin at the start of every update sequence
+    unsigned long long chains_done;    // chain workgroups that have published (monotonic within the sequence)
+    unsigned int error;                // a bounded spin gave up (never in a healthy run; hp_agent_fused_status reads it)
+    unsigned int pad;
+};
+struct FuseArgs {
+    int on;                            // 0: chains only (the tile kernel follows as its own launch)
+    int u;                             // index of this update in its sequence: poll target = (u + 1) * chains
+    int n_tiles;
+    int pad;
+    FuseSync *sync;
+    const GemmGroup *grp;              // the eight weight-gradient problems, in device memory: the tile code indexes the
+                                       // problem table dynamically, which on a by-value kernel argument would copy the whole
+                                       // argument block to scratch in every workgroup's prologue
+    AdamFuse adam;                     // optimizer epilogue: reads the chains' parameter set, writes the other one
+};
+#define S8_SPIN_LIMIT 40000            // x (s_sleep + one L2 round trip) ~ 40 ms
+
+__device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store4(float *p, const float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
 // arguments of k_fb_slab8 (both row counts)
 struct FbSlabArgs {
     FwdSlabArgs f;
     BwdSlabArgs b;
+    FuseArgs fuse;
     // Spare workgroups behind the 2 * nslab chain workgroups: n_plan (0/1) draws the index plan of a LATER update
     // (b.next_plan), n_ahead gather the NEXT update's network inputs from its already drawn plan into the other input
     // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
@@ -240,7 +275,7 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
                 lout[row * ld_out + col] = o;
                 // global copy for the weight-gradient GEMM straight from the register (a wavefront writes 64
                 // consecutive floats of one row): no second pass over the LDS slab before the next layer can start
-                if (gout) gout[(size_t)row * 256 + col] = o;
+                if (gout) wt_store(gout + (size_t)row * 256 + col, o);   // operand of the weight-gradient tiles
             }
         if (mask_out) mask_out[col] = (s8_mask_t)outbits;
     }
@@ -382,7 +417,7 @@ __device__ __forceinline__ void s8_store(const float *l, int ld, int width, floa
     const int per_row = width >> 2;
     for (int f = threadIdx.x; f < S8_ROWS * per_row; f += S8_THREADS) {
         const int r = f / per_row, c4 = f - r * per_row;
-        *reinterpret_cast<float4 *>(g + (size_t)r * ldg + 4 * c4) = *reinterpret_cast<const float4 *>(l + r * ld + 4 * c4);
+        wt_store4(g + (size_t)r * ldg + 4 * c4, *reinterpret_cast<const float4 *>(l + r * ld + 4 * c4));
     }
 }
 
@@ -434,7 +469,7 @@ __device__ __forceinline__ void s8_gather(float *xin, const GatherSrc &G, const 
             }
         }
         xin[r * S8_LDX + c] = x;
-        if (Xout && (which == 1 || c < act_off)) Xout[m * ldx + c] = x;
+        if (Xout && (which == 1 || c < act_off)) wt_store(Xout + m * ldx + c, x);
     }
     if (which == 1 && l == 63) {
         float rew = 0.f;
@@ -568,6 +603,40 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
     }
 }
 
+// Second phase of the fused launch (FuseArgs): publish (chain workgroups), wait for every chain, then this workgroup's
+// share of the weight-gradient tiles with the optimizer in their epilogue.  worker / n_workers: this workgroup's index
+// among the workgroups that take part (all but the index-plan workgroup).  lds / bsum: GL_LDS_FLOATS / 8 x 32 floats.
+__device__ __forceinline__ void s8_phase2(const FuseArgs &U, bool chain_wg, int n_chains, int worker, int n_workers,
+                                          float *lds, float (*bsum)[32], unsigned long long *tl) {
+    S8_TSTAMP(tl, 27);
+    if (chain_wg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its write-through stores have completed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&U.sync->chains_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {   // one lane polls one word, relaxed; bounded
+        const unsigned long long target = (unsigned long long)(U.u + 1) * (unsigned long long)n_chains;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&U.sync->chains_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > S8_SPIN_LIMIT) {
+                __hip_atomic_store(&U.sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    S8_TSTAMP(tl, 28);
+    __syncthreads();
+    S8_TSTAMP(tl, 29);
+    if (worker == n_workers - 1 && threadIdx.x < 64) loss_finalize(U.adam);
+    int done = 0;
+    for (int t = worker; t < U.n_tiles; t += n_workers, ++done) {
+        if (done) __syncthreads();   // the previous tile's epilogue was still reading the LDS images
+        gemm_tile<true, 16>(*U.grp, &U.adam, t, lds, bsum, false);
+        S8_TSTAMP(tl, done ? 31 : 30);
+    }
+}
+
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_slab8(const FbSlabArgs P) {
     const FwdSlabArgs &A = P.f;
     const BwdSlabArgs &Bk = P.b;
@@ -605,13 +674,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
     if ((int)blockIdx.x >= 2 * nslab) {   // spare workgroups (see FbSlabArgs)
         const int extra = (int)blockIdx.x - 2 * nslab;
-        if (extra < P.n_plan) {
+        if (extra < P.n_plan) {   // the index-plan workgroup ends here (ended waves take no part in barriers)
             if (tid >= MT_THREADS) return;
             mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
                         reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+            return;
         } else if (extra < P.n_plan + P.n_ahead) {
             s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, extra - P.n_plan, P.n_ahead);
-        } else {
+        } else if (extra < P.n_plan + P.n_ahead + P.n_pref) {
             // L2 warmer of this workgroup's XCD: touches the weight fragments the XCD's chains will stream, in the order
             // they use them, one dword per 128-byte line, so that the chains find them in their L2 instead of behind the fabric
             const int side = P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2;
@@ -653,9 +723,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (; off < ns[r]; off += step) acc += rs[r][off];
             }
             if (acc == 1.2345678e-33f) dq[0] = acc;   // keeps the loads; never true in practice, harmless if it is
-        }
-        return;
-    }
+        }   // (workgroups past the warmers exist only in a fused launch: pure tile workers on CUs that hold no chain)
+    } else {
     S8_TSTAMP(tl, 0);
     const SlabNetPtrs &on = A.online;
     if (chain == 0) {
@@ -763,16 +832,15 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_sync();
         S8_TSTAMP(tl, 21);
         if (tid < S8_ROWS) {
-            Bk.dQA[(row0 + tid) * 16] = keep_g;
-            if (tid == 0) Bk.part[slab] = keep_a;
+            wt_store(Bk.dQA + (row0 + tid) * 16, keep_g);
+            if (tid == 0) wt_store(Bk.part + slab, keep_a);
         }
-        if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
-            Bk.st->step += 1;
+        if (!P.fuse.on && slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
+            Bk.st->step += 1;                         // (fused launch: per-sequence table, k_seq_begin / k_seq_end)
             adam_prepare(Bk.st, Bk.adam);
         }
         S8_TSTAMP(tl, 22);
-        return;
-    }
+    } else {
     // ---------------------------------------------------------------------- actor side
     const PlanRec rec = s8_plan_rec(A.gs, row0);
     float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
@@ -885,7 +953,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     v = gt * (1.f - th_mine[i] * th_mine[i]);
                 }
                 dz[rr * 20 + lane] = v;
-                Bk.dZ[m * 16 + lane] = v;
+                wt_store(Bk.dZ + m * 16 + lane, v);
             }
         }
     }
@@ -903,10 +971,21 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     S8_TSTAMP(tl, 20);
     if (tid == 0) {
-        Bk.part[nslab + slab] = keep_q;
-        Bk.part[2 * nslab + slab] = keep_u;
+        wt_store(Bk.part + nslab + slab, keep_q);
+        wt_store(Bk.part + 2 * nslab + slab, keep_u);
     }
     S8_TSTAMP(tl, 21);
+    }
+    }
+    if (P.fuse.on) {
+        // every workgroup but the index-plan one becomes a tile worker; the weight ring (>= 80 KB) holds the operand images
+        const bool chain_wg = (int)blockIdx.x < 2 * nslab;
+        const int worker = chain_wg ? (int)blockIdx.x : (int)blockIdx.x - P.n_plan;
+        const int n_workers = (int)gridDim.x - P.n_plan;
+        static_assert(sizeof(wring) >= GL_LDS_FLOATS * sizeof(float), "weight ring too small for the tile images");
+        s8_phase2(P.fuse, chain_wg, 2 * nslab, worker, n_workers, reinterpret_cast<float *>(&wring[0][0][0]),
+                  reinterpret_cast<float(*)[32]>(pbuf), tl);
+    }
 }
 
 #if S8_NRG == 1

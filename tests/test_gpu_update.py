@@ -423,7 +423,9 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
 @pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
                                           ("RLARM_GEMM_PIPE=0", 1024), ("RLARM_GEMM_PIPE=0", 449), ("RLARM_GEMM_PIPE=0", 1536),
                                           ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
-                                          ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024)])
+                                          ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024),
+                                          ("RLARM_FUSE_DW=1", 256), ("RLARM_FUSE_DW=1", 128), ("RLARM_FUSE_DW=1", 449),
+                                          ("RLARM_FUSE_DW=1", 512), ("RLARM_FUSE_DW=1", 1024), ("RLARM_FUSE_DW=1", 1536)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, a ring of reduction chunks in the weight-gradient GEMM beyond 256 rows, its big problems placed on XCD
@@ -438,6 +440,45 @@ def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     got = _run_cycles(agent, graph=True)
     for a, b in zip(want, got):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+@pytest.mark.parametrize("batch", [256, 1024])
+def test_fused_single_launch_updates_are_used_and_healthy(batch, monkeypatch):
+    """RLARM_FUSE_DW=1 (opt-in, measured slower -- DESIGN.md): single-rank sampled updates run as ONE launch each (chain
+    kernel whose second phase computes the weight-gradient tiles and applies Adam into the other parameter set); odd and
+    even sequence lengths end with the live parameters in the set every other entry point reads, and the in-kernel
+    hand-off never times out."""
+    monkeypatch.setenv("RLARM_FUSE_DW", "1")
+    import ctypes as C
+    from rl_arm_under_sparse_reward_amd import _lib
+
+    def status(agent):
+        n, err = C.c_int64(), C.c_uint32()
+        _lib.check(agent.lib.hp_agent_fused_status(agent.h, C.byref(n), C.byref(err)))
+        return n.value, err.value
+
+    torch.manual_seed(0)
+    agent, rng = make_agent(batch=batch, n_eps=32, seed=3)
+    agent.buffer.store_episode(make_episodes(20, seed=5, mode="walk"))
+    agent._update_normalizer()
+    torch.manual_seed(0)
+    twin, rng2 = make_agent(batch=batch, n_eps=32, seed=3)
+    twin.buffer.store_episode(make_episodes(20, seed=5, mode="walk"))
+    twin._update_normalizer()
+    for n in (1, 2, 3, 7):                      # odd counts leave the parameters in the second set: copied back
+        agent._update_network(n)
+    for _ in range(13):
+        twin._update_network(1)                 # the same 13 updates one launch sequence at a time
+    n_fused, err = status(agent)
+    assert n_fused == 13 and err == 0, (n_fused, err)      # counts enqueued launches (the twin replays one cached graph)
+    assert status(twin)[0] >= 1 and status(twin)[1] == 0
+    for net in (NET_ACTOR, NET_CRITIC):
+        assert np.array_equal(bits(agent._get_flat(net)), bits(twin._get_flat(net)))
+    assert np.array_equal(bits(agent.last_losses(13)), bits(twin.last_losses(13)))
+    m, v, step = agent.get_adam_state(NET_CRITIC)
+    assert step == 13
+    x = torch.randn(5, 30)
+    assert np.array_equal(bits(agent.actor_network(x).numpy()), bits(twin.actor_network(x).numpy()))
 
 
 @pytest.mark.parametrize("batch", [256, 1024])

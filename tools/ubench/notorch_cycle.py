@@ -63,7 +63,8 @@ for ch, nm in ((0, "fwd T | merged critic side"), (1, "fwd A | merged actor side
 for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
     v = [tl[base + k] for k in range(8)]
     if v[0]:
-        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-tl[160])/100:.1f}" for k in range(8) if v[k]))
+        print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-tl[160])/100:.1f}" for k in range(8) if v[k]),
+              "| first stamp at", (tl[base] - tl[0]) / 100 if tl[0] else None, "us after chain start")
 floor("after cycles")
 # eager path
 _lib.check(lib.hp_agent_sample_and_update(h, buf.h, on.h, gn.h, rng.h, 0.8, squared_threshold(0.05), 40)); ctx.synchronize()
