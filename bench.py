@@ -122,7 +122,8 @@ class Runner:
             if self.in_cycle == 0 and self.feeder is not None:
                 self.feed_sem.release()      # one feeder batch per cycle, concurrent with it
                 self._releases += 1
-            if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None):
+            if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None
+                                                          or ag._peer is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
                 self.cycle += 1
                 self.opens += 1
@@ -345,6 +346,11 @@ def main():
     if world > 1:
         barrier(world)
     dp_native = r.agent._native_comm is not None
+    dp_peer = r.agent._peer is not None
+    import ctypes as _C
+    mode = _C.c_int32()
+    r.agent.lib.hp_agent_cycle_mode(r.agent.h, _C.byref(mode))
+    cycle_mode = {0: "none", 1: "hipGraph", 2: "eager launches"}.get(mode.value, str(mode.value))
     if world > 1 or force_dp:
         r.agent.close_comm()
     if rank != 0:
@@ -371,9 +377,12 @@ def main():
                    "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
                    **({"feeder_episodes_per_cycle": a.feeder_episodes} if a.feeder_episodes else {}),
                    "parallelism": f"dp{world}" + (
-                       " (RCCL grad SUM all-reduce per update [reference semantics, utils.py:47] + normalizer MEAN per cycle, " +
-                       ("issued by the library inside the cycle hipGraph)" if dp_native
-                        else "issued through torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
+                       " (grad SUM per update [reference semantics, utils.py:47] + normalizer MEAN per cycle: " +
+                       ("one-shot all-reduce over peer memory fused with Adam, inside the cycle graph)" if dp_peer else
+                        "RCCL all-reduce issued by the library inside the cycle graph)" if dp_native
+                        else "torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
+                   "exchange": ("peer-memory" if dp_peer else "rccl" if dp_native else "torch.distributed") if (world > 1 or force_dp) else None,
+                   "cycle_mode": cycle_mode,
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])],
                    "shader_clock_mhz_after_run": round(mhz.value)},

@@ -52,6 +52,7 @@ typedef struct hp_buffer hp_buffer;
 typedef struct hp_norm hp_norm;
 typedef struct hp_agent hp_agent;
 typedef struct hp_comm hp_comm;
+typedef struct hp_peer hp_peer;
 
 int hp_abi_version(void);
 const char *hp_last_error(void);
@@ -275,6 +276,25 @@ int hp_agent_set_grad_reduce(hp_agent *ag, int32_t mean);
 /* diagnostic: 0 = no cycle built yet, 1 = hp_agent_train_cycle replays a cached hipGraph, 2 = it issues eager
  * launches because a capture containing collectives was refused by the runtime */
 int hp_agent_cycle_mode(hp_agent *ag, int32_t *mode);
+
+/* ---- rank exchange as one-shot all-reduces over peer memory (xGMI), fused with the optimizer ----------------------------
+ * Same three exchanges as above, but without a collective library on the critical path of an update: every rank exports
+ * one block of exchange memory (hipIpcGetMemHandle), maps the other ranks' blocks, and the kernel that applies Adam
+ * reads the peers' gradient vectors itself and sums them in rank order (utils.py:43-48 SUM; bit-identical parameters on
+ * every rank).  Bootstrap: hp_peer_create on every rank -> exchange the 64-byte handles through any side channel ->
+ * hp_peer_connect(all handles, rank order).  Waits are bounded (RLARM_PEER_TIMEOUT_S, default 20 s); hp_peer_status
+ * reads the sticky error word.  One node only (ranks that can map each other's device memory). */
+int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floats, hp_peer **out, uint8_t *handle64);
+int hp_peer_connect(hp_peer *peer, const uint8_t *handles_world_x_64);
+/* normalizer._mpi_average (normalizer.py:60-64) and other small vectors (<= 1024 floats): in place, SUM or SUM / world
+ * (mean != 0), enqueued on the context's stream; collective */
+int hp_peer_allreduce_f32(hp_peer *peer, void *dev, int64_t n, int32_t mean);
+int hp_peer_status(hp_peer *peer, uint32_t *error);
+void hp_peer_destroy(hp_peer *peer);
+/* Attach (or detach with NULL): hp_agent_sample_and_update / hp_agent_train_cycle then exchange the gradients through
+ * peer memory inside the optimizer kernel and the normalizer sums through the mailboxes.  hp_agent_grad_buffer-style
+ * host-driven exchange keeps working.  n_grad_floats of the peer must equal hp_agent_grad_buffer's length. */
+int hp_agent_set_peer(hp_agent *ag, hp_peer *peer);
 
 /* One training cycle's learner half (ddpg_agent.py:143-150) as one cached hipGraph:
  *   store n_new episodes -> update normalizers (+recompute) -> n_batches updates -> soft update.

@@ -112,6 +112,12 @@ PROTOTYPES = {
     "hp_comm_broadcast_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "hp_comm_destroy": (None, [C.c_void_p]),
     "hp_agent_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_peer_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_pp, u8p]),
+    "hp_peer_connect": (C.c_int, [C.c_void_p, u8p]),
+    "hp_peer_allreduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "hp_peer_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "hp_peer_destroy": (None, [C.c_void_p]),
+    "hp_agent_set_peer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_agent_cycle_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hp_agent_set_grad_reduce": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,

@@ -215,6 +215,41 @@ __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
 }
 
 #include "gemm_lds.h"
+#include "peer.h"
+
+// gradients: barrier + rank-ordered sum + Adam.  n4 = arena floats / 4; u = index of the update in its sequence.
+__global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFuse F, int n4, int u, int mean) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    const int par = (int)(epoch & 1ull);
+    if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
+    peer_wait(D, D.flags_g[D.rank], epoch);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t bytes = (size_t)n4 * 16;
+    for (int q = 0; q < D.world; ++q) {   // rank order: the same float32 sum on every rank
+        const float4 v = peer_load4(D.grad[q][par], bytes, (unsigned)t * 16u, q == D.rank);
+        if (q == 0) acc = v;
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+    if (mean) {   // SUM / world, float32 true division (what the RCCL path's k_scale_div does)
+        const float w = (float)D.world;
+        acc.x /= w; acc.y /= w; acc.z /= w; acc.w /= w;
+    }
+    const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (F.keep_grads) *reinterpret_cast<float4 *>(const_cast<float *>(F.grads_base) + 4 * (size_t)t) = acc;
+    adam_apply4(F, 4 * t, g);
+}
+
+
+static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, bool mean) {
+    const int n4 = n_arena / 4;
+    hipLaunchKernelGGL(k_peer_adam, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u, mean ? 1 : 0);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
 
 // the 4x4x1 slab engine, compiled for two slab heights (see slab8.h)
 #define S8_NRG 1
@@ -286,6 +321,7 @@ struct hp_agent {
     std::vector<void *> owned;
     // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
     hp_comm *comm = nullptr;
+    hp_peer *peer = nullptr;      // one-shot exchange over peer memory (hp_agent_set_peer); takes precedence over comm
     bool grad_mean = false;       // divide the all-reduced gradients by the world size (default: SUM, like the reference)
     bool comm_warm = false;       // the collectives of a cycle have each run once outside a capture
     bool graph_refused = false;   // capturing the cycle with collectives failed once: stay on eager launches
@@ -867,6 +903,8 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     const PlanRec *ahead_plan = nullptr;
     // fused single-launch update: index of this update in its sequence (-1: chain kernel + tile kernel as two launches)
     int fuse_u = -1;
+    // data-parallel ranks exchanging through peer memory: this update's gradients go straight into the exchange buffer
+    float *grads_out = nullptr;
 };
 
 static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam);
@@ -1040,10 +1078,11 @@ static int enqueue_relayout(hp_agent *a, bool targets) {
 }
 
 // all weight gradients of one update: the only products that reduce over the batch (input sets sXA / sXP)
-static Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP) {
+static Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, float *grads = nullptr) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
-    float *Ga = a->grads, *Gc = a->grads + la.total;
+    if (!grads) grads = a->grads;
+    float *Ga = grads, *Gc = grads + la.total;
     Launch L;
     // the four 256 x 256 problems first: Launch::place_on_xcds gives each of them one pair of XCDs
     add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
@@ -1184,7 +1223,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         }
     }
     if (!fused) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
-        Launch L = build_dw_group(a, sXA, sXP);
+        Launch L = build_dw_group(a, sXA, sXP, gc ? gc->grads_out : nullptr);
         if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
@@ -1285,7 +1324,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // (slab8.h FuseArgs).  Needs the optimizer to follow the gradients directly (one rank) and every chain workgroup
     // resident at once (one per CU: the tile phase starts when ALL chains have published).
     const int chains = 2 * (a->Mp / a->s8_rows);
-    const bool fuse_dw = a->slab8 && with_adam && !a->comm && a->fuse_adam_ok && a->fuse_dw_ok && a->d_grp &&
+    const bool fuse_dw = a->slab8 && with_adam && !a->comm && !a->peer && a->fuse_adam_ok && a->fuse_dw_ok && a->d_grp &&
                          chains <= a->ctx->cu_count;
     if (fuse_dw) {
         hipLaunchKernelGGL(k_seq_begin, dim3((n_updates + 63) / 64), dim3(64), 0, a->ctx->stream, a->d_state, a->fsync,
@@ -1310,9 +1349,19 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             if (u + 1 < n_updates) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
         if (fuse_dw) gc.fuse_u = u;
+        const bool via_peer = with_adam && a->peer != nullptr;
+        if (via_peer) gc.grads_out = peer_grad_buffer(a->peer, u + 1);   // epoch base is even: parity of epoch base + u + 1
         bool fused = false;
-        HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm, &fused));
-        if (with_adam) {
+        HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm && !a->peer, &fused));
+        if (via_peer) {
+            // utils.sync_grads (utils.py:43-48) + both Adam steps in ONE kernel: every rank reads the peers' gradient
+            // vectors over xGMI, sums them in rank order and steps (peer.hip)
+            AdamFuse F = adam_fuse(a);
+            F.grads_base = a->grads;
+            F.keep_grads = 0;
+            ProfScope ps(a, PROF_ADAM);
+            HP_TRY(peer_enqueue_adam(a->peer, F, a->n_arena, u, a->grad_mean));
+        } else if (with_adam) {
             // utils.sync_grads (utils.py:43-48): SUM over ranks between backward and the optimizer step; one
             // all-reduce covers both networks (the reference sends the actor's and the critic's separately)
             if (a->comm)
@@ -1334,6 +1383,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(64), 0, s, a->d_state, n_updates, adam_cfg(a));
         HP_CHECK_HIP(hipGetLastError());
     }
+    if (with_adam && a->peer) HP_TRY(peer_enqueue_seq_end(a->peer, n_updates));
     return HP_OK;
 }
 
@@ -1893,8 +1943,17 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
                               double sq, int n_batches, PlanRec *norm_plan) {
     // ddpg_agent._update_normalizer (:187-212)
     HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, b->T, 1, future_p, norm_plan));
-    if (!a->comm) {   // single rank: update + recompute_stats of both normalizers in one launch
+    if (!a->comm && !a->peer) {   // single rank: update + recompute_stats of both normalizers in one launch
         HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, true));
+    } else if (a->peer) {
+        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
+        HP_TRY(norm_launch_begin(on));
+        HP_TRY(norm_launch_begin(gn));
+        // normalizer._mpi_average (normalizer.py:60-64) through the mailboxes
+        HP_TRY(peer_allreduce_small(a->peer, on->d->sync, (size_t)(2 * on->size + 1), true));
+        HP_TRY(peer_allreduce_small(a->peer, gn->d->sync, (size_t)(2 * gn->size + 1), true));
+        HP_TRY(norm_launch_end(on));
+        HP_TRY(norm_launch_end(gn));
     } else {
         HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
         HP_TRY(norm_launch_begin(on));
@@ -1927,6 +1986,18 @@ int hp_agent_cycle_mode(hp_agent *a, int32_t *mode) {
     HP_REQUIRE(a && mode, HP_ERR_INVALID, "hp_agent_cycle_mode: null argument");
     HP_SERIALISE(a);
     *mode = a->graph_refused ? 2 : (a->graph ? 1 : 0);
+    return HP_OK;
+}
+
+int hp_agent_set_peer(hp_agent *a, hp_peer *peer) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_peer: null handle");
+    HP_SERIALISE(a);
+    HP_REQUIRE(!peer || peer->ctx == a->ctx, HP_ERR_INVALID, "hp_agent_set_peer: exchange belongs to another context");
+    HP_REQUIRE(!peer || (peer->connected && peer->n_grad == (size_t)a->n_arena), HP_ERR_INVALID,
+               "hp_agent_set_peer: exchange not connected, or its gradient length differs from the agent's (%d floats)", a->n_arena);
+    HP_REQUIRE(!peer || a->slab, HP_ERR_INVALID, "hp_agent_set_peer: needs a slab engine (the optimizer kernel with fragment copies)");
+    drop_graph(a);
+    a->peer = peer;
     return HP_OK;
 }
 

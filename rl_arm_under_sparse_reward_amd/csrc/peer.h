@@ -1,0 +1,78 @@
+// peer.h -- one-shot all-reduce over peer memory (peer.hip): shared declarations of the library (not part of the C ABI)
+#pragma once
+#include "internal.h"
+
+#define HP_PEER_MAX 16        // ranks of one node
+#define HP_PEER_SMALL 1024    // floats of a mailbox (the normalizer exchanges 55 and 7)
+
+struct PeerDev {              // by-value kernel argument: where every rank's exchange memory is mapped in THIS process
+    int rank, world;
+    unsigned long long *flags_g[HP_PEER_MAX];   // rank q's gradient-channel flags (slot w written by rank w)
+    unsigned long long *flags_s[HP_PEER_MAX];   // rank q's mailbox-channel flags
+    float *small[HP_PEER_MAX][2];               // rank q's mailboxes (ping-pong by epoch parity)
+    float *grad[HP_PEER_MAX][2];                // rank q's gradient vectors (ping-pong)
+    unsigned long long *epoch;                  // local: [0] gradient channel base, [1] mailbox channel
+    unsigned int *error;                        // local, sticky: a wait timed out
+    unsigned long long timeout_ticks;           // 100 MHz ticks
+};
+
+struct hp_peer {
+    hp_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    size_t n_grad = 0, bytes = 0;
+    void *local = nullptr;
+    void *remote[HP_PEER_MAX] = {nullptr};
+    unsigned long long *d_epoch = nullptr;
+    unsigned char handle[64] = {0};
+    bool connected = false;
+    PeerDev dev;
+};
+
+float *peer_grad_buffer(hp_peer *p, int parity);
+int peer_enqueue_seq_end(hp_peer *p, int n_updates);
+int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean);
+
+#ifdef __HIPCC__
+// ---- device helpers shared by peer.hip (mailboxes) and agent.hip (k_peer_adam: gradients + optimizer) ----------------
+__device__ __forceinline__ unsigned long long now_ticks() { return wall_clock64(); }   // 100 MHz
+
+__device__ __forceinline__ void peer_signal(const PeerDev &D, unsigned long long *const *flags, unsigned long long epoch) {
+    // one lane per peer: my slot in the peer's flag array
+    const int q = threadIdx.x;
+    if (q < D.world && q != D.rank) __hip_atomic_store(flags[q] + D.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// every peer has signalled `epoch`?  lane q polls the local slot of peer q; returns false on timeout (wave-uniform)
+__device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *mine, unsigned long long epoch) {
+    const int q = threadIdx.x & 63;
+    const bool poll = (threadIdx.x < 64) && q < D.world && q != D.rank;
+    bool ok = true;
+    if (threadIdx.x < 64) {
+        const unsigned long long t0 = now_ticks();
+        for (;;) {
+            bool here = true;
+            if (poll) here = __hip_atomic_load(mine + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch;
+            if (__all(here)) break;
+            __builtin_amdgcn_s_sleep(16);
+            if (now_ticks() - t0 > D.timeout_ticks) {
+                if (threadIdx.x == 0) __hip_atomic_store(D.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    return ok;
+}
+
+// 4 consecutive floats of rank q's vector: the own vector with a plain load (written by the previous kernel), a peer's
+// with a system-scope load (sc0 sc1: never served from a stale line of this GPU's caches)
+__device__ __forceinline__ float4 peer_load4(const float *base, size_t bytes, unsigned off_bytes, bool own) {
+    if (own) return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_bytes, 0, /*sc0 | sc1*/ 17);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+
+#endif

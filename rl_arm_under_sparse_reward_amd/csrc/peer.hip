@@ -1,0 +1,210 @@
+// peer.hip -- the rank exchange of the hot path as ONE-SHOT all-reduces over peer memory (xGMI), fused with the optimizer.
+//
+// What the reference exchanges per update (utils.py:43-48, via ddpg_agent.py:271,276): Allreduce(SUM) of the flat
+// gradients of both networks, 1.17 MB here, between backward and the Adam steps -- on the critical path of every ~41 us
+// update, because the next forward needs the stepped weights.  A ring all-reduce of that size is pure latency (2(N-1)
+// dependent hops).  xGMI is a full mesh: every GPU reaches every peer's HBM directly, so each rank can simply READ the
+// other ranks' gradient vectors and sum them itself, in rank order (deterministic, and bit-identical on every rank), and
+// apply Adam to the sum in the same kernel: one hop, one launch, no second pass over the gradients.
+//
+//   rank r, update with epoch e:
+//     k_gemm_lds   weight gradients -> G_r[e & 1]                    (own buffer; the kernel boundary makes it visible)
+//     k_peer_adam  (a) flags_q[r] := e on every peer q               (system-scope stores over the fabric)
+//                  (b) wait until flags_r[q] >= e for every q         (local polls; bounded by wall clock)
+//                  (c) g = G_0[e&1][i] + G_1[e&1][i] + ... in rank order (peers: system-scope loads), Adam(g)
+//   Two gradient buffers alternate: a rank that passes the barrier of epoch e + 1 has finished reading epoch e's
+//   buffers everywhere it matters, so G[e & 1] may be rewritten at epoch e + 2 without a second barrier.
+//   Epochs live in device memory (base + index of the update in its sequence), so a captured hipGraph replays correctly.
+//
+// The per-cycle normalizer exchange (normalizer.py:60-64, 62 floats) uses the same mechanism through small mailboxes
+// (k_peer_small: copy in, flag, poll, sum in rank order, optional / world).
+//
+// Memory: one fine-grained device allocation per rank ([flags | mailboxes | 2 x gradients]) exported with
+// hipIpcGetMemHandle; the 64-byte handles travel through any side channel (the Python mirror uses torch.distributed).
+// RCCL (comm.hip) stays as the fallback transport; utils.Communicator picks this one when a self-check passes.
+#include "internal.h"
+
+#include "peer.h"
+
+// the gradient channel's epoch base moves on by an EVEN count per sequence, so that the buffer parity of update u is
+// known on the host when the launches are recorded
+__global__ void k_peer_seq_end(const PeerDev D, int n_updates) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.epoch[0] += (unsigned long long)(n_updates + (n_updates & 1));
+}
+
+// small vectors (normalizer sums): one workgroup.  vec[n] := sum over ranks (/ world if mean), in place.
+__global__ __launch_bounds__(256) void k_peer_small(const PeerDev D, float *vec, int n, int mean) {
+    const unsigned long long epoch = D.epoch[1] + 1ull;
+    const int par = (int)(epoch & 1ull);
+    float *mine = D.small[D.rank][par];
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        __hip_atomic_store(mine + i, vec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, system scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: stores complete before the flag goes out
+    __syncthreads();
+    peer_signal(D, D.flags_s, epoch);
+    peer_wait(D, D.flags_s[D.rank], epoch);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float acc = 0.f;
+        for (int q = 0; q < D.world; ++q) {
+            const float v = (q == D.rank) ? vec[i]
+                                          : __hip_atomic_load(D.small[q][par] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            acc = (q == 0) ? v : acc + v;
+        }
+        vec[i] = mean ? acc / (float)D.world : acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) D.epoch[1] = epoch;
+}
+
+// ---- internal entry points used by agent.hip -----------------------------------------------------------------------
+float *peer_grad_buffer(hp_peer *p, int parity) { return p->dev.grad[p->rank][parity & 1]; }
+
+int peer_enqueue_seq_end(hp_peer *p, int n_updates) {
+    hipLaunchKernelGGL(k_peer_seq_end, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, n_updates);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean) {
+    HP_REQUIRE(n <= HP_PEER_SMALL, HP_ERR_INVALID, "peer all-reduce: %zu floats exceed the mailbox (%d)", n, HP_PEER_SMALL);
+    hipLaunchKernelGGL(k_peer_small, dim3(1), dim3(256), 0, p->ctx->stream, p->dev, dev, (int)n, mean ? 1 : 0);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------- C ABI
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PeerLayout {
+    size_t flags_g, flags_s, small, grad, total;
+    explicit PeerLayout(size_t n_grad) {
+        size_t o = 0;
+        flags_g = o; o += HP_PEER_MAX * 8;
+        flags_s = o; o += HP_PEER_MAX * 8;
+        o = align_up(o, 256);
+        small = o; o += 2 * (size_t)HP_PEER_SMALL * 4;
+        o = align_up(o, 256);
+        grad = o; o += 2 * align_up(n_grad * 4, 256);
+        total = align_up(o, 4096);
+    }
+};
+
+static void peer_fill_dev(hp_peer *p) {
+    const PeerLayout L(p->n_grad);
+    const size_t gstride = align_up(p->n_grad * 4, 256);
+    for (int q = 0; q < p->world; ++q) {
+        char *b = static_cast<char *>(p->remote[q]);
+        p->dev.flags_g[q] = reinterpret_cast<unsigned long long *>(b + L.flags_g);
+        p->dev.flags_s[q] = reinterpret_cast<unsigned long long *>(b + L.flags_s);
+        for (int k = 0; k < 2; ++k) {
+            p->dev.small[q][k] = reinterpret_cast<float *>(b + L.small) + (size_t)k * HP_PEER_SMALL;
+            p->dev.grad[q][k] = reinterpret_cast<float *>(b + L.grad + k * gstride);
+        }
+    }
+}
+
+extern "C" {
+
+void hp_peer_destroy(hp_peer *p);
+
+int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floats, hp_peer **out, uint8_t *handle64) {
+    HP_REQUIRE(ctx && out && handle64, HP_ERR_INVALID, "hp_peer_create: null argument");
+    HP_REQUIRE(world >= 1 && world <= HP_PEER_MAX && rank >= 0 && rank < world, HP_ERR_INVALID,
+               "hp_peer_create: rank %d of %d (at most %d ranks)", rank, world, HP_PEER_MAX);
+    HP_REQUIRE(n_grad_floats > 0 && n_grad_floats % 4 == 0, HP_ERR_INVALID, "hp_peer_create: gradient length must be a positive multiple of 4");
+    CtxGuard guard(ctx);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hp_peer *p = new hp_peer();
+    p->ctx = ctx;
+    p->rank = rank;
+    p->world = world;
+    p->n_grad = (size_t)n_grad_floats;
+    const PeerLayout L(p->n_grad);
+    p->bytes = L.total;
+    // fine-grained: coherent with the peers' system-scope accesses; plain device memory if the runtime refuses
+    if (hipExtMallocWithFlags(&p->local, p->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        p->local = nullptr;
+        if (hipMalloc(&p->local, p->bytes) != hipSuccess) {
+            hp_set_error("hp_peer_create: cannot allocate %zu bytes of exchange memory", p->bytes);
+            delete p;
+            return HP_ERR_HIP;
+        }
+    }
+    hipError_t e = hipMemset(p->local, 0, p->bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_epoch, 2 * sizeof(unsigned long long) + 16);
+    if (e == hipSuccess) e = hipMemset(p->d_epoch, 0, 2 * sizeof(unsigned long long) + 16);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p->local);
+    if (e != hipSuccess) {
+        hp_set_error("hp_peer_create: %s", hipGetErrorString(e));
+        hp_peer_destroy(p);
+        return HP_ERR_HIP;
+    }
+    memcpy(handle64, &h, 64);
+    memcpy(p->handle, &h, 64);
+    memset(&p->dev, 0, sizeof(p->dev));
+    p->dev.rank = rank;
+    p->dev.world = world;
+    p->dev.epoch = p->d_epoch;
+    p->dev.error = reinterpret_cast<unsigned int *>(p->d_epoch + 2);
+    double secs = 20.0;   // a rank may legitimately be late by a host-side pause (checkpoint, graph capture); a dead one must not hang us
+    if (const char *t = getenv("RLARM_PEER_TIMEOUT_S")) secs = atof(t) > 0 ? atof(t) : secs;
+    p->dev.timeout_ticks = (unsigned long long)(secs * 1e8);
+    for (int q = 0; q < world; ++q) p->remote[q] = nullptr;
+    p->remote[rank] = p->local;
+    *out = p;
+    return HP_OK;
+}
+
+int hp_peer_connect(hp_peer *p, const uint8_t *handles) {
+    HP_REQUIRE(p && handles, HP_ERR_INVALID, "hp_peer_connect: null argument");
+    CtxGuard guard(p->ctx);
+    for (int q = 0; q < p->world; ++q) {
+        if (q == p->rank) continue;
+        HP_REQUIRE(memcmp(handles + 64 * q, p->handle, 64) != 0, HP_ERR_INVALID, "hp_peer_connect: rank %d sent this rank's own handle", q);
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + 64 * q, 64);
+        void *ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            hp_set_error("hp_peer_connect: hipIpcOpenMemHandle(rank %d) failed: %s", q, hipGetErrorString(e));
+            return HP_ERR_HIP;
+        }
+        p->remote[q] = ptr;
+    }
+    peer_fill_dev(p);
+    p->connected = true;
+    return HP_OK;
+}
+
+int hp_peer_allreduce_f32(hp_peer *p, void *dev, int64_t n, int32_t mean) {
+    HP_REQUIRE(p && dev && n >= 0, HP_ERR_INVALID, "hp_peer_allreduce_f32: bad argument");
+    CtxGuard guard(p->ctx);
+    HP_REQUIRE(p->connected, HP_ERR_STATE, "hp_peer_allreduce_f32: hp_peer_connect first");
+    if (n == 0) return HP_OK;
+    return peer_allreduce_small(p, static_cast<float *>(dev), (size_t)n, mean != 0);
+}
+
+int hp_peer_status(hp_peer *p, uint32_t *error) {
+    HP_REQUIRE(p && error, HP_ERR_INVALID, "hp_peer_status: null argument");
+    CtxGuard guard(p->ctx);
+    HP_CHECK_HIP(hipMemcpyAsync(error, p->dev.error, 4, hipMemcpyDeviceToHost, p->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+    return HP_OK;
+}
+
+void hp_peer_destroy(hp_peer *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (int q = 0; q < p->world; ++q)
+        if (q != p->rank && p->remote[q]) (void)hipIpcCloseMemHandle(p->remote[q]);
+    if (p->local) (void)hipFree(p->local);
+    if (p->d_epoch) (void)hipFree(p->d_epoch);
+    delete p;
+}
+
+}  // extern "C"

@@ -79,10 +79,23 @@ class ddpg_agent:
             net.attach(self, slot)
         self.actor_network.push()
         self.critic_network.push()
-        # data-parallel ranks on GPUs: the library issues the collectives itself (csrc/comm.hip)
-        self._native_comm = self.comm.attach_native(self.ctx)
-        if self._native_comm is not None:
-            _lib.check(self.lib.hp_agent_set_comm(self.h, self._native_comm))
+        # data-parallel ranks on GPUs: the library exchanges gradients and normalizer sums itself, inside the cycle graph.
+        # First choice: one-shot all-reduce over peer memory fused with the optimizer (csrc/peer.hip); else RCCL
+        # (csrc/comm.hip); else torch.distributed from a host-driven loop.
+        self._native_comm = None
+        self._peer = None
+        if self.comm.active:
+            n = C.c_int64()
+            p = C.c_void_p()
+            _lib.check(self.lib.hp_agent_grad_buffer(self.h, C.byref(p), C.byref(n)))
+            self._peer = self.comm.attach_peer(self.ctx, n.value)
+            if self._peer is not None:
+                if self.lib.hp_agent_set_peer(self.h, self._peer) != 0:      # e.g. the layer-per-launch engine
+                    self._peer = None
+        if self._peer is None:
+            self._native_comm = self.comm.attach_native(self.ctx)
+            if self._native_comm is not None:
+                _lib.check(self.lib.hp_agent_set_comm(self.h, self._native_comm))
         self._grad_mean = str(getattr(args, "grad_reduce", "sum")).lower() == "mean"
         if getattr(args, "grad_reduce", "sum") not in ("sum", "mean"):
             raise ValueError("grad_reduce must be 'sum' (reference semantics) or 'mean'")
@@ -114,10 +127,12 @@ class ddpg_agent:
     def close_comm(self):
         """Detach and destroy the library-side RCCL communicator (call on every rank before
         torch.distributed.destroy_process_group / interpreter exit)."""
-        if self._native_comm is not None:
+        if self._native_comm is not None or self._peer is not None:
             self.ctx.synchronize()
             _lib.check(self.lib.hp_agent_set_comm(self.h, None))
+            _lib.check(self.lib.hp_agent_set_peer(self.h, None))
             self._native_comm = None
+            self._peer = None
             self.comm.close()
 
     # ------------------------------------------------------------------ parameter plumbing
@@ -150,6 +165,13 @@ class ddpg_agent:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_param_buffer(self.h, C.byref(p), C.byref(n)))
+        if comm.native is None and comm.peer is not None:
+            # one-off at start-up through torch.distributed; the library keeps its own (capturable) stream, so order the
+            # two sides with full synchronisations instead of moving the library onto torch's stream
+            self.ctx.synchronize()
+            comm.broadcast_device(p.value, n.value, 0)
+            torch.cuda.synchronize(self.ctx.device_id)
+            return
         if comm.native is None:
             self.ctx.use_torch_stream()      # order our kernels with the collectives torch enqueues
         comm.broadcast_device(p.value, n.value, 0)
@@ -189,8 +211,8 @@ class ddpg_agent:
     def _update_network(self, n_updates=1):
         """ddpg_agent.py:225-277, `n_updates` times back to back (the reference's inner loop :145-147)."""
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
-        if not self.comm.active or self._native_comm is not None:
-            # single rank, or the library all-reduces the gradients itself between backward and Adam
+        if not self.comm.active or self._native_comm is not None or self._peer is not None:
+            # single rank, or the library exchanges the gradients itself between backward and Adam
             _lib.check(self.lib.hp_agent_sample_and_update(*self._handles(), fp, sq, int(n_updates)))
             return
         for _ in range(int(n_updates)):          # data-parallel ranks: grads are SUMmed between backward and Adam
@@ -257,7 +279,7 @@ class ddpg_agent:
         contains the RCCL all-reduces (gradients every update, normalizer sums once) when the library owns the
         communicator; otherwise the loop is driven from the host."""
         n_batches = int(n_batches or self.args.n_batches)
-        if self.comm.active and self._native_comm is None:      # collectives on torch.distributed: host-driven loop
+        if self.comm.active and self._native_comm is None and self._peer is None:   # collectives on torch.distributed: host-driven loop
             self.buffer.store_episode(episode_batch)
             self._update_normalizer(episode_batch)
             self._update_network(n_batches)

@@ -35,13 +35,14 @@ class Communicator:
         self.force = bool(force) and self._dist is not None   # run the collectives even in a 1-rank group (tests)
         self.native = None        # library-side RCCL communicator (hp_comm *), see attach_native
         self._native_lib = None
+        self.peer = None          # library-side peer-memory exchange (hp_peer *), see attach_peer
 
     def attach_native(self, ctx):
         """Create (once) the library's own RCCL communicator for this rank.  Collective: every rank of the
         group must call it.  Returns the handle, or None when the group is not on GPUs / RLARM_COMM=torch."""
         if self.native is not None:
             return self.native
-        if not self.active or os.environ.get("RLARM_COMM", "native") == "torch":
+        if not self.active or os.environ.get("RLARM_COMM", "auto") not in ("auto", "native", "rccl"):
             return None
         if self._dist.get_backend() != "nccl":
             return None
@@ -66,7 +67,61 @@ class Communicator:
         self.native, self._native_lib = h, lib
         return h
 
+    def attach_peer(self, ctx, n_grad_floats):
+        """Create (once) the one-shot peer-memory exchange (csrc/peer.hip) for this rank: every rank exports a block of
+        device memory, the 64-byte IPC handles travel through the torch group, every rank maps the others' blocks, and a
+        self-check all-reduce must give the exact expected sums on every rank.  Collective.  Returns the handle, or None
+        (RLARM_COMM selects another transport, ranks cannot map each other's memory, self-check failed on any rank)."""
+        if self.peer is not None:
+            return self.peer
+        want = os.environ.get("RLARM_COMM", "auto")
+        if not self.active or want not in ("auto", "peer") or self.world_size > 16:
+            return None
+        lib, dist = ctx.lib, self._dist
+        dev = torch.device("cuda", ctx.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+        def agree(flag):   # every rank must take the same decision
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        h = C.c_void_p()
+        handle = (C.c_uint8 * 64)()
+        ok = lib.hp_peer_create(ctx.h, self.rank, self.world_size, int(n_grad_floats), C.byref(h), handle) == 0
+        mine = torch.tensor(list(handle) if ok else [0] * 64, dtype=torch.uint8, device=dev)
+        every = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(self.world_size)]
+        dist.all_gather(every, mine)
+        if not agree(ok):
+            if ok:
+                lib.hp_peer_destroy(h)
+            return None
+        raw = (C.c_uint8 * (64 * self.world_size))(*[int(b) for t in every for b in t.cpu().tolist()])
+        ok = lib.hp_peer_connect(h, raw) == 0
+        if ok:   # self-check: rank r contributes (r + 1) * (i + 1); the rank-ordered sum is exact in float32
+            n, w = 257, self.world_size
+            probe = torch.arange(1, n + 1, dtype=torch.float32, device=f"cuda:{ctx.device_id}") * float(self.rank + 1)
+            torch.cuda.synchronize(ctx.device_id)
+            for mean in (0, 1):
+                v = probe.clone()
+                torch.cuda.synchronize(ctx.device_id)
+                ok = ok and lib.hp_peer_allreduce_f32(h, C.c_void_p(v.data_ptr()), n, mean) == 0
+                ctx.synchronize()
+                expect = torch.arange(1, n + 1, dtype=torch.float32) * float(w * (w + 1) // 2)
+                if mean:
+                    expect = expect / float(w)
+                ok = ok and bool(torch.equal(v.cpu(), expect))
+            err = C.c_uint32()
+            ok = ok and lib.hp_peer_status(h, C.byref(err)) == 0 and err.value == 0
+        if not agree(ok):
+            lib.hp_peer_destroy(h)
+            return None
+        self.peer, self._native_lib = h, lib
+        return h
+
     def close(self):
+        if self.peer is not None:
+            self._native_lib.hp_peer_destroy(self.peer)
+            self.peer = None
         if self.native is not None:
             self._native_lib.hp_comm_destroy(self.native)
             self.native = None
@@ -136,7 +191,9 @@ class Communicator:
     def allreduce_mean_device(self, address, n):
         if not self.active:
             return
-        if self.native is not None:
+        if self.peer is not None and n <= 1024:
+            _lib.check(self._native_lib.hp_peer_allreduce_f32(self.peer, C.c_void_p(address), int(n), 1))
+        elif self.native is not None:
             _lib.check(self._native_lib.hp_comm_allreduce_mean_f32(self.native, C.c_void_p(address), int(n)))
         else:
             self.allreduce_mean_(self._view(address, n))

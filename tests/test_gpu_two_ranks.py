@@ -27,8 +27,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, transport="torch"):
     import sys
+    os.environ["RLARM_COMM"] = transport
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,7 +56,8 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)            # ranks start from DIFFERENT nets; sync_networks must fix that (C1)
     rng = DeviceRandomState(seed)
     agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100), None, dict(ENV_PARAMS), comm=comm, rng=rng)
-    assert agent._native_comm is None        # gloo group: torch transport
+    assert agent._native_comm is None        # gloo group: no RCCL (two ranks share one device)
+    assert (agent._peer is not None) == (transport == "peer")
     a0 = {k: v.detach().clone() for k, v in agent.actor_network.state_dict().items()}
     c0 = {k: v.detach().clone() for k, v in agent.critic_network.state_dict().items()}
     agent.buffer.store_episode(eps)
@@ -86,17 +89,36 @@ def _worker(rank, world, port, out_dir):
            "oracle_critic": learner.flat("critic"), "critic0": oupd.flatten(list(c0.values())),
            "rng_equal": bool(np.array_equal(rng.get_state()[1], rs.get_state()[1]) and rng.get_state()[2] == rs.get_state()[2]),
            "o_mean": np.asarray(agent.o_norm.mean), "oracle_o_mean": np.asarray(on.mean)}
+    if transport == "peer":
+        # the whole cycle as ONE hipGraph with the exchange inside (gradients per update, normalizer sums once)
+        import ctypes as C
+        more = make_episodes(2, seed=70 + rank, mode="walk")
+        agent.train_cycle(more, n_batches=5)
+        agent.train_cycle(make_episodes(2, seed=80 + rank, mode="walk"), n_batches=5)
+        mode, err = C.c_int32(), C.c_uint32()
+        _lib.check(agent.lib.hp_agent_cycle_mode(agent.h, C.byref(mode)))
+        _lib.check(agent.lib.hp_peer_status(agent._peer, C.byref(err)))
+        out.update(cycle_mode=mode.value, peer_error=err.value, actor_after_cycles=agent._get_flat(NET_ACTOR),
+                   g_std_after_cycles=np.asarray(agent.g_norm.std), losses_after=agent.last_losses(10))
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     _lib.Context.default().synchronize()
+    agent.close_comm()
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def two_ranks(tmp_path_factory):
-    out = tmp_path_factory.mktemp("gpu2")
-    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
-    return [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+@pytest.fixture(scope="module", params=["torch", "peer"])
+def two_ranks(request, tmp_path_factory):
+    """torch: collectives through torch.distributed (gloo, host-staged) from a host-driven loop.
+    peer: the library's one-shot all-reduce over IPC-mapped peer memory, fused with Adam (csrc/peer.hip) -- the two
+    processes map each other's exchange block on the shared device, which exercises flags, epochs, buffer ping-pong and the
+    rank-ordered sum exactly as two GPUs would (the fabric itself only exists on a multi-GPU node)."""
+    out = tmp_path_factory.mktemp("gpu2_" + request.param)
+    mp.spawn(_worker, args=(2, _free_port(), str(out), request.param), nprocs=2, join=True)
+    res = [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    for r in res:
+        r["transport"] = request.param
+    return res
 
 
 def test_ranks_end_with_identical_networks(two_ranks):
@@ -117,3 +139,14 @@ def test_each_rank_tracks_the_two_rank_oracle(two_ranks):
         for name in ("actor", "critic"):
             moved = np.linalg.norm(r[f"oracle_{name}"] - r[f"{name}0"])
             assert np.linalg.norm(r[name] - r[f"oracle_{name}"]) <= 0.05 * moved
+
+
+def test_peer_exchange_keeps_ranks_identical_through_graph_cycles(two_ranks):
+    r0, r1 = two_ranks
+    if r0["transport"] != "peer":
+        pytest.skip("peer-memory transport only")
+    assert r0["cycle_mode"] == 1 and r1["cycle_mode"] == 1          # the cycle, exchange included, replays as a hipGraph
+    assert r0["peer_error"] == 0 and r1["peer_error"] == 0
+    assert np.array_equal(r0["actor_after_cycles"].view(np.uint8), r1["actor_after_cycles"].view(np.uint8))
+    assert np.array_equal(r0["g_std_after_cycles"].view(np.uint8), r1["g_std_after_cycles"].view(np.uint8))
+    assert np.all(np.isfinite(r0["losses_after"])) and not np.array_equal(r0["losses_after"], r1["losses_after"])

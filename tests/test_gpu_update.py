@@ -376,7 +376,8 @@ def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
 
 
 @pytest.mark.parametrize("transport,graph,reduce", [("torch", False, "sum"), ("native", False, "sum"), ("native", True, "sum"),
-                                                    ("torch", False, "mean"), ("native", True, "mean")])
+                                                    ("torch", False, "mean"), ("native", True, "mean"),
+                                                    ("peer", False, "sum"), ("peer", True, "sum"), ("peer", True, "mean")])
 def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, monkeypatch):
     """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
     begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
@@ -406,6 +407,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         rng = fresh_rng(21)
         agent = ddpg_agent(args, None, dict(ENV_PARAMS), comm=comm, rng=rng)
         assert (comm.native is not None) == (transport == "native")
+        assert (comm.peer is not None) == (transport == "peer")      # one-shot exchange over peer memory (csrc/peer.hip)
         got = _run_cycles(agent, graph=graph)
         _lib.Context.default().synchronize()
         torch.cuda.synchronize()
