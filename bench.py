@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--feeder-episodes", type=int, default=0,
                     help="config 5 of BASELINE.json: a host feeder thread stores this many extra episodes per cycle while "
                          "the cycles run (not part of the default bench line)")
+    ap.add_argument("--feeder-envs", type=int, default=0,
+                    help="config 5 of BASELINE.json with REAL rollouts: this many stand-in GoalEnvs stepped by worker "
+                         "processes (rl_arm_under_sparse_reward_amd/feeder.py) on the snapshot policy while the cycles run; "
+                         "every finished wave is stored into the shard by DMA out of the shared ring (not the default line)")
+    ap.add_argument("--feeder-workers", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -108,6 +113,26 @@ class Runner:
 
             self.feeder = threading.Thread(target=feed, daemon=True)
             self.feeder.start()
+        self.env_feeder = None
+        if getattr(a, "feeder_envs", 0) > 0:
+            import threading
+
+            from rl_arm_under_sparse_reward_amd.feeder import EpisodeFeeder
+            from rl_arm_under_sparse_reward_amd.synthetic import PointMassGoalEnv
+            specs = [(PointMassGoalEnv, dict(seed=1000 * rank + i, max_timesteps=100)) for i in range(a.feeder_envs)]
+            self.agent.policy_snapshot()
+            self.env_feeder = EpisodeFeeder(self.agent, specs, n_workers=a.feeder_workers, n_slots=3, seed=77 + rank,
+                                            snapshot_policy=True)
+            self.env_stop = False
+            self.env_waves = 0
+
+            def roll():
+                while not self.env_stop:
+                    slot = self.env_feeder.collect_wave(explore=True)
+                    self.env_feeder.store_wave(slot)
+                    self.env_waves += 1
+
+            self.env_thread = threading.Thread(target=roll, daemon=True)
         self.ctx.synchronize()
 
     def _open_cycle_eager(self):
@@ -122,6 +147,8 @@ class Runner:
             if self.in_cycle == 0 and self.feeder is not None:
                 self.feed_sem.release()      # one feeder batch per cycle, concurrent with it
                 self._releases += 1
+            if self.in_cycle == 0 and self.env_feeder is not None:
+                ag.policy_snapshot()         # the rollout workers' policy follows the learner one cycle behind
             if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None
                                                           or ag._peer is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
@@ -319,11 +346,14 @@ def main():
     gc.freeze()
     gc.disable()
     barrier(world)
+    if r.env_feeder is not None:
+        r.env_thread.start()                 # rollouts run concurrently with everything below
     r.run_steps(a.warmup)
     r.sync()
     barrier(world)
     r.sync()
     opens0, closes0 = r.opens, r.closes
+    waves0 = r.env_waves if r.env_feeder is not None else 0
     t0 = time.perf_counter()
     r.run_steps(a.steps)
     r.sync()
@@ -331,6 +361,18 @@ def main():
     r.sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    feeder_stats = None
+    if r.env_feeder is not None:
+        waves = r.env_waves - waves0
+        r.env_stop = True
+        r.env_thread.join(timeout=30)
+        feeder_stats = {"envs": a.feeder_envs, "worker_processes": r.env_feeder.n_workers, "waves_in_timed_region": waves,
+                        "episodes_per_s": round(waves * a.feeder_envs / dt, 1),
+                        "env_steps_per_s": round(waves * a.feeder_envs * 100 / dt, 1),
+                        "policy": "hp_agent_act_snapshot on a second stream (snapshot per cycle), one batched call per timestep",
+                        "store": "hp_buffer_store_pinned: DMA out of the device-registered shared-memory ring",
+                        "env": "synthetic.PointMassGoalEnv (PyBullet is absent from the box)"}
+        r.env_feeder.close()
     # cycle-boundary work inside the timed region: [store 2 episodes + normalizer refresh, polyak]; a steady state has
     # one of each per 40 steps
     boundaries = {"store_and_normalizer": r.opens - opens0, "polyak": r.closes - closes0,
@@ -371,6 +413,7 @@ def main():
         "init": "untimed before the warm-up: one training cycle (cycle hipGraph capture / exchange set-up) and one rehearsal "
                 "of the warm-up + timed step pattern (partial-cycle graph captures), ending on a cycle boundary",
         "cycle_boundaries_in_timed_region": boundaries,
+        **({"host_feeder": feeder_stats} if feeder_stats else {}),
         "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",

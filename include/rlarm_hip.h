@@ -102,6 +102,16 @@ int hp_buffer_store(hp_buffer *buf, hp_rng *rng, const double *obs, const double
  * hp_norm_update_from_staged then samples from exactly these episodes.  n_new == 0 -> "high <= 0" like numpy. */
 int hp_buffer_stage(hp_buffer *buf, const double *obs, const double *ag, const double *g, const double *actions,
                     int64_t n_new);
+/* Multi-process host feeder (the rollout workers of ddpg_agent.py:101-142 as processes): the episodes of a wave are
+ * written by the workers into ONE host block [obs n x (T+1) x obs_dim | ag | g | actions] that the trainer registered
+ * with the device (hp_host_register, e.g. a POSIX shared-memory segment).  hp_buffer_store_pinned is store_episode on
+ * such a block without the CPU copy: the DMA reads the block directly and asynchronously (slot draw and scatter as in
+ * hp_buffer_store); the block may be rewritten once hp_buffer_store_done reports its ticket done (wait != 0 blocks,
+ * outside the context lock). */
+int hp_host_register(hp_ctx *ctx, void *host, size_t bytes);
+int hp_host_unregister(hp_ctx *ctx, void *host);
+int hp_buffer_store_pinned(hp_buffer *buf, hp_rng *rng, const double *block, int64_t n_new, uint64_t *ticket);
+int hp_buffer_store_done(hp_buffer *buf, uint64_t ticket, int32_t wait, int32_t *done);
 int hp_buffer_info(hp_buffer *buf, int64_t *size, int64_t *current_size, int64_t *n_transitions_stored,
                    int32_t *T);
 /* slots chosen by the most recent hp_buffer_store (parity tests); synchronises */
@@ -236,6 +246,15 @@ int hp_agent_critic_forward(hp_agent *ag, int32_t net, const float *x_host, cons
  * rollouts do not, so the drop-in passes 0.  rows = the environments of a vectorised feeder stepped in lockstep. */
 int hp_agent_act(hp_agent *ag, hp_norm *o_norm, hp_norm *g_norm, int32_t net, const double *obs_host,
                  const double *g_host, int64_t rows, double clip_obs, float *actions_host);
+
+/* Policy calls that do not queue behind training: hp_agent_policy_snapshot copies the online actor and both normalizers'
+ * statistics (stream-ordered with the updates, no host wait); hp_agent_act_snapshot evaluates the most recent COMPLETE
+ * snapshot on a second stream, so a feeder can step its environments while a training cycle runs (its policy lags the
+ * learner by at most one snapshot interval; the reference's rollouts are synchronous, ddpg_agent.py:101-150).  Same
+ * arithmetic as hp_agent_act.  Callable from another host thread. */
+int hp_agent_policy_snapshot(hp_agent *ag, hp_norm *o_norm, hp_norm *g_norm);
+int hp_agent_act_snapshot(hp_agent *ag, const double *obs_host, const double *g_host, int64_t rows, double clip_obs,
+                          float *actions_host);
 
 /* Split-phase update for data-parallel ranks (utils.sync_grads, utils.py:43-48):
  *   forward_backward: sample + forwards + backwards, leaves SUM-able gradients in one flat device

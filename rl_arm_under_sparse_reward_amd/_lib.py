@@ -62,6 +62,10 @@ PROTOTYPES = {
     "hp_buffer_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_void_pp]),
     "hp_buffer_store": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p, C.c_int64]),
     "hp_buffer_stage": (C.c_int, [C.c_void_p, f64p, f64p, f64p, f64p, C.c_int64]),
+    "hp_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hp_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_buffer_store_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]),
+    "hp_buffer_store_done": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]),
     "hp_buffer_info": (C.c_int, [C.c_void_p, i64p, i64p, i64p, C.POINTER(C.c_int32)]),
     "hp_buffer_last_slots": (C.c_int, [C.c_void_p, i64p, C.c_int64]),
     "hp_buffer_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, f64p]),
@@ -98,6 +102,8 @@ PROTOTYPES = {
     "hp_agent_actor_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64, f32p]),
     "hp_agent_critic_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int64, f32p]),
     "hp_agent_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, f64p, f64p, C.c_int64, C.c_double, f32p]),
+    "hp_agent_policy_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hp_agent_act_snapshot": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int64, C.c_double, f32p]),
     "hp_agent_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_double]),
     "hp_agent_grad_buffer": (C.c_int, [C.c_void_p, c_void_pp, i64p]),

@@ -317,6 +317,19 @@ struct hp_agent {
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
+    // policy snapshots for a feeder that steps environments while cycles run (hp_agent_policy_snapshot / _act_snapshot)
+    struct PolicySnap {
+        float *params = nullptr, *fragF = nullptr;   // actor segment of the arenas
+        NormDev *on = nullptr, *gn = nullptr;
+        double clip_o = 0, clip_g = 0;
+        int od = 0, gd = 0;
+        hipEvent_t ready = nullptr;
+    } snap[2];
+    int snap_cur = -1, snap_pending = -1;
+    hipStream_t act_stream = nullptr;
+    hipEvent_t act_done = nullptr;
+    bool act_recorded = false;
+    DevBuf act_ws;
     PinnedBuf pin;
     std::vector<void *> owned;
     // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
@@ -1938,6 +1951,93 @@ int hp_agent_act(hp_agent *a, hp_norm *on, hp_norm *gn, int32_t net, const doubl
 
 }  // extern "C"
 
+extern "C" {
+
+int hp_agent_policy_snapshot(hp_agent *a, hp_norm *on, hp_norm *gn) {
+    HP_REQUIRE(a && on && gn, HP_ERR_INVALID, "hp_agent_policy_snapshot: null argument");
+    HP_SERIALISE(a);
+    HP_REQUIRE(a->slab8, HP_ERR_STATE, "hp_agent_policy_snapshot: needs the fused policy kernel (slab8 engine)");
+    HP_REQUIRE(on->size + gn->size == a->xdim, HP_ERR_INVALID, "hp_agent_policy_snapshot: normalizer sizes do not match the actor");
+    hipStream_t s = a->ctx->stream;
+    if (!a->act_stream) {
+        HP_CHECK_HIP(hipStreamCreateWithFlags(&a->act_stream, hipStreamNonBlocking));
+        HP_CHECK_HIP(hipEventCreateWithFlags(&a->act_done, hipEventDisableTiming));
+        for (auto &ps : a->snap) {
+            HP_CHECK_HIP(hipMalloc((void **)&ps.params, sizeof(float) * a->la.total));
+            HP_CHECK_HIP(hipMalloc((void **)&ps.fragF, sizeof(float) * a->la.total));
+            HP_CHECK_HIP(hipMalloc((void **)&ps.on, sizeof(NormDev)));
+            HP_CHECK_HIP(hipMalloc((void **)&ps.gn, sizeof(NormDev)));
+            HP_CHECK_HIP(hipEventCreateWithFlags(&ps.ready, hipEventDisableTiming));
+        }
+    }
+    const int target = (a->snap_cur == 0) ? 1 : 0;        // never the set policy calls are reading
+    hp_agent::PolicySnap &ps = a->snap[target];
+    if (a->act_recorded) HP_CHECK_HIP(hipStreamWaitEvent(s, a->act_done, 0));
+    const size_t nb = sizeof(float) * a->la.total;
+    HP_CHECK_HIP(hipMemcpyAsync(ps.params, a->params, nb, hipMemcpyDeviceToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(ps.fragF, a->fragF, nb, hipMemcpyDeviceToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(ps.on, on->d, sizeof(NormDev), hipMemcpyDeviceToDevice, s));
+    HP_CHECK_HIP(hipMemcpyAsync(ps.gn, gn->d, sizeof(NormDev), hipMemcpyDeviceToDevice, s));
+    ps.clip_o = on->clip; ps.clip_g = gn->clip; ps.od = on->size; ps.gd = gn->size;
+    HP_CHECK_HIP(hipEventRecord(ps.ready, s));
+    a->snap_pending = target;
+    return HP_OK;
+}
+
+int hp_agent_act_snapshot(hp_agent *a, const double *obs_host, const double *g_host, int64_t rows, double clip_obs,
+                          float *actions_host) {
+    HP_REQUIRE(a && obs_host && g_host && actions_host, HP_ERR_INVALID, "hp_agent_act_snapshot: null argument");
+    HP_REQUIRE(rows > 0 && rows < (1 << 24), HP_ERR_INVALID, "hp_agent_act_snapshot: rows out of range");
+    hipStream_t s = nullptr;
+    {
+        HP_SERIALISE(a);
+        HP_REQUIRE(a->snap_cur >= 0 || a->snap_pending >= 0, HP_ERR_STATE, "hp_agent_act_snapshot: no snapshot taken yet");
+        if (a->snap_pending >= 0) {
+            hipEvent_t ev = a->snap[a->snap_pending].ready;
+            hipError_t q = hipEventQuery(ev);
+            if (q == hipErrorNotReady && a->snap_cur < 0) {   // the very first snapshot: nothing older to fall back to
+                HP_CHECK_HIP(hipEventSynchronize(ev));
+                q = hipSuccess;
+            }
+            (void)hipGetLastError();
+            if (q == hipSuccess) {
+                a->snap_cur = a->snap_pending;
+                a->snap_pending = -1;
+            }
+        }
+        const hp_agent::PolicySnap &ps = a->snap[a->snap_cur];
+        s = a->act_stream;
+        const int ad = a->cfg.act_dim;
+        const size_t nb_o = (size_t)rows * ps.od * 8, nb_g = (size_t)rows * ps.gd * 8;
+        const size_t head = (nb_o + nb_g + 15) & ~(size_t)15;
+        HP_TRY(a->act_ws.ensure(head + (size_t)rows * ad * 4));
+        char *d = a->act_ws.as<char>();
+        float *d_act = reinterpret_cast<float *>(d + head);
+        HP_CHECK_HIP(hipMemcpyAsync(d, obs_host, nb_o, hipMemcpyHostToDevice, s));
+        HP_CHECK_HIP(hipMemcpyAsync(d + nb_o, g_host, nb_g, hipMemcpyHostToDevice, s));
+        PolicyArgs P;
+        memset(&P, 0, sizeof(P));
+        P.obs = reinterpret_cast<const double *>(d);
+        P.g = reinterpret_cast<const double *>(d + nb_o);
+        P.od = ps.od; P.gd = ps.gd;
+        P.onz = ps.on; P.gnz = ps.gn;
+        P.clip_obs = clip_obs > 0 ? clip_obs : INFINITY; P.clip_o = ps.clip_o; P.clip_g = ps.clip_g;
+        P.rows = (int)rows;
+        P.net = SlabNetPtrs{ps.fragF, nullptr, ps.params};
+        P.la = a->la; P.H = a->H; P.act_dim = ad; P.max_action = (float)a->cfg.max_action;
+        P.actions = d_act;
+        hipLaunchKernelGGL(s8r4::k_policy_slab8, dim3((unsigned)((rows + 3) / 4)), dim3(S8_THREADS), 0, s, P);
+        HP_CHECK_HIP(hipGetLastError());
+        HP_CHECK_HIP(hipMemcpyAsync(actions_host, d_act, (size_t)rows * ad * 4, hipMemcpyDeviceToHost, s));
+        HP_CHECK_HIP(hipEventRecord(a->act_done, s));
+        a->act_recorded = true;
+    }
+    HP_CHECK_HIP(hipStreamSynchronize(s));   // outside the context lock: the trainer keeps enqueueing meanwhile
+    return HP_OK;
+}
+
+}  // extern "C"
+
 // device part of one cycle after the episodes are staged: slots+scatter happen in buffer_stage_and_store
 static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
                               double sq, int n_batches, PlanRec *norm_plan) {
@@ -2218,6 +2318,19 @@ void hp_agent_destroy(hp_agent *a) {
     drop_graph(a);
     (void)hipStreamSynchronize(a->ctx->stream);
     for (void *p : a->owned) (void)hipFree(p);
+    if (a->act_stream) {
+        (void)hipStreamSynchronize(a->act_stream);
+        for (auto &ps : a->snap) {
+            if (ps.params) (void)hipFree(ps.params);
+            if (ps.fragF) (void)hipFree(ps.fragF);
+            if (ps.on) (void)hipFree(ps.on);
+            if (ps.gn) (void)hipFree(ps.gn);
+            if (ps.ready) (void)hipEventDestroy(ps.ready);
+        }
+        (void)hipEventDestroy(a->act_done);
+        (void)hipStreamDestroy(a->act_stream);
+    }
+    a->act_ws.release();
     a->plan.release();
     a->adam_tab.release();
     a->norm_plan.release();

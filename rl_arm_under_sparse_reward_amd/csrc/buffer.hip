@@ -208,6 +208,81 @@ int hp_buffer_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *
     return buffer_stage_and_store(b, rng, obs, ag, g, actions, n_new);
 }
 
+// ---- multi-process feeder support: episodes arrive in a host block the caller registered with the device
+// (shared memory that worker processes write), laid out obs | ag | g | actions back to back like the library's own
+// staging; the H2D copy reads it directly and asynchronously, the block may be rewritten once the returned ticket is done.
+int hp_host_register(hp_ctx *ctx, void *host, size_t bytes) {
+    HP_REQUIRE(ctx && host && bytes > 0, HP_ERR_INVALID, "hp_host_register: bad argument");
+    CtxGuard guard(ctx);
+    HP_CHECK_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return HP_OK;
+}
+
+int hp_host_unregister(hp_ctx *ctx, void *host) {
+    HP_REQUIRE(ctx && host, HP_ERR_INVALID, "hp_host_unregister: bad argument");
+    CtxGuard guard(ctx);
+    HP_CHECK_HIP(hipHostUnregister(host));
+    return HP_OK;
+}
+
+int hp_buffer_store_pinned(hp_buffer *b, hp_rng *rng, const double *block, int64_t n_new, uint64_t *ticket) {
+    HP_REQUIRE(b && rng && block, HP_ERR_INVALID, "hp_buffer_store_pinned: null argument");
+    HP_SERIALISE(b);
+    HP_REQUIRE(n_new > 0, HP_ERR_INVALID, "hp_buffer_store_pinned: n_new must be positive");
+    HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
+    hipStream_t s = b->ctx->stream;
+    const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
+                 n3 = n_new * b->ep_act() * 8;
+    HP_TRY(b->st_slots.ensure(n_new * 8));
+    HP_TRY(b->st_obs.ensure(n0 + n1 + n2 + n3));
+    char *dst = b->st_obs.as<char>();
+    b->st_ag = reinterpret_cast<double *>(dst + n0);
+    b->st_g = reinterpret_cast<double *>(dst + n0 + n1);
+    b->st_act = reinterpret_cast<double *>(dst + n0 + n1 + n2);
+    HP_CHECK_HIP(hipMemcpyAsync(dst, block, n0 + n1 + n2 + n3, hipMemcpyHostToDevice, s));
+    // ticket: an event behind the copy, from a small ring (a ticket older than the ring is done by construction: its
+    // event is re-recorded only after this call synchronised on it)
+    const uint64_t t = ++b->pin_tickets;
+    hipEvent_t &ev = b->pin_events[t % hp_buffer::PIN_RING];
+    if (!ev) HP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else HP_CHECK_HIP(hipEventSynchronize(ev));
+    HP_CHECK_HIP(hipEventRecord(ev, s));
+    if (ticket) *ticket = t;
+    b->staged_n = n_new;
+    HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
+    hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)(n_new * STORE_PARTS)), dim3(256), 0, s, b->st_slots.as<long long>(),
+                       (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g, b->st_act, b->d_obs, b->d_ag, b->d_g,
+                       b->d_act, (long long)b->ep_obs(), (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
+    HP_CHECK_HIP(hipGetLastError());
+    b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
+    b->n_transitions_stored += (int64_t)b->T * n_new;
+    return HP_OK;
+}
+
+int hp_buffer_store_done(hp_buffer *b, uint64_t ticket, int32_t wait, int32_t *done) {
+    HP_REQUIRE(b && done, HP_ERR_INVALID, "hp_buffer_store_done: null argument");
+    hipEvent_t ev = nullptr;
+    {
+        HP_SERIALISE(b);
+        HP_REQUIRE(ticket >= 1 && ticket <= b->pin_tickets, HP_ERR_INVALID, "hp_buffer_store_done: unknown ticket");
+        if (ticket + hp_buffer::PIN_RING <= b->pin_tickets) {   // its event slot has been reused: that store is long done
+            *done = 1;
+            return HP_OK;
+        }
+        ev = b->pin_events[ticket % hp_buffer::PIN_RING];
+    }
+    if (wait) {   // outside the context lock: a feeder waiting for its block must not stall the trainer's enqueues
+        HP_CHECK_HIP(hipEventSynchronize(ev));
+        *done = 1;
+        return HP_OK;
+    }
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipSuccess && e != hipErrorNotReady) HP_CHECK_HIP(e);
+    (void)hipGetLastError();
+    *done = (e == hipSuccess) ? 1 : 0;
+    return HP_OK;
+}
+
 int hp_buffer_stage(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
                     int64_t n_new) {
     HP_REQUIRE(b && obs && ag && g && actions, HP_ERR_INVALID, "hp_buffer_stage: null argument");
@@ -426,6 +501,8 @@ void hp_buffer_destroy(hp_buffer *b) {
     if (b->d_g) (void)hipFree(b->d_g);
     if (b->d_act) (void)hipFree(b->d_act);
     if (b->d_meta) (void)hipFree(b->d_meta);
+    for (hipEvent_t ev : b->pin_events)
+        if (ev) (void)hipEventDestroy(ev);
     b->st_obs.release();
     b->st_slots.release();
     b->pin.release();

@@ -158,6 +158,10 @@ struct hp_buffer {
     double *st_ag = nullptr, *st_g = nullptr, *st_act = nullptr;
     PinnedBuf pin;
     int64_t staged_n = 0;
+    // hp_buffer_store_pinned: tickets of the asynchronous copies out of caller-registered host blocks
+    static constexpr int PIN_RING = 16;
+    hipEvent_t pin_events[PIN_RING] = {nullptr};
+    uint64_t pin_tickets = 0;
     // sampling scratch
     DevBuf plan, out;
     size_t ep_obs() const { return (size_t)(T + 1) * obs_dim; }

@@ -293,6 +293,21 @@ class ddpg_agent:
             *self._handles(), _lib.ptr(obs, d), _lib.ptr(ag, d), _lib.ptr(g, d), _lib.ptr(act, d), n_new,
             float(self.her_module.future_p), float(self.her_module.sq_threshold), n_batches))
 
+    def train_cycle_from_feeder(self, feeder, slot, n_batches=None):
+        """ddpg_agent.py:143-150 on the episodes of a feeder wave: store_episode is an asynchronous DMA out of the feeder's
+        registered shared-memory slot (no CPU copy), the normalizer samples the staged episodes, the updates replay their
+        cached graph.  Asynchronous; ranks of a data-parallel group call it in step like train_cycle."""
+        n_batches = int(n_batches or self.args.n_batches)
+        feeder.store_wave(slot)
+        self._update_normalizer()
+        self._update_network(n_batches)
+        self._soft_update_target_network()
+
+    def policy_snapshot(self):
+        """Publish the current actor + normalizer statistics to feeders that call the policy while cycles run
+        (hp_agent_act_snapshot): stream-ordered with the updates, no host wait."""
+        _lib.check(self.lib.hp_agent_policy_snapshot(self.h, self.o_norm.h, self.g_norm.h))
+
     # ------------------------------------------------------------------ demos / checkpoints (formats preserved)
     def plot_success_rate(self):
         """ddpg_agent.py:73-80: dump the per-epoch success rates where the reference does; the plot itself needs

@@ -6,7 +6,7 @@ import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--segments", type=int, default=24); ap.add_argument("--cycles", type=int, default=10)
 ap.add_argument("--mode", default="cycle")
 x = ap.parse_args()
-a = argparse.Namespace(gpus=1, steps=0, warmup=0, batch=256, episodes=5000, replay_k=4, feeder_episodes=0)
+a = argparse.Namespace(gpus=1, steps=0, warmup=0, batch=256, episodes=5000, replay_k=4, feeder_episodes=0, feeder_envs=0)
 r = bench.Runner(a, 0, 1)
 import gc
 if x.mode == "nogc":
