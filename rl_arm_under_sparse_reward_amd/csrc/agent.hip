@@ -271,6 +271,51 @@ static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, 
 #undef S8_RING
 #undef S8_RPW
 
+// Weight-gradient tiles (+ optimizer) with the sampler's look-ahead riding along.  When the chain kernel occupies every
+// CU (batch 1024: 256 chain workgroups) it has no room for its spare workgroups -- a workgroup appended to a full launch
+// starts when the first chain ends and then runs alone (k_fb_slab8 51.5 instead of 37.8 us) -- so the index plan of
+// update u + 2 and the gather of update u + 1's inputs move into THIS launch, whose 296 tile workgroups leave half of the
+// CUs' slots free: blocks [tiles, tiles + n_plan) draw, the next n_ahead gather.  Same device functions as the chain
+// kernel's spare workgroups, same order of draws in the stream: identical bits.
+struct RideArgs {
+    int n_plan, n_ahead;
+    MtState *rng;
+    const BufMeta *meta;
+    PlanRec *next_plan;
+    double future_p;
+    int T, plan_batch;
+    GatherSrc ahead;
+    float *aXT, *aXA, *aXP;
+    int ldx, act_off, act_dim;
+    float max_action;
+};
+
+template <bool ADAM>
+__device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, int tiles) {
+    __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
+    __shared__ float bsum[GL_WAVES][32];
+    if ((int)blockIdx.x < tiles) {
+        gemm_tile<ADAM>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
+        return;
+    }
+    const int extra = (int)blockIdx.x - tiles;
+    if (extra < R.n_plan) {
+        if (threadIdx.x >= MT_THREADS) return;   // ended waves take no part in the barriers of the draw
+        mt_her_plan(R.rng, R.meta->current_size, R.T, R.plan_batch, 1, R.future_p, R.next_plan,
+                    reinterpret_cast<uint32_t(*)[MT_N]>(lds), reinterpret_cast<int *>(&bsum[0][0]));
+    } else {
+        s8r4::s8_gather_ahead(R.ahead, R.aXT, R.aXA, R.aXP, R.ldx, R.act_off, R.act_dim, R.max_action, extra - R.n_plan,
+                              R.n_ahead);
+    }
+}
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride(const GemmGroup grp, const RideArgs R, int tiles) {
+    gemm_ride_body<false>(grp, nullptr, R, tiles);
+}
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(const GemmGroup grp, const AdamFuse F, const RideArgs R,
+                                                                   int tiles) {
+    gemm_ride_body<true>(grp, &F, R, tiles);
+}
+
 
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
@@ -326,6 +371,11 @@ struct hp_agent {
         hipEvent_t ready = nullptr;
     } snap[2];
     int snap_cur = -1, snap_pending = -1;
+    // index plans of later updates drawn on a second stream, concurrently with the chain kernel, when the launch has no
+    // spare CU for a ride-along plan workgroup (enqueue_updates)
+    hipStream_t plan_stream = nullptr;
+    hipEvent_t plan_fork = nullptr, plan_join = nullptr;
+    int plan_side = -1;                  // RLARM_PLAN_SIDE: -1 by occupancy, 0 never, 1 always
     hipStream_t act_stream = nullptr;
     hipEvent_t act_done = nullptr;
     bool act_recorded = false;
@@ -889,12 +939,13 @@ static void add_dw(Launch &L, const float *dY, int ldy, int Nout, const float *X
     p.epi = EPI_NONE;
 }
 
-static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq) {
+static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq,
+                          int xset = 0, hipStream_t stream = nullptr) {
     ProfScope ps(a, PROF_SAMPLE);
-    hipLaunchKernelGGL(k_gather_fused, dim3((a->B + 3) / 4), dim3(256), 0, a->ctx->stream, b->d_obs, b->d_ag, b->d_g,
-                       b->d_act, plan, a->B, (int)b->T, (int)b->obs_dim, (int)b->goal_dim, (int)b->act_dim, sq, on->d,
-                       gn->d, a->cfg.clip_obs, a->cfg.clip_range, (float)a->cfg.max_action, a->ldx, a->act_off, a->XA,
-                       a->XP, a->XT, a->R);
+    hipLaunchKernelGGL(k_gather_fused, dim3((a->B + 3) / 4), dim3(256), 0, stream ? stream : a->ctx->stream, b->d_obs, b->d_ag,
+                       b->d_g, b->d_act, plan, a->B, (int)b->T, (int)b->obs_dim, (int)b->goal_dim, (int)b->act_dim, sq, on->d,
+                       gn->d, a->cfg.clip_obs, a->cfg.clip_range, (float)a->cfg.max_action, a->ldx, a->act_off,
+                       xset ? a->XA2 : a->XA, xset ? a->XP2 : a->XP, xset ? a->XT2 : a->XT, xset ? a->R2 : a->R);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -916,6 +967,9 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     const PlanRec *ahead_plan = nullptr;
     // fused single-launch update: index of this update in its sequence (-1: chain kernel + tile kernel as two launches)
     int fuse_u = -1;
+    // full chain launch: the plan draw (next_plan) and the look-ahead gather (ahead_plan) ride in the weight-gradient
+    // launch instead of the chain kernel
+    bool ride_in_dw = false;
     // data-parallel ranks exchanging through peer memory: this update's gradients go straight into the exchange buffer
     float *grads_out = nullptr;
 };
@@ -1054,8 +1108,6 @@ static int enqueue_forward_backward_layers(hp_agent *a) {
     return HP_OK;
 }
 
-static int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq);
-
 // one update's forwards + backwards.  gc == nullptr: the minibatch is already staged in XA/XP/XT/R.
 // fuse_adam: the optimizer step follows immediately on this rank (no gradient exchange): the slab engines then apply
 // it in the weight-gradient GEMM's epilogue and the caller must NOT enqueue Adam again (returns that via *fused).
@@ -1151,7 +1203,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.CPh1 = a->CP.h1; A.CPh2 = a->CP.h2; A.CPh3 = a->CP.h3;
         A.QT = a->QT; A.QA = a->QA; A.QP = a->QP;
     }
-    const bool ride = gc && gc->next_plan && gc->rng;
+    const bool ride_dw = gc && gc->ride_in_dw;
+    const bool ride = gc && gc->next_plan && gc->rng && !ride_dw;
     {
         BwdSlabArgs &A = P.b;
         A.tl = a->timeline + 96;
@@ -1185,7 +1238,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         P.xcd_split = (nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count);
         P.ahead = P.f.gs;
         P.aXT = P.aXA = P.aXP = nullptr;
-        if (gc && gc->ahead_plan) {   // next update's inputs into the other set
+        if (gc && gc->ahead_plan && !ride_dw) {   // next update's inputs into the other set
             P.n_ahead = S8_AHEAD_WGS;
             P.ahead.plan = gc->ahead_plan;
             P.ahead.plan_any = gc->ahead_plan;
@@ -1237,7 +1290,33 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     }
     if (!fused) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
         Launch L = build_dw_group(a, sXA, sXP, gc ? gc->grads_out : nullptr);
-        if (fuse_adam) {
+        if (ride_dw && ((gc->next_plan && gc->rng) || gc->ahead_plan)) {
+            ProfScope ps(a, PROF_DW);
+            RideArgs R;
+            memset(&R, 0, sizeof(R));
+            if (gc->next_plan && gc->rng) {
+                R.n_plan = 1;
+                R.rng = gc->rng->d_state; R.meta = gc->b->d_meta; R.next_plan = gc->next_plan; R.future_p = gc->future_p;
+                R.T = gc->b->T; R.plan_batch = a->B;
+            }
+            if (gc->ahead_plan) {
+                R.n_ahead = 8;
+                R.ahead = P.f.gs;
+                R.ahead.plan = gc->ahead_plan; R.ahead.plan_any = gc->ahead_plan;
+                R.ahead.R = xs ? a->R : a->R2;
+                R.aXT = xs ? a->XT : a->XT2; R.aXA = xs ? a->XA : a->XA2; R.aXP = xs ? a->XP : a->XP2;
+                R.ldx = ldx; R.act_off = a->act_off; R.act_dim = a->cfg.act_dim; R.max_action = (float)a->cfg.max_action;
+            }
+            const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
+            if (fuse_adam) {
+                AdamFuse F = adam_fuse(a);
+                F.keep_grads = 0;
+                hipLaunchKernelGGL(k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
+            } else {
+                hipLaunchKernelGGL(k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
+            }
+            HP_CHECK_HIP(hipGetLastError());
+        } else if (fuse_adam) {
             ProfScope ps(a, PROF_DW);
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
             // the ~6.7 MB this kernel leaves dirty in L2 for the end-of-kernel write-back
@@ -1331,14 +1410,22 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const bool ride = a->slab && with_adam;
     // merged slab8 kernel: plans are drawn TWO updates ahead so that spare workgroups of update u can gather the inputs
     // of update u+1 from a plan that an earlier launch finished (the order of draws in the stream is unchanged)
-    const bool ahead = ride && a->slab8 && a->gather_ahead;
-    const int lead = ahead ? 2 : 1;
     // Single-launch updates: the weight-gradient tiles and the optimizer run as a second phase of the chain kernel
     // (slab8.h FuseArgs).  Needs the optimizer to follow the gradients directly (one rank) and every chain workgroup
     // resident at once (one per CU: the tile phase starts when ALL chains have published).
     const int chains = 2 * (a->Mp / a->s8_rows);
     const bool fuse_dw = a->slab8 && with_adam && !a->comm && !a->peer && a->fuse_adam_ok && a->fuse_dw_ok && a->d_grp &&
                          chains <= a->ctx->cu_count;
+    // ... and when the launch is full (no CU for spare workgroups) both jobs move out of the chain kernel
+    const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
+    // slab8 engine, full launch: both jobs ride in the weight-gradient launch (k_gemm_lds_adam_ride); RLARM_PLAN_SIDE=2
+    // keeps the second-stream variant for A/B (its cross-queue graph edges cost ~4 us each: 65.5 vs 71.4 us at batch 1024)
+    const bool want_offload = ride && a->slab8 && !fuse_dw && a->plan_side != 0 && (a->plan_side >= 1 || full) &&
+                              (getenv("RLARM_AHEAD") ? a->gather_ahead : true);
+    const bool side_gather = want_offload && a->plan_side == 2 && !a->prof;
+    const bool dw_ride = want_offload && !side_gather;
+    const bool ahead = ride && a->slab8 && (a->gather_ahead || side_gather || dw_ride);
+    const int lead = ahead ? 2 : 1;
     if (fuse_dw) {
         hipLaunchKernelGGL(k_seq_begin, dim3((n_updates + 63) / 64), dim3(64), 0, a->ctx->stream, a->d_state, a->fsync,
                            a->adam_tab.as<float>(), n_updates, adam_cfg(a));
@@ -1349,18 +1436,57 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? (n_updates < lead ? n_updates : lead) : n_updates,
                                future_p, a->plan.as<PlanRec>()));
     }
+    // Where the plan of update u + lead is drawn: by a spare workgroup of update u's own launch while that launch leaves
+    // a CU free -- or, when the chains occupy every CU (batch 1024: 256 chain workgroups; the 16-row engine beyond), by
+    // k_draw_plan on a second stream next to the chain kernel.  A workgroup appended to a full launch only starts when
+    // the first chain ends and then runs its sequential MT19937 draw alone: measured 51.5 vs 37.8 us for k_fb_slab8 at
+    // batch 1024 and 96 vs 51 us for k_bwd_slab at batch 4096 (profiles/r02_large_batch_traces.txt).
+    const int spare_cus = a->ctx->cu_count - (a->slab8 ? chains + (ahead && !side_gather ? S8_AHEAD_WGS : 0)
+                                                       : 3 * (a->Mp / SL_ROWS));
+    const bool side = side_gather || (ride && !dw_ride && !a->prof && (a->plan_side >= 0 ? a->plan_side >= 1 : spare_cus < 1));
+    if (side && !a->plan_stream) {
+        HP_CHECK_HIP(hipStreamCreateWithFlags(&a->plan_stream, hipStreamNonBlocking));
+        HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_fork, hipEventDisableTiming));
+        HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_join, hipEventDisableTiming));
+    }
+    bool join_pending = false;
     for (int u = 0; u < n_updates; ++u) {
         GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
+        hipStream_t ms = a->ctx->stream;
+        if (join_pending) {   // the plan drawn beside the previous update is what this launch gathers from
+            HP_CHECK_HIP(hipStreamWaitEvent(ms, a->plan_join, 0));
+            join_pending = false;
+        }
+        const bool gather_beside = side_gather && u + 1 < n_updates;
+        if (side && (gather_beside || (ride && u + lead < n_updates))) {
+            // fork: ordered behind everything enqueued so far (the previous draws included), concurrent with update u
+            HP_CHECK_HIP(hipEventRecord(a->plan_fork, ms));
+            HP_CHECK_HIP(hipStreamWaitEvent(a->plan_stream, a->plan_fork, 0));
+            if (gather_beside)   // inputs of update u + 1 into the other input set, from the plan an earlier draw finished
+                HP_TRY(enqueue_gather(a, b, on, gn, a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B, sq, (u + 1) & 1,
+                                      a->plan_stream));
+            if (ride && u + lead < n_updates)
+                HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, 1, future_p,
+                                       a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B, a->plan_stream));
+            HP_CHECK_HIP(hipEventRecord(a->plan_join, a->plan_stream));
+            join_pending = true;
+        }
         if (ride && u + lead < n_updates) {
-            gc.rng = rng;
-            gc.next_plan = a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B;
-            gc.future_p = future_p;
+            PlanRec *next = a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B;
+            if (side) {
+                (void)next;
+            } else {
+                gc.rng = rng;
+                gc.next_plan = next;
+                gc.future_p = future_p;
+            }
         }
         if (ahead) {
             gc.xset = u & 1;
             gc.pregathered = u > 0;
-            if (u + 1 < n_updates) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
+            if (u + 1 < n_updates && !side_gather) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
+        gc.ride_in_dw = dw_ride;
         if (fuse_dw) gc.fuse_u = u;
         const bool via_peer = with_adam && a->peer != nullptr;
         if (via_peer) gc.grads_out = peer_grad_buffer(a->peer, u + 1);   // epoch base is even: parity of epoch base + u + 1
@@ -1396,6 +1522,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(64), 0, s, a->d_state, n_updates, adam_cfg(a));
         HP_CHECK_HIP(hipGetLastError());
     }
+    if (join_pending) HP_CHECK_HIP(hipStreamWaitEvent(a->ctx->stream, a->plan_join, 0));
     if (with_adam && a->peer) HP_TRY(peer_enqueue_seq_end(a->peer, n_updates));
     return HP_OK;
 }
@@ -1542,6 +1669,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // measured slower than two launches (48.2 vs 40.8 us/update at batch 256: the in-kernel hand-off costs ~4 us and a
         // tile ~7 us warm, profiles/r02_fused_single_launch.txt), so it is opt-in
         a->fuse_dw_ok = tri("RLARM_FUSE_DW") == 1;
+        if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
         // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
@@ -2318,6 +2446,12 @@ void hp_agent_destroy(hp_agent *a) {
     drop_graph(a);
     (void)hipStreamSynchronize(a->ctx->stream);
     for (void *p : a->owned) (void)hipFree(p);
+    if (a->plan_stream) {
+        (void)hipStreamSynchronize(a->plan_stream);
+        (void)hipEventDestroy(a->plan_fork);
+        (void)hipEventDestroy(a->plan_join);
+        (void)hipStreamDestroy(a->plan_stream);
+    }
     if (a->act_stream) {
         (void)hipStreamSynchronize(a->act_stream);
         for (auto &ps : a->snap) {

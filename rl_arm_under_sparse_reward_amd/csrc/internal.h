@@ -218,7 +218,7 @@ int comm_allreduce_mean_f32(hp_comm *c, float *dev, size_t n);   // normalizer.p
 // launchers implemented in the .hip files -------------------------------------------------
 // rng.hip
 int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,
-                    int32_t n_batches, double future_p, PlanRec *d_plan);
+                    int32_t n_batches, double future_p, PlanRec *d_plan, hipStream_t stream = nullptr);
 int rng_launch_slots(hp_rng *rng, hp_buffer *buf, int64_t n_new, int64_t *d_slots);
 
 // buffer.hip

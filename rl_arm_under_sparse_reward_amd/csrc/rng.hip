@@ -63,8 +63,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_test_uniform(MtState *st, long l
 
 // ------------------------------------------------------------------------------ launchers
 int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,
-                    int32_t n_batches, double future_p, PlanRec *d_plan) {
-    hipLaunchKernelGGL(k_draw_plan, dim3(1), dim3(MT_THREADS), 0, rng->ctx->stream, rng->d_state, d_meta,
+                    int32_t n_batches, double future_p, PlanRec *d_plan, hipStream_t stream) {
+    hipLaunchKernelGGL(k_draw_plan, dim3(1), dim3(MT_THREADS), 0, stream ? stream : rng->ctx->stream, rng->d_state, d_meta,
                        (long long)n_eps_fixed, (int)T, (long long)batch, (int)n_batches, future_p, d_plan);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
