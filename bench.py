@@ -431,57 +431,76 @@ def main():
                    "shader_clock_mhz_after_run": round(mhz.value)},
     }
     if prof:
-        # algorithmic MACs per transition (minimal algorithm): 5 forward passes 699,648;
-        # backward 683,264 = 395,776 (dX chains) + 287,488 (weight gradients)
-        macs = {"forward": 699_648, "backward_dx": 395_776, "weight_grad": 287_488}
-        merged = prof["backward_dx"]["launches_per_step"] == 0   # slab8: forward + backward dX in ONE kernel
-        if merged:
-            macs = {"forward_backward_dx": macs["forward"] + macs["backward_dx"], "weight_grad": macs["weight_grad"]}
-            prof["forward_backward_dx"] = prof.pop("forward")
-            prof.pop("backward_dx")
+        # ---- roofline of the matrix kernels.  Algorithmic MACs per transition (minimal algorithm):
+        # 5 forward passes 699,648 + backward dX chains 395,776 run in the chain kernel(s); weight gradients 287,488.
+        # Durations: n = 200 launches of ONE kernel as a captured hipGraph between ONE HIP event pair on the launch stream
+        # (hp_agent_debug_chain kinds 11 / 12): kernel time + one graph kernel boundary (~1.5 us) per launch, no event
+        # overhead inside.  rocprofv3 kernel durations of the same command (profiles/) are that minus the boundary.
         ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
-        kern = {"forward": "k_fwd_slab", "backward_dx": "k_bwd_slab", "forward_backward_dx": "k_fb_slab8",
-                "weight_grad": "k_gemm_lds_adam (8 dW problems + Adam epilogue)"}
+        slab8 = a.batch <= 1792 and os.environ.get("RLARM_ENGINE", "slab8") == "slab8"
+        kinds = {"chain": (11, 699_648 + 395_776, "k_fb_slab8" if slab8 else "k_fwd_slab + k_bwd_slab"),
+                 "weight_grad": (12, 287_488, "k_gemm_lds_adam")}
+        pmc, pmc_file = {}, None
+        for cand in (f"r02_pmc_traffic_b{a.batch}.json",):
+            path = os.path.join(REPO, "profiles", cand)
+            if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
+                with open(path) as fh:
+                    pmc = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
+                pmc_file = "profiles/" + cand
+        # committed rocprofv3 summary of this same configuration (tools/gpu_round2.sh): cross-check for the live numbers
+        prof_file = os.path.join(REPO, "profiles", f"r02_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+        prof_avg = {}
+        if os.path.exists(prof_file):
+            for line in open(prof_file):
+                parts = line.split()
+                if len(parts) >= 6 and parts[0][0] != "#" and parts[-1].endswith("%"):
+                    try:
+                        prof_avg.setdefault(parts[0].split("::")[-1].split("(")[0], float(parts[-4]))
+                    except ValueError:
+                        pass
         per = {}
-        for k, m in macs.items():
-            n = prof[k]["launches_per_step"]
-            ms = prof[k]["ms_per_step"]
-            if ms > 0 and n > 0:
-                tf = 2.0 * m * a.batch / (ms * 1e-3) / 1e12
-                per[k] = {"kernel": kern[k], "avg_launch_us": round(1e3 * ms / n, 3),
-                          "avg_launch_us_minus_empty_pair": round(1e3 * ms / n - ev_floor_us, 3),
-                          "launches_per_step": round(n, 2),
-                          "flop_per_launch": round(2.0 * m * a.batch / n, 1), "achieved_tflops": round(tf, 3),
-                          "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5)}
-        dom = max(per, key=lambda k: prof[k]["ms_per_step"]) if per else None
-        # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE
-        # runs of this same command at batch 256, gfx950 FETCH x2 correction); null for any other configuration
-        pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if a.batch == 256 and os.environ.get("RLARM_ENGINE", "slab8") == "slab8" and os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
-        for k in per:
-            per[k]["traffic_hbm_bytes_per_launch"] = pmc.get(per[k]["kernel"].split()[0])
-        if dom:
-            out["roofline"] = {
-                "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
-                "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
-                "flop_per_launch": per[dom]["flop_per_launch"], "avg_launch_us": per[dom]["avg_launch_us"],
-                "event_pair_empty_us": round(ev_floor_us, 3),
-                "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup, FP32 "
-                        "v_mfma_f32_4x4x1_16b_f32, 4-row slabs up to batch 448 (8-row beyond).  At batch 256 there are 64 slabs x 2 "
-                        "chains = 128 workgroups (of 256 CUs) and each chain is 16 dependent layers, 8 of them 256x256; such a "
-                        "layer costs a workgroup ~2.6 us against 2.0 us of LDS-DMA weight streaming per CU (139 GB/s), 0.95 us "
-                        "of MFMA issue and 2.0 us for both together in isolation (tools/ubench/stream_bw3.hip, DESIGN.md 3.1): "
-                        "the binding resource is the per-CU weight stream of a latency chain, not the matrix pipes.  "
-                        "avg_launch_us = HIP-event pair around each eager launch on the launch stream; an event pair with "
-                        "nothing in between already reads event_pair_empty_us, so the rocprofv3 kernel durations in profiles/ "
-                        "lie between avg_launch_us and avg_launch_us_minus_empty_pair; achieved/frac use the conservative "
-                        "avg_launch_us",
-                "all_matrix_kernels": per,
-            }
+        for name, (kind, macs, kernel) in kinds.items():
+            us = C.c_double()
+            _l.check(r.agent.lib.hp_agent_debug_chain(r.agent.h, kind, 200, C.byref(us)))
+            ev = prof.get({"chain": "forward", "weight_grad": "weight_grad"}[name], {})
+            ev2 = prof.get("backward_dx", {}) if name == "chain" else {}
+            # live, in situ: one HIP event pair around each eager launch of the training loop on the launch stream, minus what
+            # an event pair with nothing in between reads on this stack
+            live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
+            if name == "chain":
+                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fwd_slab", "k_bwd_slab"))
+            else:   # the ride-along variant runs on all but the last updates of a cycle
+                rp = prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam", 0.0)
+            used = max(live, rp)
+            tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
+            per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "live_event_pair_minus_empty_us": round(live, 3),
+                         "rocprofv3_avg_us_committed": round(rp, 3) if rp else None,
+                         "graph_replay_warm_us": round(us.value, 3), "flop_per_launch": 2.0 * macs * a.batch,
+                         "achieved_tflops": round(tf, 3), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5),
+                         "traffic_hbm_bytes_per_launch": sum(v for k, v in pmc.items() if k in kernel or kernel in k) or None}
+        dom = max(per, key=lambda k: per[k]["avg_launch_us"])
+        out["roofline"] = {
+            "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
+            "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
+            "traffic_source": pmc_file, "flop_per_launch": per[dom]["flop_per_launch"],
+            "avg_launch_us": per[dom]["avg_launch_us"],
+            "duration_method": "avg_launch_us = the LARGER of (a) live_event_pair_minus_empty_us: one HIP event pair around each "
+                               "eager launch of the training loop on the launch stream, minus event_pair_empty_us (what a pair with "
+                               "nothing in between reads), and (b) rocprofv3_avg_us_committed: the kernel's average in the "
+                               "committed rocprofv3 --kernel-trace --stats summary of this configuration "
+                               f"(profiles/{os.path.basename(prof_file)}).  graph_replay_warm_us = 200 back-to-back launches of the "
+                               "kernel alone as a hipGraph between one event pair (warm caches, no spare workgroups): a lower bound",
+            "event_pair_empty_us": round(ev_floor_us, 3),
+            "whole_update_tflops": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12, 3),
+            "whole_update_frac": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
+            "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup (4-row slabs on "
+                    "v_mfma_f32_4x4x1 up to batch 448, 8-row up to 1024, 16-row beyond; 16x16x4 MFMA engine past 1792).  At "
+                    "batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at ~2.4 us against "
+                    "2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight stream, not by the "
+                    "matrix pipes (DESIGN.md 3.1)",
+            "all_matrix_kernels": per,
+        }
         # the HBM-bound half of the path.  In the update loop the gather is fused into k_fb_slab8; the
         # standalone sampler (replay_buffer.sample: k_draw_plan + k_gather_dict in the reference's float64 dict layout)
         # is timed on its own, after the timed region (it advances the sampler stream)
@@ -499,7 +518,7 @@ def main():
             "index_draw_kernel_us": round(dus.value, 3),
             "note": "256 random 0.5 KB rows of a 150 MB buffer per launch: two dependent memory latencies, nowhere near a "
                     "bandwidth bound; averages over 200 back-to-back launches between one HIP event pair"}
-        out["kernel_time_us_per_step"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
+        out["kernel_time_us_per_step_event_bracketed"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -974,7 +974,7 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     float *grads_out = nullptr;
 };
 
-static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam);
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
 static AdamFuse adam_fuse(hp_agent *a);
 
 // layer-per-launch engine: forwards + losses + backwards of one update, inputs in XA/XP/XT/R (18 launches)
@@ -1164,7 +1164,8 @@ static Launch build_dw_group(const hp_agent *a, const float *sXA, const float *s
 }
 
 // slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
-static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam) {
+// only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
+static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
@@ -1228,7 +1229,8 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         A.T = ride ? gc->b->T : 0;
         A.plan_batch = a->B;
     }
-    if (a->slab8) {
+    if (only == 2) {
+    } else if (a->slab8) {
         // one launch: each workgroup carries its rows through forward AND backward (k_fb_slab8)
         ProfScope ps(a, PROF_GEMM_FWD);
         P.n_plan = ride ? 1 : 0;
@@ -1288,7 +1290,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             HP_CHECK_HIP(hipGetLastError());
         }
     }
-    if (!fused) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
+    if (!fused && only != 1) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
         Launch L = build_dw_group(a, sXA, sXP, gc ? gc->grads_out : nullptr);
         if (ride_dw && ((gc->next_plan && gc->rng) || gc->ahead_plan)) {
             ProfScope ps(a, PROF_DW);
@@ -2361,6 +2363,8 @@ int hp_agent_debug_chain(hp_agent *a, int32_t kind, int32_t n, double *us_per_la
             case 6: return enqueue_adam(a);
             case 8: return enqueue_polyak(a);
             case 10: return enqueue_forward_backward(a);   // whole forward+backward of the active engine
+            case 11: return a->slab ? enqueue_forward_backward_slab(a, nullptr, true, 1) : (int)HP_ERR_STATE;  // chain kernel(s) only
+            case 12: return a->slab ? enqueue_forward_backward_slab(a, nullptr, true, 2) : (int)HP_ERR_STATE;  // weight gradients + Adam only
             default: hp_set_error("hp_agent_debug_chain: unknown kind %d", kind); return HP_ERR_INVALID;
         }
     };

@@ -8,11 +8,11 @@
 //   uniform()/random    : ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53
 // Rejection makes the number of words per sample data dependent and the four draws of
 // one HER batch are consecutive in ONE stream, so the draw is inherently sequential in
-// the stream position.  Design: ONE 256-thread workgroup owns the stream.
+// the stream position.  Design: ONE MT_THREADS-thread workgroup owns the stream.
 //   * the 624-word key blocks live in an LDS ring of 4 blocks; block j+1 is produced from
 //     block j by a 3-phase parallel twist (k<227 reads only old words, 227<=k<454 reads the
 //     first phase's outputs, k>=454 the second's);
-//   * a draw consumes the stream in chunks of 256 (bounded) or 512 (double) words:
+//   * a draw consumes the stream in chunks of MT_THREADS (bounded) or 2 x MT_THREADS (double) words:
 //     each thread tempers one candidate, a ballot/popcount prefix sum compacts the
 //     accepted ones, and the position of the last accepted word advances the cursor;
 //   * the final (key, pos) is written back in numpy's own representation, so
@@ -22,11 +22,13 @@
 #include "internal.h"
 
 #define MT_M 397
-#define MT_THREADS 256
+#define MT_THREADS 512     // one candidate word per thread and chunk: fewer, larger chunks = fewer barriers per drawn index
+#define MT_WAVES (MT_THREADS / 64)
+#define MT_IBUF (MT_WAVES + 1)   // LDS ints: wave totals [0 .. MT_WAVES), last-accept position [MT_WAVES]
 
 struct MtWg {
     uint32_t (*blk)[MT_N];  // LDS ring [4][624]
-    int *ibuf;              // LDS ints [8]: wave totals [0..3], last-accept position [4]
+    int *ibuf;              // LDS ints [MT_IBUF]: wave totals, last-accept position
     long long cursor;       // absolute stream index of the next unconsumed word (block 0 = loaded key)
     int nblk;               // blocks generated so far (ring holds blocks nblk-4 .. nblk-1)
 };
@@ -96,7 +98,7 @@ __device__ __forceinline__ void mt_store(const MtWg &g, MtState *st) {
     if (threadIdx.x == 0) st->pos = pos;
 }
 
-// exclusive prefix of a predicate over the 256-thread workgroup; returns this thread's rank among the
+// exclusive prefix of a predicate over the MT_THREADS-thread workgroup; returns this thread's rank among the
 // accepting threads and the workgroup total.  Two barriers.
 __device__ __forceinline__ int mt_prefix(MtWg &g, bool acc, int &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,9 +106,14 @@ __device__ __forceinline__ int mt_prefix(MtWg &g, bool acc, int &total) {
     int within = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) g.ibuf[wave] = __popcll(m);
     __syncthreads();
-    int w0 = g.ibuf[0], w1 = g.ibuf[1], w2 = g.ibuf[2], w3 = g.ibuf[3];
-    int off = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
-    total = w0 + w1 + w2 + w3;
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MT_WAVES; ++w) {
+        const int c = g.ibuf[w];
+        off += (w < wave) ? c : 0;
+        tot += c;
+    }
+    total = tot;
     __syncthreads();
     return off + within;
 }
@@ -134,9 +141,9 @@ __device__ __forceinline__ void mt_draw_bounded(MtWg &g, uint32_t rng, long long
         long long idx = produced + rank;
         if (acc && idx < count) emit(idx, v);
         if (produced + total >= count) {
-            if (acc && idx == count - 1) g.ibuf[4] = threadIdx.x;
+            if (acc && idx == count - 1) g.ibuf[MT_WAVES] = threadIdx.x;
             __syncthreads();
-            g.cursor += g.ibuf[4] + 1;
+            g.cursor += g.ibuf[MT_WAVES] + 1;
             produced = count;
             __syncthreads();
         } else {
@@ -167,7 +174,7 @@ __device__ __forceinline__ void mt_draw_double(MtWg &g, long long count, Emit em
 
 // her.py:24-33 for `n_batches` consecutive minibatches (shared by k_draw_plan and the plan workgroup that rides
 // along with the backward slab kernel): plan[b*batch + i] = (e, t, future_t, her).  Must be executed by exactly
-// MT_THREADS threads of one workgroup (threadIdx.x < MT_THREADS); `ring` = uint32[4][624], `ibuf` = int[8] in LDS.
+// MT_THREADS threads of one workgroup (threadIdx.x < MT_THREADS); `ring` = uint32[4][624], `ibuf` = int[MT_IBUF] in LDS.
 __device__ __forceinline__ void mt_her_plan(MtState *st, long long n_eps, int T, long long batch, int n_batches,
                                             double future_p, PlanRec *plan, uint32_t (*ring)[MT_N], int *ibuf) {
     MtWg g;

@@ -9,7 +9,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_plan(MtState *st, const Buf
                                                          int T, long long batch, int n_batches, double future_p,
                                                          PlanRec *plan) {
     __shared__ uint32_t ring[4][MT_N];
-    __shared__ int ibuf[8];
+    __shared__ int ibuf[MT_IBUF];
     const long long n_eps = meta ? meta->current_size : n_eps_fixed;
     mt_her_plan(st, n_eps, T, batch, n_batches, future_p, plan, ring, ibuf);
 }
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_plan(MtState *st, const Buf
 __global__ __launch_bounds__(MT_THREADS) void k_draw_slots(MtState *st, BufMeta *meta, long long size, int T,
                                                           long long inc, long long *slots) {
     __shared__ uint32_t ring[4][MT_N];
-    __shared__ int ibuf[8];
+    __shared__ int ibuf[MT_IBUF];
     const long long cur = meta->current_size;
     if (cur + inc <= size) {
         for (long long i = threadIdx.x; i < inc; i += MT_THREADS) slots[i] = cur + i;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_slots(MtState *st, BufMeta 
 __global__ __launch_bounds__(MT_THREADS) void k_test_randint(MtState *st, long long low, uint32_t rng,
                                                             long long count, long long *out) {
     __shared__ uint32_t ring[4][MT_N];
-    __shared__ int ibuf[8];
+    __shared__ int ibuf[MT_IBUF];
     MtWg g;
     mt_load(g, st, ring, ibuf);
     mt_draw_bounded(g, rng, count, [&](long long i, uint32_t v) { out[i] = low + (long long)v; });
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_test_randint(MtState *st, long l
 
 __global__ __launch_bounds__(MT_THREADS) void k_test_uniform(MtState *st, long long count, double *out) {
     __shared__ uint32_t ring[4][MT_N];
-    __shared__ int ibuf[8];
+    __shared__ int ibuf[MT_IBUF];
     MtWg g;
     mt_load(g, st, ring, ibuf);
     mt_draw_double(g, count, [&](long long i, double u) { out[i] = u; });

@@ -9,8 +9,9 @@ cur = db.cursor()
 rows = cur.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
                    "from kernels group by name order by 6 desc").fetchall()
 tot = sum(r[5] for r in rows)
-print("# rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 2000 --warmup 400 "
-      "--no-cpu-baseline --no-profile   (tools/gpu_round.sh; kernel durations from trace_results.db, tools/trace_summary.py)")
+cmd = sys.argv[2] if len(sys.argv) > 2 else "python bench.py --steps 2000 --warmup 400 --no-cpu-baseline --no-profile"
+print(f"# rocprofv3 --kernel-trace --stats -d <dir> -o trace -- {cmd}   (kernel durations from trace_results.db, "
+      "tools/trace_summary.py)")
 print(f"{'kernel':44s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'share':>6s}")
 for r in rows:
     print(f"{r[0][:44]:44s} {r[1]:7d} {r[2]/1e3:8.2f} {r[3]/1e3:8.2f} {r[4]/1e3:8.2f} {100*r[5]/tot:5.1f}%")
