@@ -301,6 +301,9 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
     const int extra = (int)blockIdx.x - tiles;
     if (extra < R.n_plan) {
         if (threadIdx.x >= MT_THREADS) return;   // ended waves take no part in the barriers of the draw
+        // the sequential draw is the longest single job of this launch at batch 1024 (as long as the tiles): let its waves
+        // issue ahead of the tile workgroup that shares the CU
+        __builtin_amdgcn_s_setprio(3);
         mt_her_plan(R.rng, R.meta->current_size, R.T, R.plan_batch, 1, R.future_p, R.next_plan,
                     reinterpret_cast<uint32_t(*)[MT_N]>(lds), reinterpret_cast<int *>(&bsum[0][0]));
     } else {
@@ -1302,7 +1305,10 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
                 R.T = gc->b->T; R.plan_batch = a->B;
             }
             if (gc->ahead_plan) {
-                R.n_ahead = 8;
+                // one pass of 32 rows (8 waves x 4 rows in flight) per gather workgroup: each pass is two dependent HBM
+                // latencies, so fewer, longer workgroups made this launch 3 us longer than its tiles (61.0 vs 58.6 us/update at
+                // batch 1024 with 8 vs 32 of them)
+                R.n_ahead = (a->B + 31) / 32 < 64 ? (a->B + 31) / 32 : 64;
                 R.ahead = P.f.gs;
                 R.ahead.plan = gc->ahead_plan; R.ahead.plan_any = gc->ahead_plan;
                 R.ahead.R = xs ? a->R : a->R2;
