@@ -308,6 +308,9 @@ int hp_peer_connect(hp_peer *peer, const uint8_t *handles_world_x_64);
 /* normalizer._mpi_average (normalizer.py:60-64) and other small vectors (<= 1024 floats): in place, SUM or SUM / world
  * (mean != 0), enqueued on the context's stream; collective */
 int hp_peer_allreduce_f32(hp_peer *peer, void *dev, int64_t n, int32_t mean);
+/* collective self-check of the gradient channel (flags, both buffer parities, system-scope loads of every peer's vector) on an
+ * exactly representable pattern: *mismatches = number of wrong elements on this rank (top bit: a wait timed out) */
+int hp_peer_selfcheck(hp_peer *peer, uint32_t *mismatches);
 int hp_peer_status(hp_peer *peer, uint32_t *error);
 void hp_peer_destroy(hp_peer *peer);
 /* Attach (or detach with NULL): hp_agent_sample_and_update / hp_agent_train_cycle then exchange the gradients through

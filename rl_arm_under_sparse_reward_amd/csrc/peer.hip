@@ -57,6 +57,33 @@ __global__ __launch_bounds__(256) void k_peer_small(const PeerDev D, float *vec,
     if (threadIdx.x == 0) D.epoch[1] = epoch;
 }
 
+// Self-check of the GRADIENT channel (the path k_peer_adam uses: flags, buffer parity, system-scope 16-byte loads of the
+// peers' vectors): every rank fills its own buffer with an exactly representable pattern, the ranks reduce it like
+// k_peer_adam does and count the elements that differ from the known sum.  Run at attach time for both buffer parities.
+__global__ void k_peer_check_fill(const PeerDev D, int n, int par) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) D.grad[D.rank][par][i] = (float)(D.rank + 1) * (float)((i % 1021) + 1);
+}
+__global__ __launch_bounds__(256) void k_peer_check_reduce(const PeerDev D, int n4, int u, unsigned int *bad) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    const int par = (int)(epoch & 1ull);
+    if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
+    peer_wait(D, D.flags_g[D.rank], epoch);
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < D.world; ++q) {
+        const float4 v = peer_load4(D.grad[q][par], (size_t)n4 * 16, (unsigned)t * 16u, q == D.rank);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float w = (float)(D.world * (D.world + 1) / 2);
+    const float got[4] = {acc.x, acc.y, acc.z, acc.w};
+    int wrong = 0;
+    for (int j = 0; j < 4; ++j) wrong += got[j] != w * (float)(((4 * t + j) % 1021) + 1);
+    if (wrong) atomicAdd(bad, (unsigned)wrong);
+}
+
 // ---- internal entry points used by agent.hip -----------------------------------------------------------------------
 float *peer_grad_buffer(hp_peer *p, int parity) { return p->dev.grad[p->rank][parity & 1]; }
 
@@ -186,6 +213,28 @@ int hp_peer_allreduce_f32(hp_peer *p, void *dev, int64_t n, int32_t mean) {
     HP_REQUIRE(p->connected, HP_ERR_STATE, "hp_peer_allreduce_f32: hp_peer_connect first");
     if (n == 0) return HP_OK;
     return peer_allreduce_small(p, static_cast<float *>(dev), (size_t)n, mean != 0);
+}
+
+int hp_peer_selfcheck(hp_peer *p, uint32_t *mismatches) {
+    HP_REQUIRE(p && mismatches, HP_ERR_INVALID, "hp_peer_selfcheck: null argument");
+    CtxGuard guard(p->ctx);
+    HP_REQUIRE(p->connected, HP_ERR_STATE, "hp_peer_selfcheck: hp_peer_connect first");
+    hipStream_t s = p->ctx->stream;
+    unsigned int *bad = p->dev.error + 1;   // scratch word behind the sticky error word
+    HP_CHECK_HIP(hipMemsetAsync(bad, 0, 4, s));
+    const int n = (int)p->n_grad, n4 = n / 4;
+    // two consecutive epochs = both buffer parities, exactly as two updates of a sequence would use them
+    for (int u = 0; u < 2; ++u) {
+        hipLaunchKernelGGL(k_peer_check_fill, dim3((n + 255) / 256), dim3(256), 0, s, p->dev, n, (u + 1) & 1);
+        hipLaunchKernelGGL(k_peer_check_reduce, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
+    }
+    HP_CHECK_HIP(hipGetLastError());
+    HP_TRY(peer_enqueue_seq_end(p, 2));
+    uint32_t h[2] = {0, 0};
+    HP_CHECK_HIP(hipMemcpyAsync(h, p->dev.error, 8, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    *mismatches = h[1] + (h[0] ? 0x80000000u : 0u);   // top bit: a wait timed out
+    return HP_OK;
 }
 
 int hp_peer_status(hp_peer *p, uint32_t *error) {

@@ -97,6 +97,9 @@ class Communicator:
             return None
         raw = (C.c_uint8 * (64 * self.world_size))(*[int(b) for t in every for b in t.cpu().tolist()])
         ok = lib.hp_peer_connect(h, raw) == 0
+        if not agree(ok):      # before any collective kernel: a rank that could not map its peers must not leave the others waiting
+            lib.hp_peer_destroy(h)
+            return None
         if ok:   # self-check: rank r contributes (r + 1) * (i + 1); the rank-ordered sum is exact in float32
             n, w = 257, self.world_size
             probe = torch.arange(1, n + 1, dtype=torch.float32, device=f"cuda:{ctx.device_id}") * float(self.rank + 1)
@@ -110,7 +113,9 @@ class Communicator:
                 if mean:
                     expect = expect / float(w)
                 ok = ok and bool(torch.equal(v.cpu(), expect))
-            err = C.c_uint32()
+            bad, err = C.c_uint32(), C.c_uint32()
+            # ... and the gradient channel itself: both buffer parities, 16-byte system-scope loads of every peer's vector
+            ok = ok and lib.hp_peer_selfcheck(h, C.byref(bad)) == 0 and bad.value == 0
             ok = ok and lib.hp_peer_status(h, C.byref(err)) == 0 and err.value == 0
         if not agree(ok):
             lib.hp_peer_destroy(h)
