@@ -171,12 +171,13 @@ struct hp_buffer {
 };
 
 // ------------------------------------------------------------------ normalizer
-struct NormDev {  // device-resident state; size <= 64 columns
-    float local_sum[64], local_sumsq[64], local_count[4];
-    float total_sum[64], total_sumsq[64], total_count[4];
-    float sync[132];  // sum | sumsq | count snapshot exchanged between ranks
-    float mean[64];
-    double std[64];  // float64-valued (std_f32: float32 value widened)
+#define NORM_MAX 256   // columns a normalizer can hold (bmirobot: 27 observations, 3 goals); hp_norm_create rejects more
+struct NormDev {  // device-resident state; size <= NORM_MAX columns
+    float local_sum[NORM_MAX], local_sumsq[NORM_MAX], local_count[4];
+    float total_sum[NORM_MAX], total_sumsq[NORM_MAX], total_count[4];
+    float sync[2 * NORM_MAX + 4];  // sum | sumsq | count snapshot exchanged between ranks
+    float mean[NORM_MAX];
+    double std[NORM_MAX];  // float64-valued (std_f32: float32 value widened)
 };
 
 struct hp_norm {

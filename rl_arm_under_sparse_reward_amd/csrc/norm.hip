@@ -76,11 +76,11 @@ __global__ __launch_bounds__(NORM_THREADS) void k_norm_update_from_plan(
     PlanRec *sp = reinterpret_cast<PlanRec *>(norm_lds);                                   // [chunk_rows]
     double *sv = reinterpret_cast<double *>(norm_lds + (size_t)chunk_rows * sizeof(PlanRec));   // [chunk_rows][W]
     const int c = threadIdx.x;
-    const bool goal = c >= 64;
-    const int j = goal ? c - 64 : c;
+    const bool goal = c >= NORM_MAX;            // threads [0, NORM_MAX): observation columns, [NORM_MAX, 2 NORM_MAX): goal columns
+    const int j = goal ? c - NORM_MAX : c;
     NormDev *nz = goal ? gnz : onz;
     const int size = goal ? goal_dim : obs_dim;
-    const bool act = c < 128 && j < size;
+    const bool act = c < 2 * NORM_MAX && j < size;
     const int W = obs_dim + goal_dim;
     double s = 0.0, ss = 0.0;
     for (long long r0 = 0; r0 < rows; r0 += chunk_rows) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NORM_THREADS) void k_norm_update_from_plan(
         }
         __syncthreads();   // the chunk is consumed before the next one overwrites it
     }
-    if (c >= 128) return;   // whole wavefronts: the barriers below count the two that remain
+    if (c >= 2 * NORM_MAX) return;   // whole wavefronts: the barriers below count the ones that remain
     // normalizer.update: float32 accumulators += float64 column sums; count += rows
     float ls = 0.f, lss = 0.f;
     if (act) {
@@ -184,11 +184,11 @@ __global__ void k_norm_normalize(const NormDev *nz, const double *__restrict__ v
 
 __global__ void k_norm_init(NormDev *nz) {
     const int c = threadIdx.x;
-    if (c < 64) {
+    if (c < NORM_MAX) {
         nz->local_sum[c] = nz->local_sumsq[c] = nz->total_sum[c] = nz->total_sumsq[c] = nz->mean[c] = 0.f;
         nz->std[c] = 1.0;  // normalizer.py:20
     }
-    if (c < 132) nz->sync[c] = 0.f;
+    for (int k = c; k < 2 * NORM_MAX + 4; k += blockDim.x) nz->sync[k] = 0.f;
     if (c < 4) {
         nz->local_count[c] = 0.f;
         nz->total_count[c] = (c == 0) ? 1.f : 0.f;  // normalizer.py:17: total_count starts at ONE
@@ -221,13 +221,13 @@ int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const Pla
 }
 
 int norm_launch_begin(hp_norm *nz) {
-    hipLaunchKernelGGL(k_norm_begin, dim3(1), dim3(64), 0, nz->ctx->stream, nz->d, nz->size);
+    hipLaunchKernelGGL(k_norm_begin, dim3(1), dim3(NORM_MAX), 0, nz->ctx->stream, nz->d, nz->size);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
 
 int norm_launch_end(hp_norm *nz) {
-    hipLaunchKernelGGL(k_norm_end, dim3(1), dim3(64), 0, nz->ctx->stream, nz->d, nz->size, nz->eps * nz->eps,
+    hipLaunchKernelGGL(k_norm_end, dim3(1), dim3(NORM_MAX), 0, nz->ctx->stream, nz->d, nz->size, nz->eps * nz->eps,
                        nz->std_f32);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -238,7 +238,7 @@ extern "C" {
 
 int hp_norm_create(hp_ctx *ctx, int32_t size, double eps, double default_clip_range, int32_t std_f32, hp_norm **out) {
     HP_REQUIRE(ctx && out, HP_ERR_INVALID, "hp_norm_create: null argument");
-    HP_REQUIRE(size > 0 && size <= 64, HP_ERR_INVALID, "hp_norm_create: size=%d must be in [1, 64]", size);
+    HP_REQUIRE(size > 0 && size <= NORM_MAX, HP_ERR_INVALID, "hp_norm_create: size=%d must be in [1, %d]", size, NORM_MAX);
     hp_norm *nz = new hp_norm();
     nz->ctx = ctx;
     nz->size = size;
@@ -251,7 +251,7 @@ int hp_norm_create(hp_ctx *ctx, int32_t size, double eps, double default_clip_ra
         hp_set_error("hp_norm_create: hipMalloc failed: %s", hipGetErrorString(e));
         return HP_ERR_HIP;
     }
-    hipLaunchKernelGGL(k_norm_init, dim3(1), dim3(192), 0, ctx->stream, nz->d);
+    hipLaunchKernelGGL(k_norm_init, dim3(1), dim3(NORM_MAX), 0, ctx->stream, nz->d);
     *out = nz;
     return HP_OK;
 }
@@ -269,7 +269,7 @@ int hp_norm_update(hp_norm *nz, const double *v_host, int64_t rows) {
         HP_CHECK_HIP(hipMemcpyAsync(nz->scratch.p, nz->pin.p, bytes, hipMemcpyHostToDevice, s));
         HP_TRY(nz->pin.mark(s));
     }
-    hipLaunchKernelGGL(k_norm_update_rows, dim3(1), dim3(64), 0, s, nz->d, nz->scratch.as<double>(), (long long)rows,
+    hipLaunchKernelGGL(k_norm_update_rows, dim3(1), dim3(NORM_MAX), 0, s, nz->d, nz->scratch.as<double>(), (long long)rows,
                        nz->size);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -325,15 +325,16 @@ int hp_norm_set_stats(hp_norm *nz, const float *mean, const double *std) {
     HP_SERIALISE(nz);
     hipStream_t s = nz->ctx->stream;
     const int n = nz->size;
-    HP_TRY(nz->scratch2.ensure(64 * 4 + 64 * 8));
-    HP_TRY(nz->pin.ensure(64 * 4 + 64 * 8));
+    constexpr size_t MB = NORM_MAX * 4, SB = NORM_MAX * 8;
+    HP_TRY(nz->scratch2.ensure(MB + SB));
+    HP_TRY(nz->pin.ensure(MB + SB));
     char *h = static_cast<char *>(nz->pin.p);
     memcpy(h, mean, n * 4);
-    memcpy(h + 256, std, n * 8);
-    HP_CHECK_HIP(hipMemcpyAsync(nz->scratch2.p, h, 256 + 512, hipMemcpyHostToDevice, s));
+    memcpy(h + MB, std, n * 8);
+    HP_CHECK_HIP(hipMemcpyAsync(nz->scratch2.p, h, MB + SB, hipMemcpyHostToDevice, s));
     HP_TRY(nz->pin.mark(s));
-    hipLaunchKernelGGL(k_norm_set, dim3(1), dim3(64), 0, s, nz->d, nz->scratch2.as<float>(),
-                       reinterpret_cast<const double *>(nz->scratch2.as<char>() + 256), n);
+    hipLaunchKernelGGL(k_norm_set, dim3(1), dim3(NORM_MAX), 0, s, nz->d, nz->scratch2.as<float>(),
+                       reinterpret_cast<const double *>(nz->scratch2.as<char>() + MB), n);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }

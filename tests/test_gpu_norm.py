@@ -119,13 +119,13 @@ def test_set_stats_roundtrip():
     assert np.array_equal(nz.normalize(np.array([[2.0, 2.0, 43.0]])), [[2.0, 0.0, 5.0]])
 
 
-@pytest.mark.parametrize("case", range(8))
+@pytest.mark.parametrize("case", range(12))
 def test_normalizer_matches_oracle_on_random_sequences(case):
-    """Random widths (1..64), random update / recompute_stats sequences with batches of 1..300 rows at very different
+    """Random widths (1..64; cases 8-11: 65..256, several wavefronts per normalizer), random update / recompute_stats sequences with batches of 1..300 rows at very different
     scales, both `std` dtypes: accumulators, mean and std bit for bit, and normalize() -- with and without clipping --
     on fresh inputs after every recompute."""
     rs = np.random.RandomState(4000 + case)
-    size = int(rs.randint(1, 65))
+    size = int(rs.randint(1, 65)) if case < 8 else int(rs.randint(65, 257))
     f32 = bool(case & 1)
     clip = [np.inf, 5.0, 0.5][case % 3]
     dev = normalizer(size, default_clip_range=clip, std_dtype=np.float32 if f32 else np.float64)
@@ -141,6 +141,12 @@ def test_normalizer_matches_oracle_on_random_sequences(case):
             assert np.array_equal(bits(dev.normalize(x)), bits(ref.normalize(x))), step
             assert np.array_equal(bits(dev.normalize(x, 1.5)), bits(ref.normalize(x, 1.5))), step
             assert np.array_equal(bits(dev.normalize(x[0])), bits(ref.normalize(x[0]))), step
+
+
+def test_widths_beyond_the_limit_are_refused_loudly():
+    normalizer(256)
+    with pytest.raises(ValueError, match="must be in"):
+        normalizer(257)
 
 
 def test_sync_and_mpi_average_helpers_single_rank():

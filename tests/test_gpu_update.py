@@ -580,7 +580,7 @@ def test_feeder_thread_stores_while_cycles_run():
     assert np.all(np.isfinite(agent.last_losses(6))) and np.all(np.isfinite(agent._get_flat(NET_CRITIC)))
 
 
-@pytest.mark.parametrize("obs_dim,goal_dim,act_dim,T", [(10, 3, 4, 50), (60, 3, 7, 20), (25, 2, 2, 100)])
+@pytest.mark.parametrize("obs_dim,goal_dim,act_dim,T", [(10, 3, 4, 50), (60, 3, 7, 20), (25, 2, 2, 100), (130, 5, 6, 30)])
 def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
     """Other GoalEnv shapes than bmirobot's 27/3/4 ('so other GoalEnvs can plug in'): small ones run on the
     slab engine, anything wider than 48 input columns or 4 actions on the layer-per-launch engine; same oracle, same bar."""
