@@ -19,10 +19,10 @@ for cfg in "256 4 2000 400" "1024 4 800 80" "512 8 800 80" "4096 4 400 80"; do s
   rocprofv3 --kernel-trace --stats --output-format csv -d $d2 -o trace -- $CMD > $d2/log.txt 2>&1
   cp $d2/trace_kernel_stats.csv $O/rocprofv3_kernel_stats_b${B}_k$K.csv 2>/dev/null || ls $d2
 done
-for cfg in "256 4" "1024 4"; do set -- $cfg; B=$1; K=$2
+for cfg in "256 4" "1024 4" "4096 4"; do set -- $cfg; B=$1; K=$2
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$O/pmc_${c}_b$B; mkdir -p $d
-    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python bench.py --batch $B --replay-k $K --steps 200 --warmup 40 --no-cpu-baseline --no-profile > $d/log.txt 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python bench.py --batch $B --replay-k $K --steps 120 --warmup 40 --no-cpu-baseline --no-profile > $d/log.txt 2>&1
   done
   python tools/pmc_summary.py $O/pmc_FETCH_SIZE_b$B/pmc_results.db $O/pmc_WRITE_SIZE_b$B/pmc_results.db --json $O/pmc_traffic_b$B.json --note "batch $B" > $O/pmc_fetch_write_b$B.txt 2>&1
 done
