@@ -270,6 +270,7 @@ static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, 
 #undef S8_ROWS
 #undef S8_RING
 #undef S8_RPW
+#include "slab32.h"
 
 // Weight-gradient tiles (+ optimizer) with the sampler's look-ahead riding along.  When the chain kernel occupies every
 // CU (batch 1024: 256 chain workgroups) it has no room for its spare workgroups -- a workgroup appended to a full launch
@@ -343,7 +344,8 @@ struct hp_agent {
     float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
     unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
-    bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4)
+    bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: 16-row slabs on 16x16x4, or slab32)
+    bool slab32 = false;   // 32-row slabs on the 32x32x2 MFMA, forward + backward in one kernel (slab32.h: large batches)
     int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     // A/B switches, read once in hp_agent_create: RLARM_GEMM_PIPE, RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD,
@@ -1132,7 +1134,7 @@ static ArenaMap arena_map(const hp_agent *a) {
     am.la = a->la;
     am.lc = a->lc;
     am.H = a->H;
-    am.mode = a->slab8 ? 1 : 0;
+    am.mode = a->slab8 ? 1 : (a->slab32 ? 2 : 0);
     return am;
 }
 
@@ -1172,7 +1174,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
     hipStream_t s = a->ctx->stream;
-    const int nslab = Mp / (a->slab8 ? a->s8_rows : SL_ROWS);
+    const int nslab = Mp / (a->slab8 ? a->s8_rows : (a->slab32 ? S32_ROWS : SL_ROWS));
     FbSlabArgs P;
     const int xs = gc ? gc->xset : 0;
     float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
@@ -1281,6 +1283,13 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
         else
             hipLaunchKernelGGL(s8r16::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
+    } else if (a->slab32) {
+        // 32-row slabs, forward + backward of a chain in one workgroup; inputs come gathered (enqueue_updates)
+        ProfScope ps(a, PROF_GEMM_FWD);
+        P.n_plan = ride ? 1 : 0;
+        P.n_ahead = P.n_pref = P.xcd_split = 0;
+        hipLaunchKernelGGL(s32::k_fb_slab32, dim3(2 * nslab + P.n_plan), dim3(S32_THREADS), 0, s, P);
+        HP_CHECK_HIP(hipGetLastError());
     } else {
         {
             ProfScope ps(a, PROF_GEMM_FWD);
@@ -1346,7 +1355,8 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.keep_grads = 1;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
-    F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : SL_ROWS); F.B = a->B; F.act_dim = a->cfg.act_dim;
+    F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : (a->slab32 ? S32_ROWS : SL_ROWS)); F.B = a->B;
+    F.act_dim = a->cfg.act_dim;
     F.action_l2 = (float)a->cfg.action_l2; F.loss_log = a->loss_log;
     return F;
 }
@@ -1428,11 +1438,18 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
     // slab8 engine, full launch: both jobs ride in the weight-gradient launch (k_gemm_lds_adam_ride); RLARM_PLAN_SIDE=2
     // keeps the second-stream variant for A/B (its cross-queue graph edges cost ~4 us each: 65.5 vs 71.4 us at batch 1024)
-    const bool want_offload = ride && a->slab8 && !fuse_dw && a->plan_side != 0 && (a->plan_side >= 1 || full) &&
-                              (getenv("RLARM_AHEAD") ? a->gather_ahead : true);
-    const bool side_gather = want_offload && a->plan_side == 2 && !a->prof;
+    // slab32 engine: its chain kernel never gathers and its launches fill the CUs from batch 4096, so both jobs ride in the
+    // weight-gradient launch by default (measured at batch 4096: beside the chain kernel on a second stream k_draw_plan
+    // took 83 us instead of 3.4 and the chain kernel 97 us); RLARM_PLAN_SIDE=2 keeps the second stream, 0 runs the gather in
+    // front of every launch.  Profiling brackets every launch with events on the main stream: serial as well.
+    const bool s32_ride = ride && a->slab32 && !a->prof && a->plan_side != 0 && a->plan_side != 2;
+    const bool s32_side = ride && a->slab32 && !a->prof && a->plan_side == 2;
+    const bool s32_serial = a->slab32 && !s32_side && !s32_ride;
+    const bool want_offload = s32_ride || (ride && a->slab8 && !fuse_dw && a->plan_side != 0 && (a->plan_side >= 1 || full) &&
+                                           (getenv("RLARM_AHEAD") ? a->gather_ahead : true));
+    const bool side_gather = (want_offload && a->slab8 && a->plan_side == 2 && !a->prof) || s32_side;
     const bool dw_ride = want_offload && !side_gather;
-    const bool ahead = ride && a->slab8 && (a->gather_ahead || side_gather || dw_ride);
+    const bool ahead = ride && ((a->slab8 && (a->gather_ahead || side_gather || dw_ride)) || s32_side || s32_ride);
     const int lead = ahead ? 2 : 1;
     if (fuse_dw) {
         hipLaunchKernelGGL(k_seq_begin, dim3((n_updates + 63) / 64), dim3(64), 0, a->ctx->stream, a->d_state, a->fsync,
@@ -1450,7 +1467,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // the first chain ends and then runs its sequential MT19937 draw alone: measured 51.5 vs 37.8 us for k_fb_slab8 at
     // batch 1024 and 96 vs 51 us for k_bwd_slab at batch 4096 (profiles/r02_large_batch_traces.txt).
     const int spare_cus = a->ctx->cu_count - (a->slab8 ? chains + (ahead && !side_gather ? S8_AHEAD_WGS : 0)
-                                                       : 3 * (a->Mp / SL_ROWS));
+                                              : (a->slab32 ? 2 * (a->Mp / S32_ROWS) : 3 * (a->Mp / SL_ROWS)));
     const bool side = side_gather || (ride && !dw_ride && !a->prof && (a->plan_side >= 0 ? a->plan_side >= 1 : spare_cus < 1));
     if (side && !a->plan_stream) {
         HP_CHECK_HIP(hipStreamCreateWithFlags(&a->plan_stream, hipStreamNonBlocking));
@@ -1489,6 +1506,8 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
                 gc.future_p = future_p;
             }
         }
+        if (a->slab32 && (s32_serial || u == 0))   // nobody gathered this update's inputs beside the previous one
+            HP_TRY(enqueue_gather(a, b, on, gn, gc.plan, sq, ahead ? (u & 1) : 0));
         if (ahead) {
             gc.xset = u & 1;
             gc.pregathered = u > 0;
@@ -1649,9 +1668,15 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // action, padded to 16) and at most 4 action components; any other shape takes the layer-per-launch engine
         const bool slab_shape = a->H == 256 && a->ldx <= 48 && cfg->act_dim <= 4;
         a->slab = !(e && strcmp(e, "layers") == 0) && slab_shape;
-        // thin slabs (4x4x1 MFMA) up to batch 1792, 16-row slabs (16x16x4 MFMA, a quarter of the weight traffic per row)
-        // beyond: measured 110.9 vs 117.2 us/update at batch 1536, 167.0 vs 135.5 at 2048, 318.8 vs 250.1 at 4096
-        a->slab8 = a->slab && (e ? strcmp(e, "slab16") != 0 : a->B <= 1792);
+        // Thin slabs (4x4x1 MFMA, slab8.h) while their chains fit the CUs in one round (16-row slabs: batch <= 2048), 32-row
+        // slabs on the 32x32x2 MFMA (slab32.h) beyond; the 16-row two-kernel engine (16x16x4 MFMA, slab.h) stays selectable
+        // for A/B.  Measured us/update, slab8 / slab16 / slab32 (profiles/r02_large_batch_engines.txt):
+        //   1024: 59.5 / 88.0 / 106.8    1536: 87.7 / 119.5 / 113.2    2048: 97.4 / 127.5 / 119.8
+        //   3072: 163.3 / 173.6 / 132.9  4096: 180.1 / 202.7 / 146.7
+        const int cus_e = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
+        const bool thin_fits = 2 * (a->Mp / 16) <= cus_e;
+        a->slab8 = a->slab && (e ? (strcmp(e, "slab16") != 0 && strcmp(e, "slab32") != 0) : thin_fits);
+        a->slab32 = a->slab && !a->slab8 && (e ? strcmp(e, "slab32") == 0 : true);
         // Thin slabs buy latency at small batches (more CUs busy, less matrix work per streamed weight block) and cost
         // L2 weight traffic per row: measured (4 vs 8 rows, us/update) 48.4 vs 52.4 at batch 256, 50.0 vs 54.4 at 384,
         // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the

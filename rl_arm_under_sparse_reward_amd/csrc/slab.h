@@ -56,7 +56,7 @@ __host__ __device__ __forceinline__ int frag_dx_index(int n, int k, int N) {
 struct ArenaMap {  // enough of the arena geometry to find (layer, n, k) of a flat index on the device
     NetLayout la, lc;
     int H;
-    int mode;      // 0: 16-row slab fragment order (slab.h), 1: thin-slab order (slab8.h)
+    int mode;      // 0: 16-row slab fragment order (slab.h), 1: thin-slab order (slab8.h), 2: 32-row order (slab32.h)
 };
 
 // canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases
@@ -80,9 +80,11 @@ __host__ __device__ __forceinline__ void frag_offsets(const ArenaMap &am, int id
 }
 
 __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
+__host__ __device__ __forceinline__ void frag32_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
 
 __host__ __device__ __forceinline__ void frag_offsets_any(const ArenaMap &am, int idx, int &off_f, int &off_d) {
     if (am.mode == 1) frag8_offsets(am, idx, off_f, off_d);
+    else if (am.mode == 2) frag32_offsets(am, idx, off_f, off_d);
     else frag_offsets(am, idx, off_f, off_d);
 }
 

@@ -44,7 +44,7 @@ def update_agrees(p, ref, init, rel_l2, median_abs):
 
 # the engines kept in the tree for A/B runs compute the same update with other tilings / launch structures: the
 # reference-generated golden holds for each of them
-ENGINES = ["", "RLARM_SLAB_ROWS=8", "RLARM_SLAB_ROWS=16", "RLARM_ENGINE=slab16", "RLARM_ENGINE=layers"]
+ENGINES = ["", "RLARM_SLAB_ROWS=8", "RLARM_SLAB_ROWS=16", "RLARM_ENGINE=slab16", "RLARM_ENGINE=slab32", "RLARM_ENGINE=layers"]
 
 
 def _select_engine(switch, monkeypatch):
@@ -127,8 +127,10 @@ def test_three_sampled_updates_from_seed_golden(engine, monkeypatch):
 
 @pytest.mark.parametrize("batch,k", [(256, 4), (100, 8), (512, 8), (1024, 4), (7, 4), (449, 4), (1281, 4),
                                      (2048, 4)])   # 4-, 8-, 16-row slabs, ragged sizes, the slab16 engine (> 1792)
-def test_updates_track_oracle_over_a_cycle(batch, k):
+def test_updates_track_oracle_over_a_cycle(batch, k, engine="", monkeypatch=None):
     """40 updates + polyak against the torch-CPU oracle fed the same (bit-identical) minibatches."""
+    if engine:
+        _select_engine(engine, monkeypatch)
     torch.set_num_threads(4)
     n_eps = 64
     eps = make_episodes(n_eps, seed=3, mode="walk")
@@ -167,6 +169,13 @@ def test_updates_track_oracle_over_a_cycle(batch, k):
     agent._soft_update_target_network(); learner.soft_update()
     update_agrees(agent._get_flat(NET_ACTOR), learner.flat("actor"), oupd.flatten(list(a0.values())), 0.15, 3e-5)
     update_agrees(agent._get_flat(NET_CRITIC), learner.flat("critic"), oupd.flatten(list(c0.values())), 0.15, 3e-5)
+
+
+@pytest.mark.parametrize("batch", [64, 449, 1024, 4096])
+def test_slab32_engine_tracks_oracle_over_a_cycle(batch, monkeypatch):
+    """The 32-row engine on v_mfma_f32_32x32x2 (slab32.h; the default from batch 2048) on small, ragged and large batches:
+    inputs gathered by k_gather_fused beside the previous update, index plans on the second stream or in a spare workgroup."""
+    test_updates_track_oracle_over_a_cycle(batch, 4, "RLARM_ENGINE=slab32", monkeypatch)
 
 
 @pytest.mark.parametrize("n_batches", [5, 1, 2])     # 1 and 2: shorter than the two-update lead of the index plans
@@ -485,7 +494,7 @@ def test_fused_single_launch_updates_are_used_and_healthy(batch, monkeypatch):
     assert np.array_equal(bits(agent.actor_network(x).numpy()), bits(twin.actor_network(x).numpy()))
 
 
-@pytest.mark.parametrize("batch", [256, 1024])
+@pytest.mark.parametrize("batch", [256, 1024, 2048])
 def test_repeated_runs_are_bit_identical(batch, monkeypatch):
     """Race check for the concurrent pieces of a cycle (index plans drawn two updates ahead, next minibatch gathered by
     spare workgroups, input sets ping-ponging): 60 cycles = 2400 updates twice, then once with gather-ahead off --
