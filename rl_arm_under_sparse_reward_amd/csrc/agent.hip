@@ -170,11 +170,12 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
     *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    if (F.am.mode == 1) {
-        // slab8 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's row
-        // length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
+    if (F.am.mode == 1 || F.am.mode == 2) {
+        // slab8 / slab32 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's
+        // row length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
         int of, od;
-        frag8_offsets(F.am, idx0, of, od);
+        if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
+        else frag32_offsets(F.am, idx0, of, od);
         if (of >= 0) *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
         if (od >= 0) {
 #pragma unroll
@@ -320,6 +321,34 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(const GemmGro
     gemm_ride_body<true>(grp, &F, R, tiles);
 }
 
+// Large minibatches: 64 x 64 tiles with the batch rows split over workgroups (dw64.h), same riders behind the tiles
+#include "dw64.h"
+template <bool ADAM>
+__device__ __forceinline__ void dw64_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, const Dw64Args &X) {
+    __shared__ __attribute__((aligned(16))) float lds[DW_LDS_FLOATS];
+    __shared__ int aux[256];
+    if ((int)blockIdx.x < X.n_wg) {
+        dw64_tile<ADAM>(grp, F, X, (int)blockIdx.x, lds, aux);
+        return;
+    }
+    const int extra = (int)blockIdx.x - X.n_wg;
+    if (extra < R.n_plan) {
+        if (threadIdx.x >= MT_THREADS) return;
+        __builtin_amdgcn_s_setprio(3);
+        mt_her_plan(R.rng, R.meta->current_size, R.T, R.plan_batch, 1, R.future_p, R.next_plan,
+                    reinterpret_cast<uint32_t(*)[MT_N]>(lds), aux);
+    } else {
+        s8r4::s8_gather_ahead(R.ahead, R.aXT, R.aXA, R.aXP, R.ldx, R.act_off, R.act_dim, R.max_action, extra - R.n_plan,
+                              R.n_ahead);
+    }
+}
+__global__ __launch_bounds__(DW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dw64(const GemmGroup grp, const RideArgs R, const Dw64Args X) {
+    dw64_ride_body<false>(grp, nullptr, R, X);
+}
+__global__ __launch_bounds__(DW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dw64_adam(const GemmGroup grp, const AdamFuse F, const RideArgs R, const Dw64Args X) {
+    dw64_ride_body<true>(grp, &F, R, X);
+}
+
 
 enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
 
@@ -362,6 +391,10 @@ struct hp_agent {
     DevBuf adam_tab;                     // float[4] per update of a sequence (sized with the index plan)
     bool fuse_dw_ok = false;             // RLARM_FUSE_DW=1: single-launch updates (default: chain kernel + tile kernel)
     long long fused_launches = 0;
+    // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
+    bool dw64 = false;                   // RLARM_DW64: default on with the slab32 engine
+    int dw_S = 6;                        // RLARM_DW_SPLIT
+    DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -1168,6 +1201,38 @@ static Launch build_dw_group(const hp_agent *a, const float *sXA, const float *s
     return L;
 }
 
+// tile table + exchange buffers of the large-minibatch weight-gradient launch (dw64.h)
+static int dw64_args(hp_agent *a, const Launch &L, Dw64Args &X) {
+    memset(&X, 0, sizeof(X));
+    X.S = a->dw_S;
+    int K = 0, tiles = 0;
+    for (int i = 0; i < L.g.n; ++i) {
+        const GemmProb &p = L.g.p[i];
+        HP_REQUIRE(p.a_si == 1 && p.b_sj == 1 && p.M % 8 == 0 && p.N % 8 == 0 && p.K % DW_KH == 0, HP_ERR_INVALID,
+                   "dw64: operand layout");
+        X.tile0[i] = tiles;
+        X.tiles_n[i] = (p.N + 63) / 64;
+        tiles += ((p.M + 63) / 64) * X.tiles_n[i];
+        K = p.K > K ? p.K : K;
+    }
+    X.kslice = ((K + X.S - 1) / X.S + DW_KH - 1) / DW_KH * DW_KH;
+    X.n_wg = X.S * tiles;
+    X.placed = 0;
+    if (a->gemm_xcd && X.S % 2 == 0 && L.g.n == 8) {
+        X.placed = 1;
+        for (int i = 0; i < 8; ++i) {
+            const int nt = (i + 1 < 8 ? X.tile0[i + 1] : tiles) - X.tile0[i];
+            if (nt != (i < 4 ? 16 : 4)) X.placed = 0;
+        }
+    }
+    // allocated by hp_agent_create (this runs under stream capture)
+    HP_REQUIRE(a->dw_part.bytes >= (size_t)tiles * X.S * DW_PART * sizeof(float) && a->dw_ticket.bytes >= sizeof(unsigned) * (size_t)tiles,
+               HP_ERR_INVALID, "dw64: exchange buffers too small");
+    X.part = a->dw_part.as<float>();
+    X.ticket = a->dw_ticket.as<unsigned>();
+    return HP_OK;
+}
+
 // slab engine: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): 3 launches
 // only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
 static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
@@ -1304,10 +1369,10 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
     }
     if (!fused && only != 1) {   // all weight gradients (+ the optimizer when no gradient exchange follows) as their own launch
         Launch L = build_dw_group(a, sXA, sXP, gc ? gc->grads_out : nullptr);
-        if (ride_dw && ((gc->next_plan && gc->rng) || gc->ahead_plan)) {
-            ProfScope ps(a, PROF_DW);
-            RideArgs R;
-            memset(&R, 0, sizeof(R));
+        const bool riders = ride_dw && ((gc->next_plan && gc->rng) || gc->ahead_plan);
+        RideArgs R;
+        memset(&R, 0, sizeof(R));
+        if (riders) {
             if (gc->next_plan && gc->rng) {
                 R.n_plan = 1;
                 R.rng = gc->rng->d_state; R.meta = gc->b->d_meta; R.next_plan = gc->next_plan; R.future_p = gc->future_p;
@@ -1324,6 +1389,23 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
                 R.aXT = xs ? a->XT : a->XT2; R.aXA = xs ? a->XA : a->XA2; R.aXP = xs ? a->XP : a->XP2;
                 R.ldx = ldx; R.act_off = a->act_off; R.act_dim = a->cfg.act_dim; R.max_action = (float)a->cfg.max_action;
             }
+        }
+        if (a->dw64) {
+            // large minibatch: 64 x 64 tiles, batch rows split over workgroups (dw64.h); the riders follow the tiles
+            ProfScope ps(a, PROF_DW);
+            Dw64Args X;
+            HP_TRY(dw64_args(a, L, X));
+            const unsigned grid = X.n_wg + R.n_plan + R.n_ahead;
+            if (fuse_adam) {
+                AdamFuse F = adam_fuse(a);
+                F.keep_grads = (gc == nullptr) ? 1 : 0;
+                hipLaunchKernelGGL(k_dw64_adam, dim3(grid), dim3(DW_THREADS), 0, s, L.g, F, R, X);
+            } else {
+                hipLaunchKernelGGL(k_dw64, dim3(grid), dim3(DW_THREADS), 0, s, L.g, R, X);
+            }
+            HP_CHECK_HIP(hipGetLastError());
+        } else if (riders) {
+            ProfScope ps(a, PROF_DW);
             const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
@@ -1703,6 +1785,9 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // tile ~7 us warm, profiles/r02_fused_single_launch.txt), so it is opt-in
         a->fuse_dw_ok = tri("RLARM_FUSE_DW") == 1;
         if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
+        // weight gradients: 64 x 64 tiles with split batch rows (dw64.h) where the 32 x 32 tiles are L2-bound
+        a->dw64 = a->slab && (tri("RLARM_DW64") >= 0 ? tri("RLARM_DW64") == 1 : a->slab32);
+        if (const char *ds = getenv("RLARM_DW_SPLIT")) a->dw_S = atoi(ds) > 0 && atoi(ds) <= 16 ? atoi(ds) : a->dw_S;
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');
         // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
@@ -1712,6 +1797,14 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
+    if (st == HP_OK && a->dw64) {
+        Launch L = build_dw_group(a, a->XA, a->XP);
+        size_t tiles = 0;
+        for (int i = 0; i < L.g.n; ++i) tiles += (size_t)((L.g.p[i].M + 63) / 64) * ((L.g.p[i].N + 63) / 64);
+        if (a->dw_part.ensure(tiles * a->dw_S * DW_PART * sizeof(float)) != HP_OK || a->dw_ticket.ensure(tiles * sizeof(unsigned)) != HP_OK ||
+            hipMemsetAsync(a->dw_ticket.p, 0, tiles * sizeof(unsigned), a->ctx->stream) != hipSuccess)
+            st = HP_ERR_HIP;
+    }
     if (st == HP_OK && a->slab8) {   // fused single-launch update (slab8.h FuseArgs)
         A(&a->params_b, a->n_arena); A(&a->fragF_b, a->n_arena); A(&a->fragD_b, a->n_arena);
         if (st == HP_OK) st = dev_alloc(a, &a->fsync, 1);
@@ -2502,6 +2595,8 @@ void hp_agent_destroy(hp_agent *a) {
     a->act_ws.release();
     a->plan.release();
     a->adam_tab.release();
+    a->dw_part.release();
+    a->dw_ticket.release();
     a->norm_plan.release();
     a->fwd_ws.release();
     a->pin.release();

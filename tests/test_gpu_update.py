@@ -159,10 +159,12 @@ def test_updates_track_oracle_over_a_cycle(batch, k, engine="", monkeypatch=None
     for i in range(n_up):
         tr, _ = st.sample(batch, fp, rs)
         res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
-        # each update is within 1e-5 of the oracle when both start from the same state (golden tests above);
-        # over 40 chained updates the two fp32 trajectories separate slowly (observed <= 1e-5 here), so the
-        # chained comparison allows 1e-4
-        tol = 1e-4
+        # each update is within 1e-5 of the oracle when both start from the same state (golden tests above); over 40
+        # chained updates the two fp32 trajectories separate, by an amount that depends on the (batch, engine) pair and not
+        # on the engine: tools/ubench/drift_check.py over batches 512..4096 x three engines reads 1.5e-7 .. 1.4e-4 (e.g. the
+        # 16-row engine 6.6e-5 at 2560 where the 32-row engine has 2.3e-7, and the reverse at 2048) -- Adam's first steps
+        # divide by sqrt(v) ~ |g|, so a last-bit difference in a near-zero gradient moves that weight by a full lr.
+        tol = 3e-4
         assert abs(got[i, 0] - res["actor_loss"]) <= tol * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
         assert abs(got[i, 1] - res["critic_loss"]) <= tol * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
     assert state_equal(rng, *rs.get_state()[1:3])
@@ -176,6 +178,17 @@ def test_slab32_engine_tracks_oracle_over_a_cycle(batch, monkeypatch):
     """The 32-row engine on v_mfma_f32_32x32x2 (slab32.h; the default from batch 2048) on small, ragged and large batches:
     inputs gathered by k_gather_fused beside the previous update, index plans on the second stream or in a spare workgroup."""
     test_updates_track_oracle_over_a_cycle(batch, 4, "RLARM_ENGINE=slab32", monkeypatch)
+
+
+@pytest.mark.parametrize("batch,split", [(256, 1), (449, 3), (1024, 4), (1281, 6), (3072, 6), (2080, 5)])
+def test_split_weight_gradient_kernel_tracks_oracle(batch, split, monkeypatch):
+    """dw64.h (the default weight-gradient launch of the 32-row engine): 64 x 64 tiles whose batch rows are split over
+    `split` workgroups that meet through write-through partial tiles and a ticket -- forced here onto every engine and
+    onto ragged slices (1281 rows -> slices of 224/.../161 padded rows), odd splits (no XCD placement) and split 1 (no
+    exchange at all)."""
+    monkeypatch.setenv("RLARM_DW64", "1")
+    monkeypatch.setenv("RLARM_DW_SPLIT", str(split))
+    test_updates_track_oracle_over_a_cycle(batch, 4)
 
 
 @pytest.mark.parametrize("n_batches", [5, 1, 2])     # 1 and 2: shorter than the two-update lead of the index plans
@@ -494,11 +507,12 @@ def test_fused_single_launch_updates_are_used_and_healthy(batch, monkeypatch):
     assert np.array_equal(bits(agent.actor_network(x).numpy()), bits(twin.actor_network(x).numpy()))
 
 
-@pytest.mark.parametrize("batch", [256, 1024, 2048])
+@pytest.mark.parametrize("batch", [256, 1024, 2048, 3072])
 def test_repeated_runs_are_bit_identical(batch, monkeypatch):
     """Race check for the concurrent pieces of a cycle (index plans drawn two updates ahead, next minibatch gathered by
     spare workgroups, input sets ping-ponging): 60 cycles = 2400 updates twice, then once with gather-ahead off --
-    identical parameters and sampler state every time.  Batch 256 runs 4-row slabs, 1024 8-row slabs."""
+    identical parameters and sampler state every time.  Batch 256 runs 4-row slabs, 1024 8-row slabs, 3072 the 32-row
+    engine whose weight-gradient workgroups meet through tickets (dw64.h: the sum order must not depend on who arrives last)."""
     def run():
         torch.manual_seed(0)
         agent, rng = make_agent(batch=batch, n_eps=32, seed=21)

@@ -65,6 +65,8 @@ for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
     if v[0]:
         print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-tl[160])/100:.1f}" for k in range(8) if v[k]),
               "| first stamp at", (tl[base] - tl[0]) / 100 if tl[0] else None, "us after chain start")
+for k, nm in ((9, "K loop"), (11, "ticket"), (13, "end")):
+    if tl[160 + k]: print(f"[timeline dW latest {nm}] {((tl[160 + k] >> 12) - tl[160]) / 100:.1f} us by workgroup {tl[160 + k] & 4095}")
 floor("after cycles")
 # eager path
 _lib.check(lib.hp_agent_sample_and_update(h, buf.h, on.h, gn.h, rng.h, 0.8, squared_threshold(0.05), 40)); ctx.synchronize()
