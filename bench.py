@@ -426,6 +426,7 @@ def main():
                         else "torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
                    "exchange": ("peer-memory" if dp_peer else "rccl" if dp_native else "torch.distributed") if (world > 1 or force_dp) else None,
                    "cycle_mode": cycle_mode,
+                   "engine": r.agent.engine(),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])],
                    "shader_clock_mhz_after_run": round(mhz.value)},
@@ -437,9 +438,10 @@ def main():
         # (hp_agent_debug_chain kinds 11 / 12): kernel time + one graph kernel boundary (~1.5 us) per launch, no event
         # overhead inside.  rocprofv3 kernel durations of the same command (profiles/) are that minus the boundary.
         ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
-        slab8 = a.batch <= 1792 and os.environ.get("RLARM_ENGINE", "slab8") == "slab8"
-        kinds = {"chain": (11, 699_648 + 395_776, "k_fb_slab8" if slab8 else "k_fwd_slab + k_bwd_slab"),
-                 "weight_grad": (12, 287_488, "k_gemm_lds_adam")}
+        eng = r.agent.engine()
+        chain_kernel = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32", "slab16": "k_fwd_slab + k_bwd_slab"}.get(eng["engine"], "k_gemm_group")
+        dw_kernel = "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam"
+        kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
         pmc, pmc_file = {}, None
         for cand in (f"r02_pmc_traffic_b{a.batch}.json",):
             path = os.path.join(REPO, "profiles", cand)
@@ -468,9 +470,9 @@ def main():
             # an event pair with nothing in between reads on this stack
             live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
             if name == "chain":
-                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fwd_slab", "k_bwd_slab"))
+                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fb_slab32", "k_fwd_slab", "k_bwd_slab"))
             else:   # the ride-along variant runs on all but the last updates of a cycle
-                rp = prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam", 0.0)
+                rp = prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam", 0.0)
             used = max(live, rp)
             tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
             per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "live_event_pair_minus_empty_us": round(live, 3),
@@ -494,11 +496,14 @@ def main():
             "event_pair_empty_us": round(ev_floor_us, 3),
             "whole_update_tflops": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12, 3),
             "whole_update_frac": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
+            "engine": eng,
             "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup (4-row slabs on "
-                    "v_mfma_f32_4x4x1 up to batch 448, 8-row up to 1024, 16-row beyond; 16x16x4 MFMA engine past 1792).  At "
-                    "batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at ~2.4 us against "
-                    "2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight stream, not by the "
-                    "matrix pipes (DESIGN.md 3.1)",
+                    "v_mfma_f32_4x4x1 up to batch 448, 8-row up to 1024, 16-row up to 2048; 32-row slabs on v_mfma_f32_32x32x2 "
+                    "beyond).  At batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at "
+                    "~2.4 us against 2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight "
+                    "stream, not by the matrix pipes.  At batch 4096 every CU streams the weights at the ~30 GB/s per CU the L2s "
+                    "deliver to 256 CUs at once (MI355X_MICROARCH.md ldsdma-fill): 16 flop per streamed byte caps the 32-row "
+                    "engine at ~70 % of the MFMA peak (DESIGN.md 3.1, 3.3)",
             "all_matrix_kernels": per,
         }
         # the HBM-bound half of the path.  In the update loop the gather is fused into k_fb_slab8; the

@@ -338,6 +338,11 @@ int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);
  * optimizer as its second phase) and the sticky error word of their in-kernel hand-off (0 in a healthy run).
  * Synchronises. */
 int hp_agent_fused_status(hp_agent *ag, int64_t *fused_launches, uint32_t *error);
+/* Which kernels hp_agent_sample_and_update / hp_agent_train_cycle run for this agent (chosen at creation from the batch
+ * size and the RLARM_* switches): *engine = 0 layer-per-launch, 8 thin row slabs (slab8.h, *slab_rows = 4 / 8 / 16), 16
+ * two-kernel 16-row slabs (slab.h), 32 the 32-row engine (slab32.h); *dw_split = 0 for 32 x 32 weight-gradient tiles
+ * (gemm_lds.h), else the number of batch-row slices per 64 x 64 tile (dw64.h).  Any pointer may be null. */
+int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *dw_split);
 int hp_agent_profile(hp_agent *ag, int32_t enable);
 int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
 

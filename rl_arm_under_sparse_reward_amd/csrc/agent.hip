@@ -1582,6 +1582,10 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             PlanRec *next = a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B;
             if (side) {
                 (void)next;
+            } else if (a->slab32 && s32_serial && 2 * (a->Mp / S32_ROWS) >= a->ctx->cu_count) {
+                // serial mode (profiling, RLARM_PLAN_SIDE=0) of a launch that fills the CUs: a spare workgroup would only start
+                // when the first chain ends (137 instead of 87 us per launch at batch 4096) -- draw in front of the launch
+                HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, 1, future_p, next));
             } else {
                 gc.rng = rng;
                 gc.next_plan = next;
@@ -2525,6 +2529,14 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
 #ifdef SLAB_TIMELINE   // weight-gradient GEMM stamps: first workgroup at [160..175], last at [176..191]
     HP_CHECK_HIP(hipMemcpyFromSymbol(out192 + 160, HIP_SYMBOL(g_gemm_tl), 32 * 8));
 #endif
+    return HP_OK;
+}
+
+int hp_agent_engine(hp_agent *a, int32_t *engine, int32_t *slab_rows, int32_t *dw_split) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_engine: null handle");
+    if (engine) *engine = !a->slab ? 0 : (a->slab8 ? 8 : (a->slab32 ? 32 : 16));
+    if (slab_rows) *slab_rows = !a->slab ? 0 : (a->slab8 ? a->s8_rows : (a->slab32 ? S32_ROWS : SL_ROWS));
+    if (dw_split) *dw_split = a->dw64 ? a->dw_S : 0;
     return HP_OK;
 }
 

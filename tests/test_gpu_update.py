@@ -639,3 +639,14 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
     x = np.random.RandomState(1).normal(size=(9, obs_dim + goal_dim)).astype(np.float32)
     want = oupd.actor_forward({k: v.detach() for k, v in learner.actor.items()}, torch.from_numpy(x), 0.5).numpy()
     assert np.allclose(agent.actor_network(x), want, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 8, "gemm_lds 32x32")),
+                                        (2048, ("slab8", 16, "gemm_lds 32x32")), (2049, ("slab32", 32, "dw64 split 6")),
+                                        (4096, ("slab32", 32, "dw64 split 6"))])
+def test_default_engine_table(batch, want):
+    """hp_agent_engine: the kernels picked from the batch size alone (measured table in
+    profiles/r02_large_batch_engines.txt)."""
+    agent, _ = make_agent(batch=batch, n_eps=8, seed=1)
+    e = agent.engine()
+    assert (e["engine"], e["slab_rows"], e["weight_grad"]) == want
