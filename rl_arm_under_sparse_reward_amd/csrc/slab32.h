@@ -66,8 +66,11 @@ __host__ __device__ __forceinline__ void frag32_offsets(const ArenaMap &am, int 
 
 #ifdef SLAB_TIMELINE   // debug build: slab 0 of each chain stamps the 100 MHz wall clock (tl[chain * 32 + k])
 #define S32_STAMP(k) do { if (slab == 0 && tid == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
+// per-wave stamps inside one layer: wtl[4 * wave + k]
+#define S32_WSTAMP(wtl, k) do { if ((wtl) && (threadIdx.x & 63) == 0) (wtl)[4 * (threadIdx.x >> 6) + (k)] = wall_clock64(); } while (0)
 #else
 #define S32_STAMP(k) do { } while (0)
+#define S32_WSTAMP(wtl, k) do { } while (0)
 #endif
 
 namespace s32 {
@@ -138,7 +141,7 @@ __device__ __forceinline__ void ring_step32(f32x16 &c, RingSlot *ring, const flo
 // epilogue of a layer: this wave's 32 x 32 tile -> LDS slab (row major), optional global copy, ReLU masks
 //   SE_BIAS_RELU: o = max(v + bias[col], 0), mask_out[col] bit r = (o > 0)        SE_MASK: o = mask_in[col] bit r ? v : 0
 __device__ __forceinline__ void finish(const f32x16 &acc, int epi, const float *__restrict__ bias, float *lout, int ld_out,
-                                       const s32_mask_t *mask_in, s32_mask_t *mask_out, float *gout) {
+                                       const s32_mask_t *mask_in, s32_mask_t *mask_out) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = 32 * wave + (lane & 31), h = lane >> 5;
     const float b = (epi == SE_BIAS_RELU) ? bias[col] : 0.f;
@@ -156,7 +159,6 @@ __device__ __forceinline__ void finish(const f32x16 &acc, int epi, const float *
             o = ((bits >> row) & 1u) ? v : 0.f;
         }
         lout[row * ld_out + col] = o;
-        if (gout) gout[(size_t)row * 256 + col] = o;   // 32 lanes write 32 consecutive floats of one row
     }
     if (mask_out) {
         outbits |= __shfl_xor(outbits, 32);            // the two row halves of a column live in lanes l and l + 32
@@ -164,23 +166,36 @@ __device__ __forceinline__ void finish(const f32x16 &acc, int epi, const float *
     }
 }
 
+__device__ __forceinline__ void slab_store32(const float *l, int ld, int width, float *g, int ldg);
+
 // out[32][256] = epi(in[32][256] . W), DMA-ring fed.  The first S32_RING blocks of `wlayer` must be in flight; on return
 // the first S32_RING blocks of `nxt` are (if nxt != nullptr).
 template <int YS = 0>
 __device__ __forceinline__ void big_layer32(const float *lin, RingSlot *ring, const float *__restrict__ wlayer,
                                           const float *__restrict__ nxt, int epi, const float *__restrict__ bias, float *lout,
-                                          const s32_mask_t *mask_in, s32_mask_t *mask_out, float *gout) {
+                                          const s32_mask_t *mask_in, s32_mask_t *mask_out, float *gprev,
+                                          unsigned long long *wtl = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    S32_WSTAMP(wtl, 0);
+    // global copy of the INPUT slab (operand of the weight-gradient launch): 4 float4 stores per lane that complete under
+    // this layer's products.  The epilogue used to store its 16 accumulator registers one dword per lane each; in the
+    // per-wave timeline of one layer (-DSLAB_TIMELINE) that epilogue took 2.3 us for the waves that finish their products
+    // first (global stores are issue-bound) and the layer 9.2 us; with the copy here 1.0 us and 8.5 us.  The whole update did
+    // not move (132.6 vs 132.4 us at batch 4096: the next layer's start absorbs it), kept for the 4x fewer store instructions.
+    if (gprev) slab_store32(lin, S32_LD, 256, gprev, 256);
     f32x16 c;
     acc_zero(c);
     const float *arow = lin + (lane & 31) * S32_LD + 4 * (lane >> 5);
     const float4 afirst = *reinterpret_cast<const float4 *>(arow);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S32_RING - 1 + YS) : "memory");   // block 0 has landed
     const float4 bfirst = ring[0][lane];
+    S32_WSTAMP(wtl, 1);
     if (nxt) ring_step32<0, true, YS>(c, ring, wlayer, nxt, wave, arow, afirst, bfirst);
     else ring_step32<0, false, YS>(c, ring, wlayer, nxt, wave, arow, afirst, bfirst);
     __builtin_amdgcn_sched_barrier(0);
-    finish(c, epi, bias, lout, S32_LD, mask_in, mask_out, gout);
+    S32_WSTAMP(wtl, 2);
+    finish(c, epi, bias, lout, S32_LD, mask_in, mask_out);
+    S32_WSTAMP(wtl, 3);
 }
 
 // small layer (reduction length Kred = 16 / 32 / 48 -> 2 / 4 / 6 blocks): weights straight from global into registers
@@ -193,7 +208,7 @@ __device__ __forceinline__ void small_prefetch(const float *__restrict__ wlayer,
 }
 __device__ __forceinline__ void small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
                                             const float *__restrict__ bias, float *lout, const s32_mask_t *mask_in,
-                                            s32_mask_t *mask_out, float *gout) {
+                                            s32_mask_t *mask_out) {
     const int lane = threadIdx.x & 63;
     const int nb = Kred >> 3;
     f32x16 c;
@@ -202,7 +217,7 @@ __device__ __forceinline__ void small_layer(const float *lin, int ld_in, int Kre
 #pragma unroll
     for (int t = 0; t < 6; ++t)
         if (t < nb) mma432(c, *reinterpret_cast<const float4 *>(arow + 8 * t), b[t]);
-    finish(c, epi, bias, lout, S32_LD, mask_in, mask_out, gout);
+    finish(c, epi, bias, lout, S32_LD, mask_in, mask_out);
 }
 
 // Head layers (4 or 1 outputs of reduction length 256) for the S32_RPW = 4 rows a wavefront owns: lane p takes reduction
@@ -277,19 +292,21 @@ __device__ __forceinline__ void slab_load32(float *l, int ld, int width, const f
 }
 
 // xin (K1 wide) -> h1 -> h2 -> h3 (left in bufA).  Ring: layer 2 in flight on entry, `nxt` on exit.
-template <bool KEEP>   // KEEP: g1..g3 are non-null (global copies for the weight gradients): 16 stores per wave and layer
+template <bool KEEP>   // KEEP: g1..g3 are non-null (global copies for the weight gradients): each slab is copied out of LDS by
+                       // the layer that consumes it (big_layer32 gprev), h3 at the end: 4 float4 stores per lane and slab
 __device__ __forceinline__ void trunk(const float *xin, const NetLayout &l, const float4 (&wb1)[6], const float *wf,
                                       const float *canon, float *bufA, float *bufB, float *g1, float *g2, float *g3,
                                       size_t row0, RingSlot *ring, const float *nxt, s32_mask_t *m1, s32_mask_t *m2,
                                       s32_mask_t *m3) {
-    small_layer(xin, S32_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, bufA, nullptr, m1, g1 ? g1 + row0 * 256 : nullptr);
+    small_layer(xin, S32_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, bufA, nullptr, m1);
     sync();
-    big_layer32<KEEP ? 16 : 0>(bufA, ring, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, bufB, nullptr, m2,
-                               g2 ? g2 + row0 * 256 : nullptr);
+    big_layer32<KEEP ? 4 : 0>(bufA, ring, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, bufB, nullptr, m2,
+                              g1 ? g1 + row0 * 256 : nullptr);
     sync();
-    big_layer32<KEEP ? 16 : 0>(bufB, ring, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, bufA, nullptr, m3,
-                               g3 ? g3 + row0 * 256 : nullptr);
+    big_layer32<KEEP ? 4 : 0>(bufB, ring, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, bufA, nullptr, m3,
+                              g2 ? g2 + row0 * 256 : nullptr);
     sync();
+    if (g3) slab_store32(bufA, S32_LD, 256, g3 + row0 * 256, 256);
 }
 
 __device__ __forceinline__ void head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
@@ -423,10 +440,14 @@ __global__ __launch_bounds__(S32_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         slab_store32(bufA, S32_LD, H, Bk.dA3 + row0 * H, H);
         S32_STAMP(5);
         // (4 = the float4 stores per wave of the slab copy just above)
-        big_layer32<4>(bufA, ring, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, bufB, msk[1], nullptr, Bk.dA2 + row0 * H);
+        big_layer32<4>(bufA, ring, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, bufB, msk[1], nullptr, nullptr,
+                       slab == 0 ? A.tl + 96 : nullptr);
         sync();
         S32_STAMP(6);
-        big_layer32<16>(bufB, ring, on.wd + ca + lc.w2, nullptr, SE_MASK, nullptr, bufA, msk[0], nullptr, Bk.dA1 + row0 * H);
+        S32_WSTAMP(slab == 0 ? A.tl + 128 : nullptr, 0);
+        big_layer32<4>(bufB, ring, on.wd + ca + lc.w2, nullptr, SE_MASK, nullptr, bufA, msk[0], nullptr, Bk.dA2 + row0 * H);
+        sync();
+        slab_store32(bufA, S32_LD, H, Bk.dA1 + row0 * H, H);
         S32_STAMP(7);
         if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
             Bk.st->step += 1;
@@ -547,13 +568,15 @@ __global__ __launch_bounds__(S32_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     }
     sync();
     S32_STAMP(7);
-    small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, bufB, msk[4], nullptr, Bk.dK3 + row0 * H);
+    small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, bufB, msk[4], nullptr);
     sync();
     S32_STAMP(8);
-    big_layer32<16>(bufB, ring, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, bufA, msk[3], nullptr, Bk.dK2 + row0 * H);
+    big_layer32<4>(bufB, ring, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, bufA, msk[3], nullptr, Bk.dK3 + row0 * H);
     sync();
     S32_STAMP(9);
-    big_layer32<16>(bufA, ring, on.wd + la.w2, nullptr, SE_MASK, nullptr, bufB, msk[2], nullptr, Bk.dK1 + row0 * H);
+    big_layer32<4>(bufA, ring, on.wd + la.w2, nullptr, SE_MASK, nullptr, bufB, msk[2], nullptr, Bk.dK2 + row0 * H);
+    sync();
+    slab_store32(bufB, S32_LD, H, Bk.dK1 + row0 * H, H);
     S32_STAMP(10);
 }
 

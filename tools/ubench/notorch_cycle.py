@@ -65,6 +65,10 @@ for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
     if v[0]:
         print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-tl[160])/100:.1f}" for k in range(8) if v[k]),
               "| first stamp at", (tl[base] - tl[0]) / 100 if tl[0] else None, "us after chain start")
+if os.environ.get("RLARM_ENGINE") == "slab32" or int(os.environ.get("BATCH", "256")) > 2048:
+    base = tl[96]
+    for w in range(8):
+        print(f"[timeline slab32 layer wave {w}] " + " ".join(f"{k}:{(tl[96 + 4 * w + k] - base) / 100:.2f}" for k in range(4)) + f" after-sync:{(tl[128 + 4 * w] - base) / 100:.2f}")
 for k, nm in ((9, "K loop"), (11, "ticket"), (13, "end")):
     if tl[160 + k]: print(f"[timeline dW latest {nm}] {((tl[160 + k] >> 12) - tl[160]) / 100:.1f} us by workgroup {tl[160 + k] & 4095}")
 floor("after cycles")
