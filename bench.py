@@ -220,6 +220,19 @@ def profile_kernels(r: Runner, cycles=3):
     return prof
 
 
+def baseline_metric_name(a):
+    """BASELINE.json's metric string for its headline shape (batch 256, replay_k 4); the other shapes say what they are."""
+    name = "HER-relabelled transitions sampled+updated /sec"
+    try:
+        with open(os.path.join(REPO, "BASELINE.json")) as fh:
+            headline = json.load(fh)["metric"]
+    except (OSError, KeyError, ValueError):
+        headline = name + ", batch 256, 1/2/4/8 MI355X"
+    if a.batch == 256 and a.replay_k == 4:
+        return headline
+    return f"{name}, batch {a.batch}, replay_k {a.replay_k} (not the BASELINE headline shape)"
+
+
 def cpu_baseline(a, seconds):
     """The oracle ("port": numpy sampler + torch-CPU update, the reference's own arithmetic) on the
     host cores, same workload, bounded sample.  Checker code used as a timed baseline only."""
@@ -406,7 +419,7 @@ def main():
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.batch * a.steps / dt
     out = {
-        "metric": "HER-relabelled transitions sampled+updated per second",
+        "metric": baseline_metric_name(a),
         "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

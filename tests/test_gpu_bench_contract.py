@@ -1,0 +1,53 @@
+"""bench.py's output contract, checked on the line itself: the driver's own invocation (`--gpus 1 --steps 20 --warmup 5`) and
+the self-launching multi-rank form (`--gpus 2` from a plain shell; on a 1-GPU box the two ranks share the device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], cwd=REPO, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # ONE JSON line
+    assert p.stdout.rstrip().splitlines()[-1] == lines[0]   # ... and it is the last thing printed
+    return json.loads(lines[0])
+
+
+def test_driver_invocation_prints_the_contract_line():
+    with open(os.path.join(REPO, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "3")
+    assert d["metric"] == base["metric"] and d["unit"] == "transitions/s"
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 20, 5)
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 256 * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-3 * d["value"]     # value = transitions / timed region
+    assert 2e6 < d["value"] < 2e7                                     # a plausible MI355X figure, not a unit slip
+    assert d["config"]["engine"] == {"engine": "slab8", "slab_rows": 4, "weight_grad": "gemm_lds 32x32"}
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == pytest.approx(157.3)
+    assert 0.0 < r["frac"] < 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    assert r["achieved"] == pytest.approx(r["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12, rel=1e-3)
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert 0.0 < r["whole_update_frac"] < r["frac"] * 1.5
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "transitions/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["cycle_boundaries_in_timed_region"]["polyak"] == 0       # 20 steps never reach a cycle boundary: said so
+
+
+def test_plain_shell_multi_rank_launch():
+    d = _run("--gpus", "2", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile")
+    assert d["n_gpus"] == 2 and d["steps"] == 80
+    assert d["config"]["exchange"] in ("peer-memory", "rccl", "torch.distributed")
+    assert abs(d["value"] - 2 * 256 * 80 / (d["ms_per_step"] * 80e-3)) <= 1e-3 * d["value"]   # whole-job aggregate
