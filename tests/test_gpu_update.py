@@ -456,7 +456,10 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           ("RLARM_FUSE_DW=1", 256), ("RLARM_FUSE_DW=1", 128), ("RLARM_FUSE_DW=1", 449),
                                           ("RLARM_FUSE_DW=1", 512), ("RLARM_FUSE_DW=1", 1024), ("RLARM_FUSE_DW=1", 1536),
                                           ("RLARM_PLAN_SIDE=1", 256), ("RLARM_PLAN_SIDE=0", 1024), ("RLARM_PLAN_SIDE=0", 2048),
-                                          ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256)])
+                                          ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256),
+                                          # 32-row engine + split weight-gradient tiles: XCD placement of the (problem, slice)
+                                          # groups off, look-ahead on a second stream / in front of every launch
+                                          ("RLARM_GEMM_XCD=0", 3072), ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, a ring of reduction chunks in the weight-gradient GEMM beyond 256 rows, its big problems placed on XCD
