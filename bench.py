@@ -307,6 +307,44 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
+def first_cycle_or_fallback(a, rank, world, force_dp, shared):
+    """Build the rank's state and run the first full cycle (graph capture, exchange set-up).  At N > 1 the ranks then agree
+    that it went through everywhere; if the peer-memory exchange failed on any rank (a bounded wait of its kernels gave up,
+    an IPC mapping the self-check did not catch) ALL ranks rebuild on the next transport down -- library-side RCCL, then
+    torch.distributed -- instead of leaving the scaling run without a line.  config.exchange names what ran."""
+    order = ["auto", "rccl", "torch"]
+    forced = os.environ.get("RLARM_COMM")
+    if forced in order:
+        order = order[order.index(forced):]
+    elif forced:
+        order = [forced]
+    last = None
+    for mode in order:
+        if mode != "auto" or forced:
+            os.environ["RLARM_COMM"] = mode
+        ok, r = 1, None
+        try:
+            r = Runner(a, rank, world, force_dp)
+            r.run_steps(N_BATCHES)
+            r.sync()
+            if os.environ.get("RLARM_BENCH_FAIL_FIRST") == str(rank) and mode == order[0]:   # test hook: one rank's first
+                raise RuntimeError("injected failure (RLARM_BENCH_FAIL_FIRST)")                # transport "fails"
+        except Exception as e:          # noqa: BLE001 -- any failure of this rank must reach the agreement below
+            ok, last = 0, e
+            print(f"[bench rank {rank}] exchange '{mode}' failed in the first cycle: {e}", file=sys.stderr, flush=True)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([ok], dtype=torch.int32, device="cpu" if shared else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            return r
+        if world == 1:
+            break
+    raise RuntimeError(f"no exchange transport completed the first cycle: {last}")
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -338,14 +376,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-    r = Runner(a, rank, world, force_dp)
+    r = first_cycle_or_fallback(a, rank, world, force_dp, shared)
     # One-time initialisation, not warm-up.  (1) The first full cycle captures and instantiates the cycle hipGraph (and,
     # at N > 1, sets up the exchange channels).  (2) A rehearsal of the exact warm-up + timed step pattern lets the
     # library capture the partial-cycle graphs that pattern needs (hp_agent_sample_and_update caches one graph per
     # chunk length), then the cycle is completed so that the measured pass starts at the same cycle position and
     # replays the same graphs.  Without it a short --steps would time graph instantiation instead of the hot path.
-    r.run_steps(N_BATCHES)
-    r.sync()
     r.run_steps(a.warmup)
     r.run_steps(a.steps)
     r.run_steps((-r.in_cycle) % N_BATCHES)

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags, timeout=600):
-    env = dict(os.environ)
+def _run(*flags, timeout=600, **extra_env):
+    env = dict(os.environ, **extra_env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], cwd=REPO, env=env, capture_output=True,
@@ -51,3 +51,10 @@ def test_plain_shell_multi_rank_launch():
     assert d["n_gpus"] == 2 and d["steps"] == 80
     assert d["config"]["exchange"] in ("peer-memory", "rccl", "torch.distributed")
     assert abs(d["value"] - 2 * 256 * 80 / (d["ms_per_step"] * 80e-3)) <= 1e-3 * d["value"]   # whole-job aggregate
+
+
+def test_multi_rank_launch_survives_a_failing_exchange_on_one_rank():
+    """If the first transport fails on ANY rank in the first (untimed) cycle, all ranks agree and rebuild on the next one down
+    instead of leaving the scaling run without a line."""
+    d = _run("--gpus", "2", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", RLARM_BENCH_FAIL_FIRST="1")
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] in ("rccl", "torch.distributed")
