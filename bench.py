@@ -438,6 +438,12 @@ def main():
         barrier(world)
     dp_native = r.agent._native_comm is not None
     dp_peer = r.agent._peer is not None
+    peer_phases = None
+    if dp_peer:
+        import ctypes as _C
+        _ph = _C.c_int32()
+        r.agent.lib.hp_peer_phases(r.agent._peer, _C.byref(_ph))
+        peer_phases = _ph.value
     import ctypes as _C
     mode = _C.c_int32()
     r.agent.lib.hp_agent_cycle_mode(r.agent.h, _C.byref(mode))
@@ -474,6 +480,8 @@ def main():
                         "RCCL all-reduce issued by the library inside the cycle graph)" if dp_native
                         else "torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
                    "exchange": ("peer-memory" if dp_peer else "rccl" if dp_native else "torch.distributed") if (world > 1 or force_dp) else None,
+                   "peer_exchange_form": {1: "one-shot (every rank reads every peer's whole gradient vector)",
+                                          2: "two-phase (reduce-scatter + all-gather over peer memory)"}.get(peer_phases),
                    "cycle_mode": cycle_mode,
                    "engine": r.agent.engine(),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",

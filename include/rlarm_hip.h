@@ -312,6 +312,9 @@ int hp_peer_allreduce_f32(hp_peer *peer, void *dev, int64_t n, int32_t mean);
  * exactly representable pattern: *mismatches = number of wrong elements on this rank (top bit: a wait timed out) */
 int hp_peer_selfcheck(hp_peer *peer, uint32_t *mismatches);
 int hp_peer_status(hp_peer *peer, uint32_t *error);
+/* 1: one-shot exchange (every rank reads every peer's whole gradient vector), 2: reduce-scatter + all-gather over the same
+ * peer memory (default from 4 ranks; RLARM_PEER_PHASES=1|2).  Both sum in rank order: bit-identical results. */
+int hp_peer_phases(hp_peer *p, int32_t *phases);
 void hp_peer_destroy(hp_peer *peer);
 /* Attach (or detach with NULL): hp_agent_sample_and_update / hp_agent_train_cycle then exchange the gradients through
  * peer memory inside the optimizer kernel and the normalizer sums through the mailboxes.  hp_agent_grad_buffer-style

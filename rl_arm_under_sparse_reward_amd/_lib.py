@@ -123,6 +123,7 @@ PROTOTYPES = {
     "hp_peer_allreduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "hp_peer_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "hp_peer_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "hp_peer_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hp_peer_destroy": (None, [C.c_void_p]),
     "hp_agent_set_peer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_agent_cycle_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

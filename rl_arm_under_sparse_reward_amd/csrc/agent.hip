@@ -245,9 +245,32 @@ __global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFu
 }
 
 
+// two-phase exchange, phase 2 (phase 1 = k_peer_reduce_slice in peer.hip): every element's sum comes from the rank that
+// owns its slice; Adam on all of them.  Same values as k_peer_adam computes itself: bit-identical.
+__global__ __launch_bounds__(256) void k_peer_adam2(const PeerDev D, const AdamFuse F, int n4, int u) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    const int par = (int)(epoch & 1ull);
+    if (blockIdx.x == 0) peer_signal(D, D.flags_r, epoch);
+    peer_wait(D, D.flags_r[D.rank], epoch);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int owner = t / peer_slice_len(D, n4);
+    const float4 acc = peer_load4(D.red[owner][par], (size_t)n4 * 16, (unsigned)t * 16u, owner == D.rank);
+    const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (F.keep_grads) *reinterpret_cast<float4 *>(const_cast<float *>(F.grads_base) + 4 * (size_t)t) = acc;
+    adam_apply4(F, 4 * t, g);
+}
+
 static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, bool mean) {
     const int n4 = n_arena / 4;
-    hipLaunchKernelGGL(k_peer_adam, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u, mean ? 1 : 0);
+    if (p->phases == 2) {
+        HP_TRY(peer_enqueue_reduce_slice(p, n4, u, mean));
+        hipLaunchKernelGGL(k_peer_adam2, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u);
+    } else {
+        hipLaunchKernelGGL(k_peer_adam, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u, mean ? 1 : 0);
+    }
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }

@@ -11,6 +11,8 @@ struct PeerDev {              // by-value kernel argument: where every rank's ex
     unsigned long long *flags_s[HP_PEER_MAX];   // rank q's mailbox-channel flags
     float *small[HP_PEER_MAX][2];               // rank q's mailboxes (ping-pong by epoch parity)
     float *grad[HP_PEER_MAX][2];                // rank q's gradient vectors (ping-pong)
+    unsigned long long *flags_r[HP_PEER_MAX];   // two-phase exchange: rank q's "reduced slice ready" flags
+    float *red[HP_PEER_MAX][2];                 // two-phase exchange: rank q's buffer of reduced sums (it fills ITS slice)
     unsigned long long *epoch;                  // local: [0] gradient channel base, [1] mailbox channel
     unsigned int *error;                        // local, sticky: a wait timed out
     unsigned long long timeout_ticks;           // 100 MHz ticks
@@ -25,11 +27,13 @@ struct hp_peer {
     unsigned long long *d_epoch = nullptr;
     unsigned char handle[64] = {0};
     bool connected = false;
+    int phases = 1;            // 1: every rank reads all peers' whole vectors; 2: reduce-scatter + all-gather (peer.hip)
     PeerDev dev;
 };
 
 float *peer_grad_buffer(hp_peer *p, int parity);
 int peer_enqueue_seq_end(hp_peer *p, int n_updates);
+int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean);   // phase 1 of the two-phase exchange
 int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean);
 
 #ifdef __HIPCC__
@@ -63,6 +67,9 @@ __device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *
     }
     return ok;
 }
+
+// float4s [lo, lo + per) of the vector are rank r's slice in the two-phase exchange
+__device__ __forceinline__ int peer_slice_len(const PeerDev &D, int n4) { return (n4 + D.world - 1) / D.world; }
 
 // 4 consecutive floats of rank q's vector: the own vector with a plain load (written by the previous kernel), a peer's
 // with a system-scope load (sc0 sc1: never served from a stale line of this GPU's caches)

@@ -16,10 +16,18 @@
 //   buffers everywhere it matters, so G[e & 1] may be rewritten at epoch e + 2 without a second barrier.
 //   Epochs live in device memory (base + index of the update in its sequence), so a captured hipGraph replays correctly.
 //
+// Two-phase variant (default from 4 ranks, RLARM_PEER_PHASES=1|2): the one-shot form pulls every peer's WHOLE vector over
+// its link (1.17 MB per link and update whatever the world size); with W ranks a reduce-scatter + all-gather moves 2/W of
+// that per link -- rank r sums slice r of all vectors in rank order into its `red` buffer (k_peer_reduce_slice), a second
+// barrier, then every rank reads the W reduced slices from their owners and steps (k_peer_adam2 in agent.hip).  Same sums in
+// the same order: bit-identical to the one-shot form; one more kernel boundary and flag round trip (~4-5 us), so it only
+// pays once the link time it saves exceeds that (8 ranks: 2 x 146 KB instead of 1.17 MB per link).  Not measured on a
+// multi-GPU node (none available to the build); both forms are exercised by two processes sharing one device.
+//
 // The per-cycle normalizer exchange (normalizer.py:60-64, 62 floats) uses the same mechanism through small mailboxes
 // (k_peer_small: copy in, flag, poll, sum in rank order, optional / world).
 //
-// Memory: one fine-grained device allocation per rank ([flags | mailboxes | 2 x gradients]) exported with
+// Memory: one fine-grained device allocation per rank ([flags | mailboxes | 2 x gradients | 2 x reduced sums]) exported with
 // hipIpcGetMemHandle; the 64-byte handles travel through any side channel (the Python mirror uses torch.distributed).
 // RCCL (comm.hip) stays as the fallback transport; utils.Communicator picks this one when a self-check passes.
 #include "internal.h"
@@ -57,6 +65,31 @@ __global__ __launch_bounds__(256) void k_peer_small(const PeerDev D, float *vec,
     if (threadIdx.x == 0) D.epoch[1] = epoch;
 }
 
+// Two-phase exchange, phase 1: this rank reduces ITS slice of the gradient vectors, in rank order, into red[rank][par]
+__global__ __launch_bounds__(256) void k_peer_reduce_slice(const PeerDev D, int n4, int u, int mean) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    const int par = (int)(epoch & 1ull);
+    if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
+    peer_wait(D, D.flags_g[D.rank], epoch);
+    __syncthreads();
+    const int per = peer_slice_len(D, n4);
+    const int lo = D.rank * per, hi = (lo + per) < n4 ? (lo + per) : n4;
+    const int t = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hi) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t bytes = (size_t)n4 * 16;
+    for (int q = 0; q < D.world; ++q) {   // rank order: the same float32 sum as the one-shot form
+        const float4 v = peer_load4(D.grad[q][par], bytes, (unsigned)t * 16u, q == D.rank);
+        if (q == 0) acc = v;
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+    if (mean) {
+        const float w = (float)D.world;
+        acc.x /= w; acc.y /= w; acc.z /= w; acc.w /= w;
+    }
+    *reinterpret_cast<float4 *>(D.red[D.rank][par] + 4 * (size_t)t) = acc;   // own memory; the kernel boundary publishes it
+}
+
 // Self-check of the GRADIENT channel (the path k_peer_adam uses: flags, buffer parity, system-scope 16-byte loads of the
 // peers' vectors): every rank fills its own buffer with an exactly representable pattern, the ranks reduce it like
 // k_peer_adam does and count the elements that differ from the known sum.  Run at attach time for both buffer parities.
@@ -84,11 +117,36 @@ __global__ __launch_bounds__(256) void k_peer_check_reduce(const PeerDev D, int 
     if (wrong) atomicAdd(bad, (unsigned)wrong);
 }
 
+// ... and of the two-phase form: k_peer_reduce_slice (above) followed by this gather + compare
+__global__ __launch_bounds__(256) void k_peer_check_gather(const PeerDev D, int n4, int u, unsigned int *bad) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    const int par = (int)(epoch & 1ull);
+    if (blockIdx.x == 0) peer_signal(D, D.flags_r, epoch);
+    peer_wait(D, D.flags_r[D.rank], epoch);
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int owner = t / peer_slice_len(D, n4);
+    const float4 acc = peer_load4(D.red[owner][par], (size_t)n4 * 16, (unsigned)t * 16u, owner == D.rank);
+    const float w = (float)(D.world * (D.world + 1) / 2);
+    const float got[4] = {acc.x, acc.y, acc.z, acc.w};
+    int wrong = 0;
+    for (int j = 0; j < 4; ++j) wrong += got[j] != w * (float)(((4 * t + j) % 1021) + 1);
+    if (wrong) atomicAdd(bad, (unsigned)wrong);
+}
+
 // ---- internal entry points used by agent.hip -----------------------------------------------------------------------
 float *peer_grad_buffer(hp_peer *p, int parity) { return p->dev.grad[p->rank][parity & 1]; }
 
 int peer_enqueue_seq_end(hp_peer *p, int n_updates) {
     hipLaunchKernelGGL(k_peer_seq_end, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, n_updates);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean) {
+    const int per = (n4 + p->world - 1) / p->world;
+    hipLaunchKernelGGL(k_peer_reduce_slice, dim3((per + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, n4, u, mean ? 1 : 0);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -104,15 +162,17 @@ int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PeerLayout {
-    size_t flags_g, flags_s, small, grad, total;
+    size_t flags_g, flags_s, flags_r, small, grad, red, total;
     explicit PeerLayout(size_t n_grad) {
         size_t o = 0;
         flags_g = o; o += HP_PEER_MAX * 8;
         flags_s = o; o += HP_PEER_MAX * 8;
+        flags_r = o; o += HP_PEER_MAX * 8;
         o = align_up(o, 256);
         small = o; o += 2 * (size_t)HP_PEER_SMALL * 4;
         o = align_up(o, 256);
         grad = o; o += 2 * align_up(n_grad * 4, 256);
+        red = o; o += 2 * align_up(n_grad * 4, 256);
         total = align_up(o, 4096);
     }
 };
@@ -124,9 +184,11 @@ static void peer_fill_dev(hp_peer *p) {
         char *b = static_cast<char *>(p->remote[q]);
         p->dev.flags_g[q] = reinterpret_cast<unsigned long long *>(b + L.flags_g);
         p->dev.flags_s[q] = reinterpret_cast<unsigned long long *>(b + L.flags_s);
+        p->dev.flags_r[q] = reinterpret_cast<unsigned long long *>(b + L.flags_r);
         for (int k = 0; k < 2; ++k) {
             p->dev.small[q][k] = reinterpret_cast<float *>(b + L.small) + (size_t)k * HP_PEER_SMALL;
             p->dev.grad[q][k] = reinterpret_cast<float *>(b + L.grad + k * gstride);
+            p->dev.red[q][k] = reinterpret_cast<float *>(b + L.red + k * gstride);
         }
     }
 }
@@ -147,6 +209,8 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     p->rank = rank;
     p->world = world;
     p->n_grad = (size_t)n_grad_floats;
+    p->phases = world >= 4 ? 2 : 1;
+    if (const char *ph = getenv("RLARM_PEER_PHASES")) p->phases = atoi(ph) == 2 ? 2 : (atoi(ph) == 1 ? 1 : p->phases);
     const PeerLayout L(p->n_grad);
     p->bytes = L.total;
     // fine-grained: coherent with the peers' system-scope accesses; plain device memory if the runtime refuses
@@ -226,7 +290,12 @@ int hp_peer_selfcheck(hp_peer *p, uint32_t *mismatches) {
     // two consecutive epochs = both buffer parities, exactly as two updates of a sequence would use them
     for (int u = 0; u < 2; ++u) {
         hipLaunchKernelGGL(k_peer_check_fill, dim3((n + 255) / 256), dim3(256), 0, s, p->dev, n, (u + 1) & 1);
-        hipLaunchKernelGGL(k_peer_check_reduce, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
+        if (p->phases == 2) {
+            HP_TRY(peer_enqueue_reduce_slice(p, n4, u, false));
+            hipLaunchKernelGGL(k_peer_check_gather, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
+        } else {
+            hipLaunchKernelGGL(k_peer_check_reduce, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
+        }
     }
     HP_CHECK_HIP(hipGetLastError());
     HP_TRY(peer_enqueue_seq_end(p, 2));
@@ -242,6 +311,12 @@ int hp_peer_status(hp_peer *p, uint32_t *error) {
     CtxGuard guard(p->ctx);
     HP_CHECK_HIP(hipMemcpyAsync(error, p->dev.error, 4, hipMemcpyDeviceToHost, p->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+    return HP_OK;
+}
+
+int hp_peer_phases(hp_peer *p, int32_t *phases) {
+    HP_REQUIRE(p && phases, HP_ERR_INVALID, "hp_peer_phases: null argument");
+    *phases = p->phases;
     return HP_OK;
 }
 

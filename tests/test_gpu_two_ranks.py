@@ -29,7 +29,9 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir, transport="torch"):
     import sys
-    os.environ["RLARM_COMM"] = transport
+    os.environ["RLARM_COMM"] = "peer" if transport == "peer2" else transport
+    if transport == "peer2":                 # reduce-scatter + all-gather over the same peer memory (default from 4 ranks)
+        os.environ["RLARM_PEER_PHASES"] = "2"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -57,7 +59,12 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     rng = DeviceRandomState(seed)
     agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100), None, dict(ENV_PARAMS), comm=comm, rng=rng)
     assert agent._native_comm is None        # gloo group: no RCCL (two ranks share one device)
-    assert (agent._peer is not None) == (transport == "peer")
+    assert (agent._peer is not None) == transport.startswith("peer")
+    if transport.startswith("peer"):
+        import ctypes as C
+        ph = C.c_int32()
+        _lib.check(agent.lib.hp_peer_phases(agent._peer, C.byref(ph)))
+        assert ph.value == (2 if transport == "peer2" else 1)
     a0 = {k: v.detach().clone() for k, v in agent.actor_network.state_dict().items()}
     c0 = {k: v.detach().clone() for k, v in agent.critic_network.state_dict().items()}
     agent.buffer.store_episode(eps)
@@ -89,7 +96,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
            "oracle_critic": learner.flat("critic"), "critic0": oupd.flatten(list(c0.values())),
            "rng_equal": bool(np.array_equal(rng.get_state()[1], rs.get_state()[1]) and rng.get_state()[2] == rs.get_state()[2]),
            "o_mean": np.asarray(agent.o_norm.mean), "oracle_o_mean": np.asarray(on.mean)}
-    if transport == "peer":
+    if transport.startswith("peer"):
         # the whole cycle as ONE hipGraph with the exchange inside (gradients per update, normalizer sums once)
         import ctypes as C
         more = make_episodes(2, seed=70 + rank, mode="walk")
@@ -107,12 +114,14 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module", params=["torch", "peer"])
+@pytest.fixture(scope="module", params=["torch", "peer", "peer2"])
 def two_ranks(request, tmp_path_factory):
     """torch: collectives through torch.distributed (gloo, host-staged) from a host-driven loop.
     peer: the library's one-shot all-reduce over IPC-mapped peer memory, fused with Adam (csrc/peer.hip) -- the two
     processes map each other's exchange block on the shared device, which exercises flags, epochs, buffer ping-pong and the
-    rank-ordered sum exactly as two GPUs would (the fabric itself only exists on a multi-GPU node)."""
+    rank-ordered sum exactly as two GPUs would (the fabric itself only exists on a multi-GPU node).
+    peer2: the same memory used as reduce-scatter + all-gather (each rank sums its slice, a second flag round, every rank
+    gathers the reduced slices), the default from 4 ranks."""
     out = tmp_path_factory.mktemp("gpu2_" + request.param)
     mp.spawn(_worker, args=(2, _free_port(), str(out), request.param), nprocs=2, join=True)
     res = [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=False) for r in range(2)]
@@ -143,7 +152,7 @@ def test_each_rank_tracks_the_two_rank_oracle(two_ranks):
 
 def test_peer_exchange_keeps_ranks_identical_through_graph_cycles(two_ranks):
     r0, r1 = two_ranks
-    if r0["transport"] != "peer":
+    if not r0["transport"].startswith("peer"):
         pytest.skip("peer-memory transport only")
     assert r0["cycle_mode"] == 1 and r1["cycle_mode"] == 1          # the cycle, exchange included, replays as a hipGraph
     assert r0["peer_error"] == 0 and r1["peer_error"] == 0

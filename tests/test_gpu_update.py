@@ -400,7 +400,8 @@ def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
 @pytest.mark.parametrize("transport,graph,reduce", [("torch", False, "sum"), ("native", False, "sum"), ("native", True, "sum"),
                                                     ("torch", False, "mean"), ("native", True, "mean"),
                                                     ("peer", False, "sum"), ("peer", True, "sum"), ("peer", True, "mean"),
-                                                    ("native+dw64", True, "sum"), ("peer+dw64", True, "sum")])
+                                                    ("native+dw64", True, "sum"), ("peer+dw64", True, "sum"),
+                                                    ("peer+2phase", True, "sum"), ("peer+2phase", False, "mean")])
 def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, monkeypatch):
     """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
     begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
@@ -411,6 +412,9 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
     import socket
     import torch.distributed as dist
     from rl_arm_under_sparse_reward_amd.utils import Communicator
+    if transport.endswith("+2phase"):   # reduce-scatter + all-gather form of the peer exchange (one rank: one slice)
+        transport = transport[:-7]
+        monkeypatch.setenv("RLARM_PEER_PHASES", "2")
     if transport.endswith("+dw64"):   # the split weight-gradient kernel without its optimizer epilogue (k_dw64 -> exchange -> Adam)
         transport = transport[:-5]
         monkeypatch.setenv("RLARM_DW64", "1")
