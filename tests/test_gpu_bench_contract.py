@@ -18,7 +18,9 @@ def _run(*flags, timeout=600, **extra_env):
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], cwd=REPO, env=env, capture_output=True,
                        text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # (the ranks' constructor prints -- the reference's own "Buffer_size: ..." line -- may interleave; the record is the one
+    # line that parses as the contract's JSON object)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:]          # ONE JSON line
     assert p.stdout.rstrip().splitlines()[-1] == lines[0]   # ... and it is the last thing printed
     return json.loads(lines[0])
