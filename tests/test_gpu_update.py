@@ -161,7 +161,7 @@ def test_updates_track_oracle_over_a_cycle(batch, k, engine="", monkeypatch=None
         res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
         # each update is within 1e-5 of the oracle when both start from the same state (golden tests above); over 40
         # chained updates the two fp32 trajectories separate, by an amount that depends on the (batch, engine) pair and not
-        # on the engine: tools/ubench/drift_check.py over batches 512..4096 x three engines reads 1.5e-7 .. 1.4e-4 (e.g. the
+        # on the engine: tests/drift_check.py over batches 512..4096 x three engines reads 1.5e-7 .. 1.4e-4 (e.g. the
         # 16-row engine 6.6e-5 at 2560 where the 32-row engine has 2.3e-7, and the reverse at 2048) -- Adam's first steps
         # divide by sqrt(v) ~ |g|, so a last-bit difference in a near-zero gradient moves that weight by a full lr.
         tol = 3e-4
