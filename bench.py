@@ -555,7 +555,7 @@ def main():
             "whole_update_frac": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
             "engine": eng,
             "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup (4-row slabs on "
-                    "v_mfma_f32_4x4x1 up to batch 448, 8-row up to 1024, 16-row up to 2048; 32-row slabs on v_mfma_f32_32x32x2 "
+                    "v_mfma_f32_4x4x1 up to batch 512, 8-row up to 1024, 16-row up to 2048; 32-row slabs on v_mfma_f32_32x32x2 "
                     "beyond).  At batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at "
                     "~2.4 us against 2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight "
                     "stream, not by the matrix pipes.  At batch 4096 every CU streams the weights at the ~30 GB/s per CU the L2s "

@@ -1787,14 +1787,13 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->slab8 = a->slab && (e ? (strcmp(e, "slab16") != 0 && strcmp(e, "slab32") != 0) : thin_fits);
         a->slab32 = a->slab && !a->slab8 && (e ? strcmp(e, "slab32") == 0 : true);
         // Thin slabs buy latency at small batches (more CUs busy, less matrix work per streamed weight block) and cost
-        // L2 weight traffic per row: measured (4 vs 8 rows, us/update) 48.4 vs 52.4 at batch 256, 50.0 vs 54.4 at 384,
-        // 62.3 vs 55.5 at 512, 81.9 vs 60.5 at 768 (tools/ubench/sweep_rows.sh): 4 rows while 2 * B / 4 chains fit the
-        // 256 CUs with room for the spare workgroups.
-        // 8 vs 16 rows: 60.6 vs 87.4 at 768, 89.3 vs 91.1 at 1024, 111.0 vs 99.6 at 1536 (16-row slabs are MFMA-bound).
-        // The kernel's LDS footprint allows one workgroup per CU, so a launch with more workgroups than CUs runs in two
-        // waves: 8 rows while the 2 * B / 8 chains fit (98.3 vs 90.9 at 1280, where they no longer do).
+        // L2 weight traffic per row.  The kernel's LDS footprint allows one workgroup per CU, so a launch with more chain
+        // workgroups than CUs runs in two rounds: the rule is "the thinnest slab whose 2 * B / rows chains fit the CUs".
+        // Measured, us/update (tools/ubench/rows_sweep2.sh, sweep_rows.sh): 4 vs 8 rows 41.4 vs 45 at batch 256, 46.8 vs 48.6
+        // at 448, 47.5 vs 49.6 at 480, 48.4 vs 49.9 at 512 (256 chains: the look-ahead then rides in the weight-gradient
+        // launch), 73.4 vs 52.0 at 544 (two rounds); 8 vs 16 rows 59.1 vs 81.4 at 1024, 98.3 vs 90.9 at 1280.
         const int cus = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
-        a->s8_rows = (a->B <= 448) ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
+        a->s8_rows = 2 * (a->Mp / 4) <= cus ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;

@@ -653,7 +653,7 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
     assert np.allclose(agent.actor_network(x), want, rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 8, "gemm_lds 32x32")),
+@pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 4, "gemm_lds 32x32")), (513, ("slab8", 8, "gemm_lds 32x32")),
                                         (2048, ("slab8", 16, "gemm_lds 32x32")), (2049, ("slab32", 32, "dw64 split 6")),
                                         (4096, ("slab32", 32, "dw64 split 6"))])
 def test_default_engine_table(batch, want):
