@@ -1249,10 +1249,10 @@ static int dw64_args(hp_agent *a, const Launch &L, Dw64Args &X) {
         }
     }
     // allocated by hp_agent_create (this runs under stream capture)
-    HP_REQUIRE(a->dw_part.bytes >= (size_t)tiles * X.S * DW_PART * sizeof(float) && a->dw_ticket.bytes >= sizeof(unsigned) * (size_t)tiles,
+    HP_REQUIRE(a->dw_part.bytes >= (size_t)tiles * X.S * DW_PART * sizeof(float) && a->dw_ticket.bytes >= sizeof(unsigned long long) * (size_t)tiles,
                HP_ERR_INVALID, "dw64: exchange buffers too small");
     X.part = a->dw_part.as<float>();
-    X.ticket = a->dw_ticket.as<unsigned>();
+    X.ticket = a->dw_ticket.as<unsigned long long>();
     return HP_OK;
 }
 
@@ -1827,8 +1827,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         Launch L = build_dw_group(a, a->XA, a->XP);
         size_t tiles = 0;
         for (int i = 0; i < L.g.n; ++i) tiles += (size_t)((L.g.p[i].M + 63) / 64) * ((L.g.p[i].N + 63) / 64);
-        if (a->dw_part.ensure(tiles * a->dw_S * DW_PART * sizeof(float)) != HP_OK || a->dw_ticket.ensure(tiles * sizeof(unsigned)) != HP_OK ||
-            hipMemsetAsync(a->dw_ticket.p, 0, tiles * sizeof(unsigned), a->ctx->stream) != hipSuccess)
+        if (a->dw_part.ensure(tiles * a->dw_S * DW_PART * sizeof(float)) != HP_OK || a->dw_ticket.ensure(tiles * sizeof(unsigned long long)) != HP_OK ||
+            hipMemsetAsync(a->dw_ticket.p, 0, tiles * sizeof(unsigned long long), a->ctx->stream) != hipSuccess)
             st = HP_ERR_HIP;
     }
     if (st == HP_OK && a->slab8) {   // fused single-launch update (slab8.h FuseArgs)

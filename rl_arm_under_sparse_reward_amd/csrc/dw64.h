@@ -41,7 +41,8 @@ struct Dw64Args {
     int tile0[MAX_PROBS];   // first 64 x 64 tile of each problem
     int tiles_n[MAX_PROBS]; // tiles along the columns
     float *part;            // exchange buffer: DW_PART floats per (tile, slice)
-    unsigned *ticket;       // one arrival counter per tile, monotonic over the life of the agent
+    unsigned long long *ticket;   // one arrival counter per tile, monotonic over the life of the agent (64-bit: a 32-bit
+                            // count would wrap after 2^32 / S launches -- a day of training -- and S = 6 does not divide 2^32)
 };
 
 #pragma clang diagnostic push
@@ -220,8 +221,8 @@ __device__ __forceinline__ void dw64_tile(const GemmGroup &grp, const AdamFuse *
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have completed
         __syncthreads();
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(X.ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = ((old + 1u) % (unsigned)X.S == 0u) ? 1 : 0;
+            const unsigned long long old = __hip_atomic_fetch_add(X.ticket + tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = ((old + 1ull) % (unsigned long long)X.S == 0ull) ? 1 : 0;
         }
         __syncthreads();
         DW_STAMP(3);
