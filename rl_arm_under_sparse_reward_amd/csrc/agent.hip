@@ -30,6 +30,7 @@
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------- structures
 struct NetLayout {     // offsets in floats inside one net's arena segment
@@ -59,7 +60,7 @@ struct GemmProb {
 #define MAX_PROBS 8
 struct GemmGroup {
     int n;
-    int pipe;   // ring of reduction chunks for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: off, for A/B)
+    int pipe;   // per-wave LDS-DMA rings for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: workgroup-staged chunks, for A/B)
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
     int pad_;
     GemmProb p[MAX_PROBS];

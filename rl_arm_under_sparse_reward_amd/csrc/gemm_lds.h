@@ -15,6 +15,9 @@
 //   * operand with a strided reduction index ("kmajor": W in dX, dY and X in dW)
 //       LDS image [KC][36] floats; lane (i, q) reads lds[16S + 4q + c][i], c = 0..3: lanes i are
 //       consecutive banks and the q groups are 4 rows = 144 floats = 16 banks apart.
+// Reductions longer than 256 with both operands k-major (weight gradients of minibatches > 256) do not stage chunks for the
+// workgroup at all: every wave brings its own 8-row blocks in through a private LDS-DMA ring and accumulates the whole tile
+// on v_mfma_f32_32x32x2 (gemm_tile, ring path).
 // 8 wavefronts split the super-steps of a chunk (short dependent MFMA chains), partial tiles are
 // combined through LDS in a fixed order, bias / ReLU / tanh / ReLU-mask run in the epilogue, whose
 // operands are prefetched before the products (every kernel starts cache-cold).
@@ -102,6 +105,15 @@ __device__ __forceinline__ void gl_stage_kmajor_async(float *lds, const float *b
                          : "memory", "m0");
     }
 }
+// one LDS-DMA wave instruction (64 lanes x 16 B -> 1 KB at dst), issued from assembly for the same reason
+template <int AUX = 0>
+__device__ __forceinline__ void gl_dma(float *dst, const float *src) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
+    if constexpr (AUX == 16)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(src) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 
 // products of one staged chunk: wave w takes the 16-row blocks w, w + 8, ... of the chunk
@@ -184,29 +196,49 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     float as0 = 0.f, as1 = 0.f;
     const float *Abase = p.A + (long long)m0 * p.a_si;
     const float *Bbase = p.B + (long long)n0 * p.b_sj;
+    bool ring_path = false;
+    f32x16 cr;
+    float asr = 0.f;
     if (grp.pipe && !a_rowk && !b_rowk && p.K > GL_KC) {
-        // Weight gradients of a large minibatch (reduction = batch rows > 256): 128-row half chunks, double buffered --
-        // the LDS-DMA of chunk c+1 is in flight while chunk c feeds the MFMAs, one barrier per chunk instead of
-        // stage -> barrier -> products -> barrier.  Wave w still owns the 16-row blocks w, w+8, w+16, ... of the
-        // reduction in increasing order: bit-identical to the single-buffer loop.  (A ring of four 64-row stages with
-        // three chunks in flight measured the same: beyond 256 rows the kernel moves ~6.5 TB/s out of the L2s either
-        // way, 74.0 vs 72.8 us/update at batch 1024.)
-        constexpr int KH = GL_KC / 2, IMG = KH * 32;   // 4 images of 16 KB in the 72 KB
-        gl_stage_kmajor_async<AUX>(lds, Abase, p.a_sk, vm, KH);
-        gl_stage_kmajor_async<AUX>(lds + IMG, Bbase, p.b_sk, vn, KH);
-        int c = 0;
-        for (int k0 = 0; k0 < p.K; k0 += KH, ++c) {
-            const int kc = (p.K - k0) < KH ? (p.K - k0) : KH;
-            const int k1 = k0 + KH, kn = (p.K - k1) < KH ? (p.K - k1) : KH;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();   // chunk c has landed (every wave's transfers); chunk c-1's buffer is free again
-            const float *cur = lds + (c & 1) * 2 * IMG;
-            float *nxt = lds + ((c + 1) & 1) * 2 * IMG;
-            if (kn > 0) {
-                gl_stage_kmajor_async<AUX>(nxt, Abase + (long long)k1 * p.a_sk, p.a_sk, vm, kn);
-                gl_stage_kmajor_async<AUX>(nxt + IMG, Bbase + (long long)k1 * p.b_sk, p.b_sk, vn, kn);
+        // Weight gradients of a large minibatch (reduction = batch rows > 256).  Every wave owns blocks of 8 batch rows (block
+        // i of wave w: rows 64 i + 8 w .. + 7), brings them in through its OWN ring of 4 blocks (A rows | B rows, 2 KB, one
+        // LDS-DMA instruction per operand) and accumulates the whole 32 x 32 tile on v_mfma_f32_32x32x2: no barrier in the
+        // loop, 3 blocks in flight per wave.  The version before (128-row chunks staged by the workgroup, double buffered, one
+        // barrier per chunk) waited 1.4-1.75 us per chunk for its transfer: 11-14 us for the 1024 rows of batch 1024.
+        ring_path = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cr[r] = 0.f;
+        float *ring = lds + wave * (4 * 512);
+        const int h = lane >> 5, l = lane & 31;
+        const int rsub = lane >> 3, chunk = lane & 7;
+        const int gchA = chunk < (vm >> 2) ? chunk : (vm >> 2) - 1, gchB = chunk < (vn >> 2) ? chunk : (vn >> 2) - 1;
+        const float *srcA = Abase + (long long)(8 * wave + rsub) * p.a_sk + 4 * gchA;
+        const float *srcB = Bbase + (long long)(8 * wave + rsub) * p.b_sk + 4 * gchB;
+        const long long stepA = 64LL * p.a_sk, stepB = 64LL * p.b_sk;
+        const int nblk = (p.K - 8 * wave + 63) >> 6;   // K is a multiple of 8
+        for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) {
+            gl_dma<AUX>(ring + (i2 & 3) * 512, srcA + i2 * stepA);
+            gl_dma<AUX>(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
+        }
+        for (int i2 = 0; i2 < nblk; ++i2) {
+            const int ahead = i2 + 3;
+            if (ahead < nblk) {   // into the slot of block i2 - 1, whose operands the MFMAs of the previous turn have consumed
+                gl_dma<AUX>(ring + (ahead & 3) * 512, srcA + ahead * stepA);
+                gl_dma<AUX>(ring + (ahead & 3) * 512 + 256, srcB + ahead * stepB);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                const int rem = nblk - 1 - i2;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            gl_products(cur, cur + IMG, false, false, kc, wave, i, q, c00, c01, c10, c11, as0, as1);
+            const float *blk = ring + (i2 & 3) * 512 + h * 32 + l;
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const float av = blk[kp * 64], bv = blk[256 + kp * 64];
+                cr = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, cr, 0, 0, 0);
+                asr += av;
+            }
         }
         GL_STAMP(1);
     } else
@@ -222,6 +254,16 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
     float *my = lds + wave * (32 * 33);
+    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0;
+    if (ring_path) {   // 32 x 32 accumulator layout: register r -> row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
+        const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + l] = cr[r];
+        if (want_bias_grad) {
+            asr += __shfl_xor(asr, 32);
+            if (h == 0) bsum[wave][l] = asr;
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * q + r;
@@ -230,8 +272,8 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         my[(16 + row) * 33 + i] = c10[r];
         my[(16 + row) * 33 + 16 + i] = c11[r];
     }
-    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0;
-    if (want_bias_grad) {
+    }
+    if (want_bias_grad && !ring_path) {
         as0 += __shfl_xor(as0, 16);
         as0 += __shfl_xor(as0, 32);
         as1 += __shfl_xor(as1, 16);

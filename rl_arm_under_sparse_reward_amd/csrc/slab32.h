@@ -33,7 +33,6 @@
 #define S32_RING 8     // x 1 KiB per wave; must divide the 32 blocks of a layer (the ring base is 0 at every layer start)
 #define S32_RPW (S32_ROWS / S32_WAVES)   // rows per wavefront in the one-wavefront-per-row stages
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int s32_mask_t;   // ReLU mask of one column: bit r = row r of the slab
 
 __host__ __device__ __forceinline__ int frag32_fwd_index(int n, int k, int K) {

@@ -12,10 +12,12 @@ import re
 # same body as the test, but report instead of assert
 body = src[src.index("def test_updates_track_oracle_over_a_cycle"):src.index("@pytest.mark.parametrize(\"batch\", [64, 449, 1024, 4096])")]
 body = body.replace("def test_updates_track_oracle_over_a_cycle(batch, k, engine=\"\", monkeypatch=None):", "def run(batch, k, engine=\"\", monkeypatch=None):")
-body = re.sub(r"        assert abs\(got\[i, 0\].*\n", "        worst[0] = max(worst[0], abs(got[i, 0] - res['actor_loss']) / max(abs(res['actor_loss']), 1e-2))\n", body)
+body = re.sub(r"        assert abs\(got\[i, 0\].*\n", "        worst[0] = max(worst[0], abs(got[i, 0] - res['actor_loss']) / max(abs(res['actor_loss']), 1e-2)); trace.append(float(abs(got[i, 0] - res['actor_loss']) / max(abs(res['actor_loss']), 1e-2)))\n", body)
 body = re.sub(r"        assert abs\(got\[i, 1\].*\n", "        worst[1] = max(worst[1], abs(got[i, 1] - res['critic_loss']) / max(abs(res['critic_loss']), 1e-2))\n", body)
 worst = [0.0, 0.0]
-ns = dict(T.__dict__); ns["worst"] = worst
+trace = []
+ns = dict(T.__dict__); ns["worst"] = worst; ns["trace"] = trace
 exec(body, ns)
-ns["run"](batch, 4)
+ns["run"](batch, int(os.environ.get("REPLAY_K", "4")))
+if os.environ.get("TRACE"): print(" ".join(f"{v:.1e}" for v in trace))
 print("batch", batch, os.environ.get("RLARM_DW64"), os.environ.get("RLARM_DW_SPLIT"), os.environ.get("RLARM_ENGINE"), "worst rel dev actor/critic", worst)

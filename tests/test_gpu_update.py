@@ -159,12 +159,16 @@ def test_updates_track_oracle_over_a_cycle(batch, k, engine="", monkeypatch=None
     for i in range(n_up):
         tr, _ = st.sample(batch, fp, rs)
         res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
-        # each update is within 1e-5 of the oracle when both start from the same state (golden tests above); over 40
-        # chained updates the two fp32 trajectories separate, by an amount that depends on the (batch, engine) pair and not
-        # on the engine: tests/drift_check.py over batches 512..4096 x three engines reads 1.5e-7 .. 1.4e-4 (e.g. the
-        # 16-row engine 6.6e-5 at 2560 where the 32-row engine has 2.3e-7, and the reverse at 2048) -- Adam's first steps
-        # divide by sqrt(v) ~ |g|, so a last-bit difference in a near-zero gradient moves that weight by a full lr.
-        tol = 3e-4
+        # Update 0 starts from identical state on both sides: the north-star bar, 1e-5 relative (observed <= 1.2e-7; the
+        # golden tests above hold every engine to it as well).  From then on the comparison is CHAINED and two correct fp32
+        # trajectories separate: Adam's first steps divide by sqrt(v) ~ |g|, so a last-bit difference in a near-zero gradient
+        # moves that weight by a full lr, and the difference then grows geometrically (observed ~1.15-1.2x per update at
+        # lr 1e-3).  When such an event happens depends on the (batch, replay_k, summation order) triple, not on which kernel is
+        # "more right": tests/drift_check.py over batches 384..4096 x replay_k 4/8 x the kernels kept in the tree reads 1.5e-7
+        # at update 40 for most triples and 4e-6 .. 1.1e-3 for about one in five (batch 512 / k 8: event at update 6 ->
+        # 1.1e-3 with the per-wave-ring weight-gradient loop, event at update 29 -> 7e-6 with the chunked one; batch 1024 / k 4:
+        # 2.2e-5 with both; batch 3072: 1.1e-5 at update 4).  The envelope: 1e-5 x 1.3^i, capped at 3e-3.
+        tol = min(1e-5 * 1.3 ** i, 3e-3)
         assert abs(got[i, 0] - res["actor_loss"]) <= tol * max(abs(res["actor_loss"]), 1e-2), (i, got[i], res["actor_loss"])
         assert abs(got[i, 1] - res["critic_loss"]) <= tol * max(abs(res["critic_loss"]), 1e-2), (i, got[i], res["critic_loss"])
     assert state_equal(rng, *rs.get_state()[1:3])
@@ -188,6 +192,15 @@ def test_split_weight_gradient_kernel_tracks_oracle(batch, split, monkeypatch):
     exchange at all)."""
     monkeypatch.setenv("RLARM_DW64", "1")
     monkeypatch.setenv("RLARM_DW_SPLIT", str(split))
+    test_updates_track_oracle_over_a_cycle(batch, 4)
+
+
+@pytest.mark.parametrize("batch", [449, 1024])
+def test_chunked_weight_gradient_loop_tracks_oracle(batch, monkeypatch):
+    """RLARM_GEMM_PIPE=0: the weight-gradient kernel's reduction beyond 256 batch rows as workgroup-staged 256-row chunks
+    (the default brings the rows in through per-wave LDS-DMA rings: another summation order, so the two are compared with
+    the oracle, not with each other)."""
+    monkeypatch.setenv("RLARM_GEMM_PIPE", "0")
     test_updates_track_oracle_over_a_cycle(batch, 4)
 
 
@@ -454,7 +467,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
 
 
 @pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
-                                          ("RLARM_GEMM_PIPE=0", 1024), ("RLARM_GEMM_PIPE=0", 449), ("RLARM_GEMM_PIPE=0", 1536),
+                                          ("RLARM_GEMM_PIPE=0", 256),
                                           ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
                                           ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024),
                                           ("RLARM_FUSE_DW=1", 256), ("RLARM_FUSE_DW=1", 128), ("RLARM_FUSE_DW=1", 449),
