@@ -28,6 +28,9 @@
 #define GL_KC 256
 #define GL_ROWK_LD (GL_KC + 4)
 #define GL_KMAJ_LD 36
+#ifndef GL_RING_MIN_K
+#define GL_RING_MIN_K 64   // k-major x k-major reductions of at least this length take the per-wave ring path (gemm_tile)
+#endif
 #define GL_OPERAND_FLOATS (GL_KC * GL_KMAJ_LD)  // 9216 floats = larger of the two images (rowK: 32*260 = 8320)
 
 #ifdef SLAB_TIMELINE   // debug build: first and last workgroup stamp the 100 MHz wall clock at stage boundaries
@@ -199,7 +202,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     bool ring_path = false;
     f32x16 cr;
     float asr = 0.f;
-    if (grp.pipe && !a_rowk && !b_rowk && p.K > GL_KC) {
+    if (grp.pipe && !a_rowk && !b_rowk && p.K >= GL_RING_MIN_K) {
         // Weight gradients of a large minibatch (reduction = batch rows > 256).  Every wave owns blocks of 8 batch rows (block
         // i of wave w: rows 64 i + 8 w .. + 7), brings them in through its OWN ring of 4 blocks (A rows | B rows, 2 KB, one
         // LDS-DMA instruction per operand) and accumulates the whole 32 x 32 tile on v_mfma_f32_32x32x2: no barrier in the

@@ -195,9 +195,9 @@ def test_split_weight_gradient_kernel_tracks_oracle(batch, split, monkeypatch):
     test_updates_track_oracle_over_a_cycle(batch, 4)
 
 
-@pytest.mark.parametrize("batch", [449, 1024])
+@pytest.mark.parametrize("batch", [256, 449, 1024])
 def test_chunked_weight_gradient_loop_tracks_oracle(batch, monkeypatch):
-    """RLARM_GEMM_PIPE=0: the weight-gradient kernel's reduction beyond 256 batch rows as workgroup-staged 256-row chunks
+    """RLARM_GEMM_PIPE=0: the weight-gradient kernel's reduction over the batch rows as workgroup-staged 256-row chunks
     (the default brings the rows in through per-wave LDS-DMA rings: another summation order, so the two are compared with
     the oracle, not with each other)."""
     monkeypatch.setenv("RLARM_GEMM_PIPE", "0")
@@ -467,7 +467,6 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
 
 
 @pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
-                                          ("RLARM_GEMM_PIPE=0", 256),
                                           ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
                                           ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024),
                                           ("RLARM_FUSE_DW=1", 256), ("RLARM_FUSE_DW=1", 128), ("RLARM_FUSE_DW=1", 449),
@@ -663,7 +662,10 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
     assert np.array_equal(bits(agent.o_norm.mean), bits(on.mean)) and np.array_equal(bits(agent.g_norm.std), bits(gn.std))
     x = np.random.RandomState(1).normal(size=(9, obs_dim + goal_dim)).astype(np.float32)
     want = oupd.actor_forward({k: v.detach() for k, v in learner.actor.items()}, torch.from_numpy(x), 0.5).numpy()
-    assert np.allclose(agent.actor_network(x), want, rtol=1e-4, atol=2e-5)
+    # six chained Adam steps: a weight whose gradient is at rounding level moves by +-lr either way, so the policies of two
+    # correct fp32 implementations differ by a few 1e-5 on outputs of ~3e-2 (tests/shape_probe.py: 1.5e-8 with one
+    # summation order of the weight-gradient kernel, 2.7e-5 with another, losses within 1e-4 in both)
+    assert np.allclose(agent.actor_network(x), want, rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 4, "gemm_lds 32x32")), (513, ("slab8", 8, "gemm_lds 32x32")),
