@@ -48,11 +48,18 @@ def test_driver_invocation_prints_the_contract_line():
     assert d["cycle_boundaries_in_timed_region"]["polyak"] == 0       # 20 steps never reach a cycle boundary: said so
 
 
-def test_plain_shell_multi_rank_launch():
-    d = _run("--gpus", "2", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile")
+@pytest.mark.parametrize("batch", [256, 3072])     # 3072: the 32-row engine + split weight-gradient tiles under the exchange
+def test_plain_shell_multi_rank_launch(batch):
+    d = _run("--gpus", "2", "--batch", str(batch), "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile")
     assert d["n_gpus"] == 2 and d["steps"] == 80
     assert d["config"]["exchange"] in ("peer-memory", "rccl", "torch.distributed")
-    assert abs(d["value"] - 2 * 256 * 80 / (d["ms_per_step"] * 80e-3)) <= 1e-3 * d["value"]   # whole-job aggregate
+    assert abs(d["value"] - 2 * batch * 80 / (d["ms_per_step"] * 80e-3)) <= 1e-3 * d["value"]   # whole-job aggregate
+    if batch == 3072:     # both forms of the peer exchange end in the same bits
+        e = _run("--gpus", "2", "--batch", str(batch), "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile",
+                 RLARM_PEER_PHASES="2")
+        if d["config"]["exchange"] == "peer-memory":
+            assert e["config"]["peer_exchange_form"].startswith("two-phase")
+            assert e["config"]["final_losses"] == d["config"]["final_losses"]
 
 
 def test_multi_rank_launch_survives_a_failing_exchange_on_one_rank():
