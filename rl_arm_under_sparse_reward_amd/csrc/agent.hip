@@ -417,7 +417,7 @@ struct hp_agent {
     long long fused_launches = 0;
     // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
     bool dw64 = false;                   // RLARM_DW64: default on with the slab32 engine
-    int dw_S = 6;                        // RLARM_DW_SPLIT
+    int dw_S = 3;                        // RLARM_DW_SPLIT
     DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
@@ -1241,14 +1241,6 @@ static int dw64_args(hp_agent *a, const Launch &L, Dw64Args &X) {
     }
     X.kslice = ((K + X.S - 1) / X.S + DW_KH - 1) / DW_KH * DW_KH;
     X.n_wg = X.S * tiles;
-    X.placed = 0;
-    if (a->gemm_xcd && X.S % 2 == 0 && L.g.n == 8) {
-        X.placed = 1;
-        for (int i = 0; i < 8; ++i) {
-            const int nt = (i + 1 < 8 ? X.tile0[i + 1] : tiles) - X.tile0[i];
-            if (nt != (i < 4 ? 16 : 4)) X.placed = 0;
-        }
-    }
     // allocated by hp_agent_create (this runs under stream capture)
     HP_REQUIRE(a->dw_part.bytes >= (size_t)tiles * X.S * DW_PART * sizeof(float) && a->dw_ticket.bytes >= sizeof(unsigned long long) * (size_t)tiles,
                HP_ERR_INVALID, "dw64: exchange buffers too small");

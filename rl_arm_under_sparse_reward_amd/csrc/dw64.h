@@ -4,7 +4,9 @@
 // gives every 32 x 32 output tile to one workgroup that walks ALL the batch rows: 8 flop per operand byte, and beyond
 // ~1024 rows the launch is bound by what the L2s deliver (~6.5 TB/s measured; 58 us at batch 4096 = 41 TFLOP/s).  Here:
 //   * 64 x 64 output tiles on v_mfma_f32_32x32x2_f32: 16 flop per operand byte, half the L2 -> LDS traffic;
-//   * the batch rows of a tile are split over S workgroups (S x 80 tiles: enough workgroups for 256 CUs at two per CU);
+//   * the batch rows of a tile are split over S workgroups (80 tiles x S = 3: 240 workgroups, one per CU and one round -- the
+//     product loop is bound by what a CU can stream, so more workgroups per CU buy nothing and every extra slice adds
+//     a partial tile to exchange: us/update at batch 4096 for S = 2 / 3 / 4 / 5 / 6 / 8: 136.4 / 128.1 / 141.1 / 134.6 / 132.1 / 145.9);
 //     every workgroup writes its partial tile write-through, takes a ticket, and the LAST one to arrive sums the S
 //     partials in slice order and runs the epilogue (optimizer step or gradient store).  Nobody waits for anybody, the
 //     sum order is fixed: deterministic.  Hand-off as in slab8.h (cdna_hip_programming.md Guideline 16 form R1):
@@ -37,7 +39,6 @@ struct Dw64Args {
     int S;                  // workgroups (batch-row slices) per tile
     int kslice;             // batch rows per slice (multiple of DW_KH)
     int n_wg;               // tile workgroups of the launch = S * tiles
-    int placed;             // problems 0..3 have 16 tiles, 4..7 have 4, S is even: (problem, slice) groups placed on XCDs
     int tile0[MAX_PROBS];   // first 64 x 64 tile of each problem
     int tiles_n[MAX_PROBS]; // tiles along the columns
     float *part;            // exchange buffer: DW_PART floats per (tile, slice)
@@ -60,19 +61,8 @@ template <bool ADAM>
 __device__ __forceinline__ void dw64_tile(const GemmGroup &grp, const AdamFuse *F, const Dw64Args &X, int bx, float *lds, int *flag) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int pi, s, t;
-    if (X.placed) {
-        // Workgroups are dealt round-robin to the 8 XCDs (own L2 each).  A group = the tiles of one (problem, slice): its 16
-        // (4 for the narrow problems) workgroups share every operand row, so a whole group goes to ONE XCD: XCD x = bx & 7
-        // takes groups x, x + 8, ... -- each operand byte crosses the fabric once.
-        const int nbig = 4 * X.S * 16;
-        const bool big = bx < nbig;
-        const int b = big ? bx : bx - nbig;
-        const int x = b & 7, slot = b >> 3;
-        const int group = x + 8 * (big ? slot >> 4 : slot >> 2);
-        t = big ? slot & 15 : slot & 3;
-        pi = (big ? 0 : 4) + group / X.S;
-        s = group - (group / X.S) * X.S;
-    } else {   // problem-major, slice-major within a problem
+    {   // problem-major, slice-major within a problem.  (Placing all tiles of a (problem, slice) group on one XCD so that every
+        // operand byte crosses the fabric once measured the same: 132.06 vs 132.16 us/update at batch 4096, split 6.)
         pi = 0;
 #pragma unroll
         for (int i = 1; i < MAX_PROBS; ++i)

@@ -305,7 +305,7 @@ class ddpg_agent:
 
     def engine(self):
         """Kernels this agent's updates run (hp_agent_engine): e.g. {'engine': 'slab8', 'slab_rows': 4, 'weight_grad':
-        'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 6'} at 4096."""
+        'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 3'} at 4096."""
         e, r, d = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.hp_agent_engine(self.h, C.byref(e), C.byref(r), C.byref(d)))
         return {"engine": {0: "layers", 8: "slab8", 16: "slab16", 32: "slab32"}[e.value], "slab_rows": r.value,

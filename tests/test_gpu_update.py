@@ -473,9 +473,9 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           ("RLARM_FUSE_DW=1", 512), ("RLARM_FUSE_DW=1", 1024), ("RLARM_FUSE_DW=1", 1536),
                                           ("RLARM_PLAN_SIDE=1", 256), ("RLARM_PLAN_SIDE=0", 1024), ("RLARM_PLAN_SIDE=0", 2048),
                                           ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256),
-                                          # 32-row engine + split weight-gradient tiles: XCD placement of the (problem, slice)
-                                          # groups off, look-ahead on a second stream / in front of every launch
-                                          ("RLARM_GEMM_XCD=0", 3072), ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560)])
+                                          # 32-row engine + split weight-gradient tiles: look-ahead on a second stream / in front of
+                                          # every launch
+                                          ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, a ring of reduction chunks in the weight-gradient GEMM beyond 256 rows, its big problems placed on XCD
@@ -669,8 +669,8 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
 
 
 @pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 4, "gemm_lds 32x32")), (513, ("slab8", 8, "gemm_lds 32x32")),
-                                        (2048, ("slab8", 16, "gemm_lds 32x32")), (2049, ("slab32", 32, "dw64 split 6")),
-                                        (4096, ("slab32", 32, "dw64 split 6"))])
+                                        (2048, ("slab8", 16, "gemm_lds 32x32")), (2049, ("slab32", 32, "dw64 split 3")),
+                                        (4096, ("slab32", 32, "dw64 split 3"))])
 def test_default_engine_table(batch, want):
     """hp_agent_engine: the kernels picked from the batch size alone (measured table in
     profiles/r02_large_batch_engines.txt)."""
