@@ -416,7 +416,7 @@ struct hp_agent {
     bool fuse_dw_ok = false;             // RLARM_FUSE_DW=1: single-launch updates (default: chain kernel + tile kernel)
     long long fused_launches = 0;
     // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
-    bool dw64 = false;                   // RLARM_DW64: default on with the slab32 engine
+    bool dw64 = false;                   // RLARM_DW64: default from batch 1536
     int dw_S = 3;                        // RLARM_DW_SPLIT
     DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
@@ -1805,7 +1805,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->fuse_dw_ok = tri("RLARM_FUSE_DW") == 1;
         if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
         // weight gradients: 64 x 64 tiles with split batch rows (dw64.h) where the 32 x 32 tiles are L2-bound
-        a->dw64 = a->slab && (tri("RLARM_DW64") >= 0 ? tri("RLARM_DW64") == 1 : a->slab32);
+        // (us/update, 32 x 32 tiles vs dw64: 56.6 / 58.9 at batch 1024, 85.8 / 85.1 at 1536, 93.9 / 92.2 at 2048, 146 / 128 at 4096)
+        a->dw64 = a->slab && (tri("RLARM_DW64") >= 0 ? tri("RLARM_DW64") == 1 : a->Mp >= 1536);
         if (const char *ds = getenv("RLARM_DW_SPLIT")) a->dw_S = atoi(ds) > 0 && atoi(ds) <= 16 ? atoi(ds) : a->dw_S;
         const char *ah = getenv("RLARM_AHEAD");
         a->gather_ahead = !(ah && ah[0] == '0');

@@ -470,7 +470,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
                                           ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024),
                                           ("RLARM_FUSE_DW=1", 256), ("RLARM_FUSE_DW=1", 128), ("RLARM_FUSE_DW=1", 449),
-                                          ("RLARM_FUSE_DW=1", 512), ("RLARM_FUSE_DW=1", 1024), ("RLARM_FUSE_DW=1", 1536),
+                                          ("RLARM_FUSE_DW=1", 512), ("RLARM_FUSE_DW=1", 1024), ("RLARM_FUSE_DW=1", 1280),
                                           ("RLARM_PLAN_SIDE=1", 256), ("RLARM_PLAN_SIDE=0", 1024), ("RLARM_PLAN_SIDE=0", 2048),
                                           ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256),
                                           # 32-row engine + split weight-gradient tiles: look-ahead on a second stream / in front of
@@ -669,7 +669,8 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
 
 
 @pytest.mark.parametrize("batch,want", [(256, ("slab8", 4, "gemm_lds 32x32")), (512, ("slab8", 4, "gemm_lds 32x32")), (513, ("slab8", 8, "gemm_lds 32x32")),
-                                        (2048, ("slab8", 16, "gemm_lds 32x32")), (2049, ("slab32", 32, "dw64 split 3")),
+                                        (1504, ("slab8", 16, "gemm_lds 32x32")), (1536, ("slab8", 16, "dw64 split 3")), (2048, ("slab8", 16, "dw64 split 3")),
+                                        (2049, ("slab32", 32, "dw64 split 3")),
                                         (4096, ("slab32", 32, "dw64 split 3"))])
 def test_default_engine_table(batch, want):
     """hp_agent_engine: the kernels picked from the batch size alone (measured table in
