@@ -24,11 +24,24 @@
 #define MT_M 397
 #define MT_THREADS 512     // one candidate word per thread and chunk: fewer, larger chunks = fewer barriers per drawn index
 #define MT_WAVES (MT_THREADS / 64)
-#define MT_IBUF (MT_WAVES + 1)   // LDS ints: wave totals [0 .. MT_WAVES), last-accept position [MT_WAVES]
+#define MT_IBUF (2 * MT_WAVES + 1)   // LDS ints: wave totals, two sets used alternately [0 .. 2 MT_WAVES), last-accept position [2 MT_WAVES]
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)),
+// and the draws below store their results to global memory between barriers: every barrier then waited a memory round
+// trip for stores nobody in this kernel reads back -- ~190 barriers per 4096-sample HER batch, 37 us for a draw whose
+// twists and compactions are ~10 us of work.  The one place where a thread reads what another thread stored (p[i].t in
+// mt_her_plan) keeps the full barrier.
+__device__ __forceinline__ void mt_sync() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 struct MtWg {
     uint32_t (*blk)[MT_N];  // LDS ring [4][624]
-    int *ibuf;              // LDS ints [MT_IBUF]: wave totals, last-accept position
+    int *ibuf;              // LDS ints [MT_IBUF]: wave totals (two sets), last-accept position
+    int flip;               // which set of wave totals the next mt_prefix uses
     long long cursor;       // absolute stream index of the next unconsumed word (block 0 = loaded key)
     int nblk;               // blocks generated so far (ring holds blocks nblk-4 .. nblk-1)
 };
@@ -54,11 +67,11 @@ __device__ __forceinline__ void mt_generate_block(MtWg &g) {
     uint32_t *dst = g.blk[g.nblk & 3];
     const int tid = threadIdx.x;
     if (tid < MT_N - MT_M) dst[tid] = mt_twist_one(src, dst, tid);  // k in [0,227)
-    __syncthreads();
+    mt_sync();
     if (tid < MT_N - MT_M) dst[227 + tid] = mt_twist_one(src, dst, 227 + tid);  // k in [227,454)
-    __syncthreads();
+    mt_sync();
     if (tid < MT_N - 454) dst[454 + tid] = mt_twist_one(src, dst, 454 + tid);  // k in [454,624)
-    __syncthreads();
+    mt_sync();
     g.nblk += 1;
 }
 
@@ -78,6 +91,7 @@ __device__ __forceinline__ void mt_load(MtWg &g, const MtState *st, uint32_t (*r
     for (int k = threadIdx.x; k < MT_N; k += MT_THREADS) ring[0][k] = st->key[k];
     g.cursor = st->pos;
     g.nblk = 1;
+    g.flip = 0;
     __syncthreads();
 }
 
@@ -99,22 +113,25 @@ __device__ __forceinline__ void mt_store(const MtWg &g, MtState *st) {
 }
 
 // exclusive prefix of a predicate over the MT_THREADS-thread workgroup; returns this thread's rank among the
-// accepting threads and the workgroup total.  Two barriers.
+// accepting threads and the workgroup total.  ONE barrier: consecutive calls alternate between two sets of wave totals, so
+// a fast wave writing the next call's totals cannot overtake a slow wave still reading this call's (it would have to pass
+// the next call's barrier first, which the slow wave has not reached).
 __device__ __forceinline__ int mt_prefix(MtWg &g, bool acc, int &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *tot_w = g.ibuf + g.flip * MT_WAVES;
+    g.flip ^= 1;
     unsigned long long m = __ballot(acc);
     int within = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) g.ibuf[wave] = __popcll(m);
-    __syncthreads();
+    if (lane == 0) tot_w[wave] = __popcll(m);
+    mt_sync();
     int off = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < MT_WAVES; ++w) {
-        const int c = g.ibuf[w];
+        const int c = tot_w[w];
         off += (w < wave) ? c : 0;
         tot += c;
     }
     total = tot;
-    __syncthreads();
     return off + within;
 }
 
@@ -141,11 +158,11 @@ __device__ __forceinline__ void mt_draw_bounded(MtWg &g, uint32_t rng, long long
         long long idx = produced + rank;
         if (acc && idx < count) emit(idx, v);
         if (produced + total >= count) {
-            if (acc && idx == count - 1) g.ibuf[MT_WAVES] = threadIdx.x;
-            __syncthreads();
-            g.cursor += g.ibuf[MT_WAVES] + 1;
+            if (acc && idx == count - 1) g.ibuf[2 * MT_WAVES] = threadIdx.x;
+            mt_sync();
+            g.cursor += g.ibuf[2 * MT_WAVES] + 1;
             produced = count;
-            __syncthreads();
+            mt_sync();
         } else {
             g.cursor += MT_THREADS;
             produced += total;
