@@ -327,6 +327,7 @@ def first_cycle_or_fallback(a, rank, world, force_dp, shared):
             r = Runner(a, rank, world, force_dp)
             r.run_steps(N_BATCHES)
             r.sync()
+            r.agent.check_exchange()     # a wait that timed out inside the cycle (peer.h: fatal, sticky) fails this transport
             if os.environ.get("RLARM_BENCH_FAIL_FIRST") == str(rank) and mode == order[0]:   # test hook: one rank's first
                 raise RuntimeError("injected failure (RLARM_BENCH_FAIL_FIRST)")                # transport "fails"
         except Exception as e:          # noqa: BLE001 -- any failure of this rank must reach the agreement below
@@ -410,6 +411,7 @@ def main():
     r.sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    r.agent.check_exchange()      # a timed region in which an exchange wait timed out (steps skipped) is not a measurement
     feeder_stats = None
     if r.env_feeder is not None:
         waves = r.env_waves - waves0
@@ -430,7 +432,41 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # A timed region shorter than one training cycle (the driver's --steps 20) crosses no cycle boundary: measure the
+    # boundary-inclusive rate as well, over whole cycles (store 2 episodes, normalizer refresh, 40 updates, polyak each),
+    # after the timed region so that the contract's K steps stay exactly K
+    cycle_inclusive = None
+    if boundaries["polyak"] < max(1, a.steps // N_BATCHES) or a.steps < N_BATCHES:
+        n_cyc = 25
+        r.run_steps((-r.in_cycle) % N_BATCHES)
+        r.run_steps(2 * N_BATCHES)
+        r.sync()
+        barrier(world)
+        tc = time.perf_counter()
+        r.run_steps(n_cyc * N_BATCHES)
+        r.sync()
+        barrier(world)
+        dtc = time.perf_counter() - tc
+        if world > 1:
+            t = torch.tensor([dtc], dtype=torch.float64, device="cpu" if shared else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtc = float(t.item())
+        cycle_inclusive = {"steps": n_cyc * N_BATCHES, "cycle_boundaries": n_cyc,
+                           "ms_per_step": round(1e3 * dtc / (n_cyc * N_BATCHES), 6),
+                           "value": round(world * a.batch * n_cyc * N_BATCHES / dtc, 1),
+                           "note": "same process, measured right after the timed region over whole cycles; `value` above is the "
+                                   "contract's K-step figure"}
     losses = r.agent.last_losses(1)[0]
+    # data-parallel replicas must hold the SAME networks bit for bit (same summed gradients, same Adam): every rank
+    # fingerprints its online + target parameters and rank 0 reports whether all fingerprints agree
+    replicas_identical = None
+    if world > 1:
+        import zlib
+        crc = [zlib.crc32(r.agent._get_flat(slot).tobytes()) for slot in (0, 1, 2, 3)]
+        mine = torch.tensor(crc, dtype=torch.int64, device="cpu" if shared else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        replicas_identical = all(bool(torch.equal(e, every[0])) for e in every)
     prof = None
     if rank == 0 and world == 1 and not a.no_profile:   # N=1 only: the eager profile pass would issue collectives alone
         prof = profile_kernels(r)
@@ -468,6 +504,7 @@ def main():
         "init": "untimed before the warm-up: one training cycle (cycle hipGraph capture / exchange set-up) and one rehearsal "
                 "of the warm-up + timed step pattern (partial-cycle graph captures), ending on a cycle boundary",
         "cycle_boundaries_in_timed_region": boundaries,
+        **({"cycle_inclusive_estimate": cycle_inclusive} if cycle_inclusive else {}),
         **({"host_feeder": feeder_stats} if feeder_stats else {}),
         "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
@@ -483,6 +520,9 @@ def main():
                    "peer_exchange_form": {1: "one-shot (every rank reads every peer's whole gradient vector)",
                                           2: "two-phase (reduce-scatter + all-gather over peer memory)"}.get(peer_phases),
                    "cycle_mode": cycle_mode,
+                   "peer_gate_kernels": bool(r.agent.comm.shared_device) if dp_peer else None,
+                   "replicas_bit_identical": replicas_identical,
+                   "devices_shared_by_ranks": bool(shared) if world > 1 else None,
                    "engine": r.agent.engine(),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])],
@@ -499,15 +539,29 @@ def main():
         chain_kernel = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32", "slab16": "k_fwd_slab + k_bwd_slab"}.get(eng["engine"], "k_gemm_group")
         dw_kernel = "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam"
         kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
-        pmc, pmc_file = {}, None
-        for cand in (f"r02_pmc_traffic_b{a.batch}.json",):
+        # HBM traffic needs rocprofv3 --pmc passes around the process (tools/gpu_round3.sh), so it cannot be measured from
+        # inside this run: it is read from the newest committed counter summary of this shape, which records a fingerprint of
+        # the kernel sources it was taken on -- when the sources have changed since, the figure is reported as stale
+        pmc, pmc_file, pmc_sha = {}, None, None
+        for cand in (f"r03_pmc_traffic_b{a.batch}.json", f"r02_pmc_traffic_b{a.batch}.json"):
             path = os.path.join(REPO, "profiles", cand)
             if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
                 with open(path) as fh:
-                    pmc = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
-                pmc_file = "profiles/" + cand
-        # committed rocprofv3 summary of this same configuration (tools/gpu_round2.sh): cross-check for the live numbers
-        prof_file = os.path.join(REPO, "profiles", f"r02_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+                    doc = json.load(fh)
+                pmc = {k: v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items()}
+                pmc_file, pmc_sha = "profiles/" + cand, doc.get("csrc_sha16")
+                break
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        try:
+            from pmc_summary import csrc_sha16
+            sha_now = csrc_sha16()
+        except Exception:                      # noqa: BLE001
+            sha_now = None
+        traffic_stale = (pmc_sha is None or sha_now is None or pmc_sha != sha_now) if pmc_file else None
+        # committed rocprofv3 summary of this same configuration (tools/gpu_round3.sh): cross-check for the live numbers
+        prof_file = os.path.join(REPO, "profiles", f"r03_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+        if not os.path.exists(prof_file):
+            prof_file = os.path.join(REPO, "profiles", f"r02_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
         prof_avg = {}
         if os.path.exists(prof_file):
             for line in open(prof_file):
@@ -542,7 +596,11 @@ def main():
             "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
             "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
-            "traffic_source": pmc_file, "flop_per_launch": per[dom]["flop_per_launch"],
+            "traffic_source": pmc_file, "traffic_stale": traffic_stale,
+            "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB per launch from separate rocprofv3 --pmc passes of this "
+                            "shape; traffic_stale = the kernel sources differ from the ones the counters were taken on "
+                            f"(csrc fingerprint then {pmc_sha}, now {sha_now})",
+            "flop_per_launch": per[dom]["flop_per_launch"],
             "avg_launch_us": per[dom]["avg_launch_us"],
             "duration_method": "avg_launch_us = the LARGER of (a) live_event_pair_minus_empty_us: one HIP event pair around each "
                                "eager launch of the training loop on the launch stream, minus event_pair_empty_us (what a pair with "
@@ -584,6 +642,17 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        # the port timed next to the imported reference where both can run (the build container,
+        # tools/cpu_ratio.py) -- the factor that turns "x the port" into "x the reference CPU path"
+        ratio_file = os.path.join(REPO, "profiles", "r03_cpu_port_over_reference.json")
+        if os.path.exists(ratio_file):
+            with open(ratio_file) as fh:
+                rdoc = json.load(fh)
+            out["cpu_baseline"]["port_over_reference"] = rdoc["port_over_reference"]
+            out["cpu_baseline"]["port_over_reference_source"] = (
+                "profiles/r03_cpu_port_over_reference.json (tools/cpu_ratio.py on the build container: "
+                f"{rdoc.get('host_cpu', '?')}, by threads {({k: v['port_over_reference'] for k, v in rdoc['by_threads'].items()})})")
+            out["speedup_vs_reference_cpu_estimate"] = round(out["speedup_vs_cpu_baseline"] * rdoc["port_over_reference_min"], 1)
     if world > 1 or force_dp:
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER Python's output at exit:

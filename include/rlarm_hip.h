@@ -64,6 +64,7 @@ int hp_ctx_create(int device_id, hp_ctx **out);
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
+int hp_ctx_pci_bus_id(hp_ctx *ctx, char *buf, size_t len);      /* "0000:05:00.0"; len >= 16 */
 /* diagnostic: average microseconds per dependent trivial kernel on the context's stream, measured
  * as an n-node captured hipGraph (graph != 0) or n eager launches (the launch floor in DESIGN.md) */
 int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel);
@@ -219,6 +220,9 @@ int hp_agent_get_params(hp_agent *ag, int32_t net, float *flat_host, int64_t n);
  * written) */
 int hp_agent_get_grads(hp_agent *ag, int32_t net, float *flat_host, int64_t n);  /* net = actor|critic */
 int hp_agent_get_adam(hp_agent *ag, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step);
+/* test hook: load torch.optim.Adam state (exp_avg, exp_avg_sq in the flat order of utils.py:18-27; either may be NULL) and the
+ * number of optimizer steps already taken (shared by both optimizers, ddpg_agent.py:272,277 step together) */
+int hp_agent_set_adam(hp_agent *ag, int32_t net, const float *m_host, const float *v_host, int64_t n, int64_t step);
 
 /* One ddpg_agent._update_network (:250-277) on a caller-provided, already normalised minibatch
  * (host float32: x [B,obs+goal], x_next [B,obs+goal], actions [B,act], r [B]).
@@ -301,8 +305,12 @@ int hp_agent_cycle_mode(hp_agent *ag, int32_t *mode);
  * one block of exchange memory (hipIpcGetMemHandle), maps the other ranks' blocks, and the kernel that applies Adam
  * reads the peers' gradient vectors itself and sums them in rank order (utils.py:43-48 SUM; bit-identical parameters on
  * every rank).  Bootstrap: hp_peer_create on every rank -> exchange the 64-byte handles through any side channel ->
- * hp_peer_connect(all handles, rank order).  Waits are bounded (RLARM_PEER_TIMEOUT_S, default 20 s); hp_peer_status
- * reads the sticky error word.  One node only (ranks that can map each other's device memory). */
+ * hp_peer_connect(all handles, rank order).  Waits are bounded (RLARM_PEER_TIMEOUT_S, default 20 s) and a timeout is FATAL
+ * for the exchange: the kernel whose wait gave up skips its sum / optimizer step, sets a sticky error word that makes every
+ * later exchange kernel return at once, and mirrors it into pinned host memory -- hp_agent_train_cycle /
+ * hp_agent_sample_and_update then fail with HP_ERR_STATE at their next call (no synchronisation needed), hp_peer_status
+ * reads the word explicitly.  The reference's MPI Allreduce (utils.py:47) would block forever instead; silent divergence of
+ * the replicas is the one outcome that is excluded.  One node only (ranks that can map each other's device memory). */
 int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floats, hp_peer **out, uint8_t *handle64);
 int hp_peer_connect(hp_peer *peer, const uint8_t *handles_world_x_64);
 /* normalizer._mpi_average (normalizer.py:60-64) and other small vectors (<= 1024 floats): in place, SUM or SUM / world
@@ -312,6 +320,12 @@ int hp_peer_allreduce_f32(hp_peer *peer, void *dev, int64_t n, int32_t mean);
  * exactly representable pattern: *mismatches = number of wrong elements on this rank (top bit: a wait timed out) */
 int hp_peer_selfcheck(hp_peer *peer, uint32_t *mismatches);
 int hp_peer_status(hp_peer *peer, uint32_t *error);
+/* Gate mode (every rank alike, before the first exchange): each wait of the gradient exchange runs in a ONE-WAVEFRONT kernel
+ * of its own in front of the kernel that consumes the peers' data, instead of inside that kernel's hundreds of workgroups.
+ * Needed when ranks share one physical device (rehearsals of an N-GPU job on one GPU): there a rank's progress depends on
+ * its kernels being co-resident with the other ranks' WAITING kernels, and workgroups spinning by the hundred can starve
+ * them of registers / LDS.  Costs one kernel boundary per wait; default off (RLARM_PEER_GATE=0|1 overrides). */
+int hp_peer_set_gate(hp_peer *peer, int32_t on);
 /* 1: one-shot exchange (every rank reads every peer's whole gradient vector), 2: reduce-scatter + all-gather over the same
  * peer memory (default from 4 ranks; RLARM_PEER_PHASES=1|2).  Both sum in rank order: bit-identical results. */
 int hp_peer_phases(hp_peer *p, int32_t *phases);

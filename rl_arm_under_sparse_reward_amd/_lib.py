@@ -48,6 +48,7 @@ PROTOTYPES = {
     "hp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "hp_ctx_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "hp_ctx_launch_floor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p]),
     "hp_ctx_event_pair_us": (C.c_int, [C.c_void_p, C.c_int, f64p]),
     "hp_ctx_clock_mhz": (C.c_int, [C.c_void_p, f64p]),
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "hp_agent_get_params": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
     "hp_agent_get_grads": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
     "hp_agent_get_adam": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int64, i64p]),
+    "hp_agent_set_adam": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int64, C.c_int64]),
     "hp_agent_update_minibatch": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, f32p]),
     "hp_agent_sample_and_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                              C.c_double, C.c_int32]),
@@ -124,6 +126,7 @@ PROTOTYPES = {
     "hp_peer_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "hp_peer_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "hp_peer_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "hp_peer_set_gate": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_peer_destroy": (None, [C.c_void_p]),
     "hp_agent_set_peer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_agent_cycle_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

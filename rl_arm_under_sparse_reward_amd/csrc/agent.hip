@@ -224,8 +224,7 @@ __global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFu
     const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
     const int par = (int)(epoch & 1ull);
     if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
-    peer_wait(D, D.flags_g[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_g[D.rank], epoch)) return;   // dead exchange: no step from a partial sum (peer.h)
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -252,8 +251,7 @@ __global__ __launch_bounds__(256) void k_peer_adam2(const PeerDev D, const AdamF
     const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
     const int par = (int)(epoch & 1ull);
     if (blockIdx.x == 0) peer_signal(D, D.flags_r, epoch);
-    peer_wait(D, D.flags_r[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_r[D.rank], epoch, 3u)) return;
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -268,8 +266,10 @@ static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, 
     const int n4 = n_arena / 4;
     if (p->phases == 2) {
         HP_TRY(peer_enqueue_reduce_slice(p, n4, u, mean));
+        HP_TRY(peer_enqueue_gate(p, 3, u));
         hipLaunchKernelGGL(k_peer_adam2, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u);
     } else {
+        HP_TRY(peer_enqueue_gate(p, 1, u));
         hipLaunchKernelGGL(k_peer_adam, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u, mean ? 1 : 0);
     }
     HP_CHECK_HIP(hipGetLastError());
@@ -419,6 +419,7 @@ struct hp_agent {
     bool dw64 = false;                   // RLARM_DW64: default from batch 1536
     int dw_S = 3;                        // RLARM_DW_SPLIT
     DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
+    bool keep_grads_dbg = false;   // RLARM_KEEP_GRADS=1 (parity tests): the peer optimizer kernels also write the summed gradients out
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
     bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
     DevBuf plan, norm_plan;
@@ -1345,7 +1346,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             F.fragF = rset ? a->fragF : a->fragF_b;
             F.fragD = rset ? a->fragD : a->fragD_b;
             F.scal = a->adam_tab.as<float>() + 4 * (size_t)gc->fuse_u;
-            F.keep_grads = 0;            // nobody reads the gradient vector inside a sampled update loop
+            F.keep_grads = a->keep_grads_dbg ? 1 : 0;   // nobody reads the gradient vector inside a sampled update loop (RLARM_KEEP_GRADS=1: parity tests do)
             P.fuse.on = 1;
             P.fuse.u = gc->fuse_u;
             P.fuse.n_tiles = a->dw_tiles;
@@ -1414,7 +1415,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             const unsigned grid = X.n_wg + R.n_plan + R.n_ahead;
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
-                F.keep_grads = (gc == nullptr) ? 1 : 0;
+                F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
                 hipLaunchKernelGGL(k_dw64_adam, dim3(grid), dim3(DW_THREADS), 0, s, L.g, F, R, X);
             } else {
                 hipLaunchKernelGGL(k_dw64, dim3(grid), dim3(DW_THREADS), 0, s, L.g, R, X);
@@ -1425,7 +1426,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
-                F.keep_grads = 0;
+                F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 hipLaunchKernelGGL(k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
             } else {
                 hipLaunchKernelGGL(k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
@@ -1436,7 +1437,7 @@ static int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool 
             // inside a sampled update loop nobody reads the gradient vector (hp_agent_get_grads documents this): 1.17 MB of
             // the ~6.7 MB this kernel leaves dirty in L2 for the end-of-kernel write-back
             AdamFuse F = adam_fuse(a);
-            F.keep_grads = (gc == nullptr) ? 1 : 0;
+            F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
             hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
@@ -1626,7 +1627,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             // vectors over xGMI, sums them in rank order and steps (peer.hip)
             AdamFuse F = adam_fuse(a);
             F.grads_base = a->grads;
-            F.keep_grads = 0;
+            F.keep_grads = a->keep_grads_dbg ? 1 : 0;   // RLARM_KEEP_GRADS=1: hp_agent_get_grads then returns the exchanged sum
             ProfScope ps(a, PROF_ADAM);
             HP_TRY(peer_enqueue_adam(a->peer, F, a->n_arena, u, a->grad_mean));
         } else if (with_adam) {
@@ -1800,6 +1801,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->fb_xcd = tri("RLARM_FB_XCD");
         a->fb_prefetch = tri("RLARM_FB_PREFETCH");
         a->upd_graph_ok = tri("RLARM_UPDATE_GRAPH") != 0;
+        a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
         // measured slower than two launches (48.2 vs 40.8 us/update at batch 256: the in-kernel hand-off costs ~4 us and a
         // tile ~7 us warm, profiles/r02_fused_single_launch.txt), so it is opt-in
         a->fuse_dw_ok = tri("RLARM_FUSE_DW") == 1;
@@ -1905,6 +1907,33 @@ int hp_agent_get_adam(hp_agent *a, int32_t net, float *m_host, float *v_host, in
     return HP_OK;
 }
 
+// test hook beside hp_agent_get_adam: load optimizer state (torch.optim.Adam's exp_avg / exp_avg_sq in the reference's flat
+// order, and the number of steps already taken -- both optimizers step together) so that a teacher-forced comparison can
+// restart every update from the oracle's exact state
+int hp_agent_set_adam(hp_agent *a, int32_t net, const float *m_host, const float *v_host, int64_t n, int64_t step) {
+    HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_set_adam: null handle");
+    HP_SERIALISE(a);
+    HP_REQUIRE(net == HP_NET_ACTOR || net == HP_NET_CRITIC, HP_ERR_INVALID, "hp_agent_set_adam: net must be actor or critic");
+    HP_REQUIRE(step >= 0, HP_ERR_INVALID, "hp_agent_set_adam: step must be >= 0");
+    const bool critic = net == HP_NET_CRITIC;
+    HP_REQUIRE(n == flat_count(a, critic), HP_ERR_INVALID, "hp_agent_set_adam: got %lld values, expected %lld", (long long)n,
+               (long long)flat_count(a, critic));
+    const NetLayout &l = critic ? a->lc : a->la;
+    std::vector<float> seg(l.total);
+    for (int which = 0; which < 2; ++which) {
+        const float *src = which ? v_host : m_host;
+        if (!src) continue;
+        pack_net(a, critic, src, seg.data());
+        float *dst = (which ? a->adam_v : a->adam_m) + (critic ? a->la.total : 0);
+        HP_CHECK_HIP(hipMemcpyAsync(dst, seg.data(), sizeof(float) * l.total, hipMemcpyHostToDevice, a->ctx->stream));
+        HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+    }
+    const long long st = step;
+    HP_CHECK_HIP(hipMemcpyAsync(&a->d_state->step, &st, sizeof(st), hipMemcpyHostToDevice, a->ctx->stream));
+    HP_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+    return HP_OK;
+}
+
 int hp_agent_sync_targets(hp_agent *a) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_sync_targets: null handle");
     HP_SERIALISE(a);
@@ -1951,6 +1980,7 @@ int hp_agent_sample_and_update(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *
     HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_sample_and_update"));
     HP_SERIALISE(a);
     HP_REQUIRE(n_updates > 0, HP_ERR_INVALID, "hp_agent_sample_and_update: n_updates must be positive");
+    HP_TRY(peer_check_alive(a->peer, "hp_agent_sample_and_update"));
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     HP_TRY(ensure_plan(a, n_updates));
     hipStream_t s = a->ctx->stream;
@@ -2395,6 +2425,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
     HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "hp_agent_train_cycle: n_new and n_batches must be positive");
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
     HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_train_cycle: profiling mode uses the eager path (hp_agent_profile(0) first)");
+    HP_TRY(peer_check_alive(a->peer, "hp_agent_train_cycle"));
     hipStream_t s = a->ctx->stream;
     // 1. episodes -> pinned -> device staging, slots, scatter (eager: the source pointers change per call)
     HP_TRY(buffer_stage_and_store(b, rng, obs, ag_host, g, actions, n_new));

@@ -271,15 +271,20 @@ int hp_buffer_store_done(hp_buffer *b, uint64_t ticket, int32_t wait, int32_t *d
         }
         ev = b->pin_events[ticket % hp_buffer::PIN_RING];
     }
-    if (wait) {   // outside the context lock: a feeder waiting for its block must not stall the trainer's enqueues
-        HP_CHECK_HIP(hipEventSynchronize(ev));
-        *done = 1;
-        return HP_OK;
-    }
-    const hipError_t e = hipEventQuery(ev);
+    // outside the context lock: a feeder waiting for its block must not stall the trainer's enqueues.  A concurrent
+    // hp_buffer_store_pinned may re-record this very event object for ticket + PIN_RING in the meantime (it synchronises on
+    // it first, so OUR copy is done by then): the slot is re-checked afterwards and a recycled slot reads as done, whatever
+    // the wait / query observed of the newer copy
+    hipError_t e = hipSuccess;
+    if (wait) HP_CHECK_HIP(hipEventSynchronize(ev));
+    else e = hipEventQuery(ev);
     if (e != hipSuccess && e != hipErrorNotReady) HP_CHECK_HIP(e);
     (void)hipGetLastError();
     *done = (e == hipSuccess) ? 1 : 0;
+    if (!*done) {
+        HP_SERIALISE(b);
+        if (ticket + hp_buffer::PIN_RING <= b->pin_tickets) *done = 1;
+    }
     return HP_OK;
 }
 

@@ -98,6 +98,13 @@ int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len) {
     return HP_OK;
 }
 
+// PCI bus id of the context's device ("0000:05:00.0"): what tells two ranks on ONE physical device apart from two GPUs
+int hp_ctx_pci_bus_id(hp_ctx *ctx, char *buf, size_t len) {
+    HP_REQUIRE(ctx && buf && len >= 16, HP_ERR_INVALID, "hp_ctx_pci_bus_id: bad argument");
+    HP_CHECK_HIP(hipDeviceGetPCIBusId(buf, (int)len, ctx->device));
+    return HP_OK;
+}
+
 // diagnostic: average cost of one dependent trivial kernel on the context's stream, as a captured
 // hipGraph of n nodes (graph != 0) or n eager launches.  Used by DESIGN.md's launch-floor numbers.
 int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel) {

@@ -14,7 +14,8 @@ struct PeerDev {              // by-value kernel argument: where every rank's ex
     unsigned long long *flags_r[HP_PEER_MAX];   // two-phase exchange: rank q's "reduced slice ready" flags
     float *red[HP_PEER_MAX][2];                 // two-phase exchange: rank q's buffer of reduced sums (it fills ITS slice)
     unsigned long long *epoch;                  // local: [0] gradient channel base, [1] mailbox channel
-    unsigned int *error;                        // local, sticky: a wait timed out
+    unsigned int *error;                        // local, sticky: a wait timed out (every later exchange kernel returns at once)
+    unsigned int *error_host;                   // the same word in pinned host memory: the host reads it without a sync
     unsigned long long timeout_ticks;           // 100 MHz ticks
 };
 
@@ -25,9 +26,11 @@ struct hp_peer {
     void *local = nullptr;
     void *remote[HP_PEER_MAX] = {nullptr};
     unsigned long long *d_epoch = nullptr;
+    unsigned int *h_error = nullptr;           // pinned + mapped: set by the kernel whose wait timed out
     unsigned char handle[64] = {0};
     bool connected = false;
     int phases = 1;            // 1: every rank reads all peers' whole vectors; 2: reduce-scatter + all-gather (peer.hip)
+    bool gate = false;         // every wait of the gradient exchange in a one-wavefront kernel of its own (hp_peer_set_gate)
     PeerDev dev;
 };
 
@@ -35,6 +38,11 @@ float *peer_grad_buffer(hp_peer *p, int parity);
 int peer_enqueue_seq_end(hp_peer *p, int n_updates);
 int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean);   // phase 1 of the two-phase exchange
 int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean);
+int peer_enqueue_gate(hp_peer *p, int channel, int u);                 // no-op unless p->gate; channel 1 gradients, 3 reduced slices
+// a wait of an earlier exchange kernel timed out: optimizer steps were skipped, the replicas are no longer in step.  Free
+// for the host (a read of pinned memory); what every entry point that enqueues exchange kernels checks first.
+inline bool peer_failed(const hp_peer *p) { return p && p->h_error && *(volatile const unsigned int *)p->h_error != 0u; }
+int peer_check_alive(const hp_peer *p, const char *who);   // HP_ERR_STATE + message when peer_failed
 
 #ifdef __HIPCC__
 // ---- device helpers shared by peer.hip (mailboxes) and agent.hip (k_peer_adam: gradients + optimizer) ----------------
@@ -46,26 +54,42 @@ __device__ __forceinline__ void peer_signal(const PeerDev &D, unsigned long long
     if (q < D.world && q != D.rank) __hip_atomic_store(flags[q] + D.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// every peer has signalled `epoch`?  lane q polls the local slot of peer q; returns false on timeout (wave-uniform)
-__device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *mine, unsigned long long epoch) {
-    const int q = threadIdx.x & 63;
-    const bool poll = (threadIdx.x < 64) && q < D.world && q != D.rank;
-    bool ok = true;
+// every peer has signalled `epoch`?  lane q of the first wave polls the local slot of peer q.  Returns the same answer to
+// every thread of the workgroup (it contains a barrier: call it from uniform control flow).  false = the exchange is dead:
+// a wait timed out now or in an earlier kernel (sticky) -- the caller must NOT consume the peers' buffers or step the
+// optimizer; the host sees the pinned error word at its next call (peer_failed) and every later exchange kernel returns at
+// once instead of stalling for another timeout.
+__device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *mine, unsigned long long epoch, unsigned channel = 1u) {
+    __shared__ int s_peer_ok;
     if (threadIdx.x < 64) {
-        const unsigned long long t0 = now_ticks();
-        for (;;) {
-            bool here = true;
-            if (poll) here = __hip_atomic_load(mine + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch;
-            if (__all(here)) break;
-            __builtin_amdgcn_s_sleep(16);
-            if (now_ticks() - t0 > D.timeout_ticks) {
-                if (threadIdx.x == 0) __hip_atomic_store(D.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
+        const int q = threadIdx.x & 63;
+        const bool poll = q < D.world && q != D.rank;
+        bool ok = __hip_atomic_load(D.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        if (ok) {
+            const unsigned long long t0 = now_ticks();
+            for (;;) {
+                bool here = true;
+                if (poll) here = __hip_atomic_load(mine + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch;
+                if (__all(here)) break;
+                __builtin_amdgcn_s_sleep(16);
+                if (now_ticks() - t0 > D.timeout_ticks) {
+                    // error word: bit 0 = dead, bits 4-7 = channel (1 gradients, 2 mailboxes, 3 reduced slices),
+                    // bits 8-23 = ranks whose flag had not arrived, bits 24-31 = low bits of the epoch waited for
+                    const unsigned missing = (unsigned)(__ballot(!here) & 0xffffull);
+                    if (threadIdx.x == 0) {
+                        const unsigned word = 1u | (channel << 4) | (missing << 8) | ((unsigned)(epoch & 0xffull) << 24);
+                        __hip_atomic_store(D.error, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(D.error_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    ok = false;
+                    break;
+                }
             }
         }
+        if (threadIdx.x == 0) s_peer_ok = ok ? 1 : 0;
     }
-    return ok;
+    __syncthreads();
+    return s_peer_ok != 0;
 }
 
 // float4s [lo, lo + per) of the vector are rank r's slice in the two-phase exchange

@@ -40,6 +40,16 @@ __global__ void k_peer_seq_end(const PeerDev D, int n_updates) {
     if (blockIdx.x == 0 && threadIdx.x == 0) D.epoch[0] += (unsigned long long)(n_updates + (n_updates & 1));
 }
 
+// Gate (hp_peer_set_gate): signal + wait of one channel as ONE wavefront.  The kernel behind it signals the same epoch again
+// (idempotent) and finds every flag there, so its own wait falls through.  On one shared device this is what keeps a rank
+// that is still computing from being starved by the other ranks' waiting workgroups.
+__global__ __launch_bounds__(64) void k_peer_gate(const PeerDev D, int channel, int u) {
+    const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
+    unsigned long long *const *flags = channel == 3 ? D.flags_r : D.flags_g;
+    peer_signal(D, flags, epoch);
+    (void)peer_wait(D, flags[D.rank], epoch, (unsigned)channel);
+}
+
 // small vectors (normalizer sums): one workgroup.  vec[n] := sum over ranks (/ world if mean), in place.
 __global__ __launch_bounds__(256) void k_peer_small(const PeerDev D, float *vec, int n, int mean) {
     const unsigned long long epoch = D.epoch[1] + 1ull;
@@ -50,8 +60,7 @@ __global__ __launch_bounds__(256) void k_peer_small(const PeerDev D, float *vec,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: stores complete before the flag goes out
     __syncthreads();
     peer_signal(D, D.flags_s, epoch);
-    peer_wait(D, D.flags_s[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_s[D.rank], epoch, 2u)) return;   // dead exchange: leave vec alone, the host raises (peer_failed)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float acc = 0.f;
         for (int q = 0; q < D.world; ++q) {
@@ -70,8 +79,7 @@ __global__ __launch_bounds__(256) void k_peer_reduce_slice(const PeerDev D, int 
     const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
     const int par = (int)(epoch & 1ull);
     if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
-    peer_wait(D, D.flags_g[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_g[D.rank], epoch)) return;
     const int per = peer_slice_len(D, n4);
     const int lo = D.rank * per, hi = (lo + per) < n4 ? (lo + per) : n4;
     const int t = lo + blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,8 +109,7 @@ __global__ __launch_bounds__(256) void k_peer_check_reduce(const PeerDev D, int 
     const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
     const int par = (int)(epoch & 1ull);
     if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
-    peer_wait(D, D.flags_g[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_g[D.rank], epoch)) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -122,8 +129,7 @@ __global__ __launch_bounds__(256) void k_peer_check_gather(const PeerDev D, int 
     const unsigned long long epoch = D.epoch[0] + (unsigned long long)u + 1ull;
     const int par = (int)(epoch & 1ull);
     if (blockIdx.x == 0) peer_signal(D, D.flags_r, epoch);
-    peer_wait(D, D.flags_r[D.rank], epoch);
-    __syncthreads();
+    if (!peer_wait(D, D.flags_r[D.rank], epoch, 3u)) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
     const int owner = t / peer_slice_len(D, n4);
@@ -138,13 +144,33 @@ __global__ __launch_bounds__(256) void k_peer_check_gather(const PeerDev D, int 
 // ---- internal entry points used by agent.hip -----------------------------------------------------------------------
 float *peer_grad_buffer(hp_peer *p, int parity) { return p->dev.grad[p->rank][parity & 1]; }
 
+int peer_check_alive(const hp_peer *p, const char *who) {
+    if (!peer_failed(p)) return HP_OK;
+    const unsigned w = *(volatile const unsigned int *)p->h_error;
+    static const char *chan[4] = {"?", "gradient", "normalizer mailbox", "reduced-slice"};
+    HP_REQUIRE(false, HP_ERR_STATE,
+               "%s: the peer-memory exchange is dead -- rank %d waited longer than the bound (RLARM_PEER_TIMEOUT_S) on the %s "
+               "channel for ranks 0x%x (epoch ..%u): late or gone.  The optimizer steps from that update on were skipped on this "
+               "rank and the replicas are no longer in step",
+               who, p->rank, chan[(w >> 4) & 3u], (w >> 8) & 0xffffu, w >> 24);
+    return HP_OK;
+}
+
 int peer_enqueue_seq_end(hp_peer *p, int n_updates) {
     hipLaunchKernelGGL(k_peer_seq_end, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, n_updates);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
 
+int peer_enqueue_gate(hp_peer *p, int channel, int u) {
+    if (!p->gate) return HP_OK;
+    hipLaunchKernelGGL(k_peer_gate, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, channel, u);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
 int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean) {
+    HP_TRY(peer_enqueue_gate(p, 1, u));
     const int per = (n4 + p->world - 1) / p->world;
     hipLaunchKernelGGL(k_peer_reduce_slice, dim3((per + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, n4, u, mean ? 1 : 0);
     HP_CHECK_HIP(hipGetLastError());
@@ -211,6 +237,7 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     p->n_grad = (size_t)n_grad_floats;
     p->phases = world >= 4 ? 2 : 1;
     if (const char *ph = getenv("RLARM_PEER_PHASES")) p->phases = atoi(ph) == 2 ? 2 : (atoi(ph) == 1 ? 1 : p->phases);
+    if (const char *g = getenv("RLARM_PEER_GATE")) p->gate = g[0] != '0';
     const PeerLayout L(p->n_grad);
     p->bytes = L.total;
     // fine-grained: coherent with the peers' system-scope accesses; plain device memory if the runtime refuses
@@ -226,6 +253,9 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     hipError_t e = hipMemset(p->local, 0, p->bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_epoch, 2 * sizeof(unsigned long long) + 16);
     if (e == hipSuccess) e = hipMemset(p->d_epoch, 0, 2 * sizeof(unsigned long long) + 16);
+    void *h_err_dev = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_error, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { *p->h_error = 0u; e = hipHostGetDevicePointer(&h_err_dev, p->h_error, 0); }
     hipIpcMemHandle_t h;
     if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p->local);
     if (e != hipSuccess) {
@@ -240,6 +270,7 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     p->dev.world = world;
     p->dev.epoch = p->d_epoch;
     p->dev.error = reinterpret_cast<unsigned int *>(p->d_epoch + 2);
+    p->dev.error_host = static_cast<unsigned int *>(h_err_dev);
     double secs = 20.0;   // a rank may legitimately be late by a host-side pause (checkpoint, graph capture); a dead one must not hang us
     if (const char *t = getenv("RLARM_PEER_TIMEOUT_S")) secs = atof(t) > 0 ? atof(t) : secs;
     p->dev.timeout_ticks = (unsigned long long)(secs * 1e8);
@@ -292,8 +323,10 @@ int hp_peer_selfcheck(hp_peer *p, uint32_t *mismatches) {
         hipLaunchKernelGGL(k_peer_check_fill, dim3((n + 255) / 256), dim3(256), 0, s, p->dev, n, (u + 1) & 1);
         if (p->phases == 2) {
             HP_TRY(peer_enqueue_reduce_slice(p, n4, u, false));
+            HP_TRY(peer_enqueue_gate(p, 3, u));
             hipLaunchKernelGGL(k_peer_check_gather, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
         } else {
+            HP_TRY(peer_enqueue_gate(p, 1, u));
             hipLaunchKernelGGL(k_peer_check_reduce, dim3((n4 + 255) / 256), dim3(256), 0, s, p->dev, n4, u, bad);
         }
     }
@@ -311,6 +344,14 @@ int hp_peer_status(hp_peer *p, uint32_t *error) {
     CtxGuard guard(p->ctx);
     HP_CHECK_HIP(hipMemcpyAsync(error, p->dev.error, 4, hipMemcpyDeviceToHost, p->ctx->stream));
     HP_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (peer_failed(p)) *error |= *(volatile const unsigned int *)p->h_error;
+    return HP_OK;
+}
+
+int hp_peer_set_gate(hp_peer *p, int32_t on) {
+    HP_REQUIRE(p, HP_ERR_INVALID, "hp_peer_set_gate: null handle");
+    p->gate = on != 0;
+    if (const char *g = getenv("RLARM_PEER_GATE")) p->gate = g[0] != '0';
     return HP_OK;
 }
 
@@ -328,6 +369,7 @@ void hp_peer_destroy(hp_peer *p) {
         if (q != p->rank && p->remote[q]) (void)hipIpcCloseMemHandle(p->remote[q]);
     if (p->local) (void)hipFree(p->local);
     if (p->d_epoch) (void)hipFree(p->d_epoch);
+    if (p->h_error) (void)hipHostFree(p->h_error);
     delete p;
 }
 

@@ -90,7 +90,13 @@ class ddpg_agent:
             _lib.check(self.lib.hp_agent_grad_buffer(self.h, C.byref(p), C.byref(n)))
             self._peer = self.comm.attach_peer(self.ctx, n.value)
             if self._peer is not None:
-                if self.lib.hp_agent_set_peer(self.h, self._peer) != 0:      # e.g. the layer-per-launch engine
+                # e.g. the layer-per-launch engine cannot use it.  The ranks decide TOGETHER, and an exchange nobody uses is
+                # destroyed (not merely forgotten): `comm.peer` must not outlive it, or the fallback below would take the
+                # peer start-up path while its gradients go through another transport
+                ok = self.lib.hp_agent_set_peer(self.h, self._peer) == 0
+                if not self.comm.agree(ok, self.ctx):
+                    _lib.check(self.lib.hp_agent_set_peer(self.h, None))
+                    self.comm.drop_peer()
                     self._peer = None
         if self._peer is None:
             self._native_comm = self.comm.attach_native(self.ctx)
@@ -110,7 +116,8 @@ class ddpg_agent:
                                       else getattr(args, "distance_threshold", 0.05),
                                       reward_type=None if reward_func is not None and hasattr(
                                           getattr(reward_func, "__self__", None), "reward_type")
-                                      else getattr(args, "reward_type", "sparse"), rng=self.rng)
+                                      else getattr(args, "reward_type", "sparse"), rng=self.rng,
+                                      goal_dim=env_params['goal'])
         self.buffer = replay_buffer(self.env_params, self.args.buffer_size, self.her_module.sample_her_transitions,
                                     rng=self.rng, ctx=self.ctx)
         if getattr(self.args, "add_demo", False):
@@ -121,19 +128,32 @@ class ddpg_agent:
         self.g_norm = normalizer(size=env_params['goal'], default_clip_range=self.args.clip_range, ctx=self.ctx,
                                  comm=self.comm)
         self._norm_stage = None          # staging buffer of _update_normalizer(episode_batch)
+        import threading
+        self._stage_lock = threading.RLock()   # orders "store a wave, then sample ITS staged episodes" across feeder threads
         self.success_rates = []
         self.model_path = os.path.join(self.args.save_dir, self.args.env_name)
 
     def close_comm(self):
         """Detach and destroy the library-side RCCL communicator (call on every rank before
         torch.distributed.destroy_process_group / interpreter exit)."""
-        if self._native_comm is not None or self._peer is not None:
+        if self._native_comm is not None or self._peer is not None or self.comm.peer is not None or self.comm.native is not None:
             self.ctx.synchronize()
             _lib.check(self.lib.hp_agent_set_comm(self.h, None))
             _lib.check(self.lib.hp_agent_set_peer(self.h, None))
             self._native_comm = None
             self._peer = None
             self.comm.close()
+
+    def check_exchange(self):
+        """Raise if the peer-memory exchange died (a rank late by more than RLARM_PEER_TIMEOUT_S, or gone): the optimizer
+        steps from that update on were skipped, so the replicas are no longer in step.  train_cycle / _update_network raise
+        the same at their next call without synchronising; learn() asks at every epoch boundary."""
+        if self._peer is not None:
+            err = C.c_uint32()
+            _lib.check(self.lib.hp_peer_status(self._peer, C.byref(err)))
+            if err.value:
+                raise RuntimeError("peer-memory exchange timed out: a rank was late by more than RLARM_PEER_TIMEOUT_S or is "
+                                   "gone; updates were skipped on this rank and the replicas are no longer in step")
 
     # ------------------------------------------------------------------ parameter plumbing
     def _count(self, slot):
@@ -160,20 +180,30 @@ class ddpg_agent:
                                               C.byref(step)))
         return m, v, step.value
 
+    def set_adam_state(self, slot, m, v, step):
+        """Load optimizer state (test hook, hp_agent_set_adam): torch.optim.Adam's exp_avg / exp_avg_sq in the flat order of
+        utils.py:18-27 and the number of steps already taken (both optimizers step together)."""
+        m, v = _lib.as_f32(m), _lib.as_f32(v)
+        _lib.check(self.lib.hp_agent_set_adam(self.h, slot, _lib.ptr(m, C.c_float), _lib.ptr(v, C.c_float), m.size,
+                                              int(step)))
+
     def _broadcast_params(self, comm):
         if not comm.active:
             return
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.hp_agent_param_buffer(self.h, C.byref(p), C.byref(n)))
-        if comm.native is None and comm.peer is not None:
-            # one-off at start-up through torch.distributed; the library keeps its own (capturable) stream, so order the
-            # two sides with full synchronisations instead of moving the library onto torch's stream
+        if comm.native is None and self._peer is not None and comm.peer is not None:
+            # the library exchanges gradients itself over peer memory: only this one-off broadcast goes through
+            # torch.distributed; the library keeps its own (capturable) stream, so order the two sides with full
+            # synchronisations instead of moving the library onto torch's stream
             self.ctx.synchronize()
             comm.broadcast_device(p.value, n.value, 0)
             torch.cuda.synchronize(self.ctx.device_id)
             return
         if comm.native is None:
-            self.ctx.use_torch_stream()      # order our kernels with the collectives torch enqueues
+            # every exchange of this run goes through torch.distributed (host-driven loop): the library's kernels must be
+            # stream-ordered with the collectives torch enqueues
+            self.ctx.use_torch_stream()
         comm.broadcast_device(p.value, n.value, 0)
 
     def _allreduce_grads(self, comm):
@@ -298,8 +328,9 @@ class ddpg_agent:
         registered shared-memory slot (no CPU copy), the normalizer samples the staged episodes, the updates replay their
         cached graph.  Asynchronous; ranks of a data-parallel group call it in step like train_cycle."""
         n_batches = int(n_batches or self.args.n_batches)
-        feeder.store_wave(slot)
-        self._update_normalizer()
+        with self._stage_lock:       # store + normalizer update as one unit: another thread's store_wave (e.g. a rollout
+            feeder.store_wave(slot)  # thread) must not replace the staged episodes in between
+            self._update_normalizer()
         self._update_network(n_batches)
         self._soft_update_target_network()
 
@@ -443,6 +474,7 @@ class ddpg_agent:
                 if share:
                     np.random.set_state(self.rng.get_state())
             self.ctx.synchronize()
+            self.check_exchange()
             print(str(time.time() - start))
             rate = self._eval_agent()
             self.success_rates.append(rate)

@@ -184,9 +184,10 @@ class EpisodeFeeder:
         """replay_buffer.store_episode of the slot's episodes: asynchronous DMA straight out of the shared ring."""
         ag = self.agent
         ticket = C.c_uint64()
-        self._lib.check(ag.lib.hp_buffer_store_pinned(ag.buffer._dev.h, ag.rng.h,
-                                                      C.c_void_p(self._ring_addr + slot * self.lay.slot_elems * 8),
-                                                      self.n_envs, C.byref(ticket)))
+        with ag._stage_lock:     # the device staging of "the most recent store" is what _update_normalizer(None) samples
+            self._lib.check(ag.lib.hp_buffer_store_pinned(ag.buffer._dev.h, ag.rng.h,
+                                                          C.c_void_p(self._ring_addr + slot * self.lay.slot_elems * 8),
+                                                          self.n_envs, C.byref(ticket)))
         self._tickets[slot] = ticket.value
         return ticket.value
 

@@ -15,6 +15,14 @@ of an object with `distance_threshold` / `reward_type` attributes they are honou
 anything else must be described with the keyword arguments.  Both branches of the envs'
 compute_reward run on the device: 'sparse' (-(d > threshold)) and 'dense' (-d); any other
 reward is refused loudly rather than silently computed on the host.
+
+The callable is never trusted to BE what its description says: her.py:38 calls
+`self.reward_func(ag_next, g, None)`, so at construction the sampler calls the given
+callable on a fixed set of goal pairs (exact hits, pairs straddling the threshold by a few
+ulp, far pairs) and compares the result BIT FOR BIT with what the device will compute
+(`hp_compute_reward` with the resolved threshold / type).  A callable that answers anything
+else -- another threshold, a shaped reward, a different dtype -- raises NotImplementedError
+instead of being silently replaced by the bmirobot reward.
 """
 from __future__ import annotations
 
@@ -46,7 +54,7 @@ def squared_threshold(distance_threshold: float) -> float:
 
 class her_sampler:
     def __init__(self, replay_strategy, replay_k, reward_func=None, distance_threshold=None, reward_type=None,
-                 rng=None):
+                 rng=None, goal_dim=3):
         self.replay_strategy = replay_strategy
         self.replay_k = replay_k
         if self.replay_strategy == 'future':                       # her.py:7-10
@@ -68,6 +76,43 @@ class her_sampler:
         # the kernels take the squared threshold; a negative value selects the dense reward -d (compute_reward :89-90)
         self.sq_threshold = squared_threshold(self.distance_threshold) if reward_type == "sparse" else -1.0
         self._rng = rng
+        if reward_func is not None:
+            self._probe_reward_func(reward_func, int(goal_dim))
+
+    def _probe_reward_func(self, reward_func, gd=3):
+        """her.py:38 would call `reward_func(ag_next, g, None)`; the device computes the goal-distance reward described by
+        (distance_threshold, reward_type) instead.  Check that they are the same function where it matters."""
+        from .goal_env import GoalDistanceReward
+
+        if isinstance(getattr(reward_func, "__self__", None), GoalDistanceReward):
+            return                                               # the device op itself
+        thr = self.distance_threshold
+        rs = np.random.RandomState(20240607)                     # private stream: the global one is the sampler's
+        far = rs.uniform(-1.0, 1.0, size=(24, 2, gd))
+        base = rs.uniform(-0.5, 0.5, size=(20, gd))
+        dirs = rs.normal(size=(20, gd))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        near = [base + dirs * (thr * f) for f in (1.0 - 1e-12, 1.0, 1.0 + 1e-12, 0.999, 1.001, 0.5, 2.0)]
+        ag = np.concatenate([far[:, 0], base, base] + near)      # far pairs, exact hits, a ring around the threshold
+        g = np.concatenate([far[:, 1], base, base] + [base] * len(near))
+        try:
+            got = np.asarray(reward_func(ag.copy(), g.copy(), None))
+        except Exception as e:
+            raise NotImplementedError(
+                f"reward_func {reward_func!r} could not be evaluated as compute_reward(achieved_goal, goal, info) on "
+                f"[n, {gd}] arrays ({type(e).__name__}: {e}); the device computes the bmirobot goal-distance reward only"
+            ) from e
+        ctx = getattr(self._rng, "ctx", None) or _lib.Context.default()
+        want = GoalDistanceReward(thr, self.reward_type, ctx=ctx).compute_reward(ag, g, None)
+        if got.shape != want.shape or got.dtype != want.dtype or not np.array_equal(
+                np.ascontiguousarray(got).view(np.uint8), np.ascontiguousarray(want).view(np.uint8)):
+            n_bad = int(np.sum(got.reshape(-1) != want.reshape(-1))) if got.shape == want.shape else -1
+            raise NotImplementedError(
+                f"reward_func {reward_func!r} is not the goal-distance reward the device computes "
+                f"(reward_type={self.reward_type!r}, distance_threshold={thr!r}): dtype {got.dtype} vs {want.dtype}, "
+                f"shape {got.shape} vs {want.shape}, {n_bad} of {want.size} probe pairs differ.  Describe the reward with "
+                "distance_threshold= / reward_type= (her_sampler keyword arguments or attributes of the env); arbitrary "
+                "Python rewards are not evaluated on the host (her.py:38) -- there is no host fallback")
 
     @property
     def rng(self):

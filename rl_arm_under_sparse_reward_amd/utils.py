@@ -36,6 +36,27 @@ class Communicator:
         self.native = None        # library-side RCCL communicator (hp_comm *), see attach_native
         self._native_lib = None
         self.peer = None          # library-side peer-memory exchange (hp_peer *), see attach_peer
+        self.shared_device = False   # two or more ranks on one physical device (set by attach_peer)
+
+    def agree(self, flag, ctx=None):
+        """True iff `flag` is true on EVERY rank (collective).  Transport decisions must be taken by all ranks together."""
+        if self._dist is None:
+            return bool(flag)
+        if self._dist.get_backend() == "nccl":
+            dev_id = ctx.device_id if ctx is not None else (self.device_id if self.device_id is not None else torch.cuda.current_device())
+            dev = torch.device("cuda", dev_id)
+        else:
+            dev = torch.device("cpu")
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def drop_peer(self):
+        """Destroy the peer-memory exchange (every rank, together: e.g. the agent's engine cannot use it), so that the
+        next transport down is attached and the exchange memory / IPC mappings do not stay open."""
+        if self.peer is not None:
+            self._native_lib.hp_peer_destroy(self.peer)
+            self.peer = None
 
     def attach_native(self, ctx):
         """Create (once) the library's own RCCL communicator for this rank.  Collective: every rank of the
@@ -96,27 +117,40 @@ class Communicator:
                 lib.hp_peer_destroy(h)
             return None
         raw = (C.c_uint8 * (64 * self.world_size))(*[int(b) for t in every for b in t.cpu().tolist()])
+        # ranks that share one physical device (an N-rank rehearsal on fewer GPUs) depend on each other's kernels being
+        # co-resident: their waits go into one-wavefront gate kernels (hp_peer_set_gate) so that waiting ranks cannot
+        # starve a computing one of registers / LDS.  One rank per GPU (the real job): no gate, no extra kernel boundary
+        bus = C.create_string_buffer(32)
+        _lib.check(lib.hp_ctx_pci_bus_id(ctx.h, bus, 32))
+        mine_id = torch.tensor(list(bus.raw), dtype=torch.uint8, device=dev)
+        ids = [torch.zeros(32, dtype=torch.uint8, device=dev) for _ in range(self.world_size)]
+        dist.all_gather(ids, mine_id)
+        self.shared_device = len({bytes(t.cpu().tolist()) for t in ids}) < self.world_size
+        _lib.check(lib.hp_peer_set_gate(h, 1 if self.shared_device else 0))
         ok = lib.hp_peer_connect(h, raw) == 0
         if not agree(ok):      # before any collective kernel: a rank that could not map its peers must not leave the others waiting
             lib.hp_peer_destroy(h)
             return None
-        if ok:   # self-check: rank r contributes (r + 1) * (i + 1); the rank-ordered sum is exact in float32
-            n, w = 257, self.world_size
-            probe = torch.arange(1, n + 1, dtype=torch.float32, device=f"cuda:{ctx.device_id}") * float(self.rank + 1)
+        # self-check: rank r contributes (r + 1) * (i + 1); the rank-ordered sum is exact in float32.  Every rank runs EVERY
+        # collective step whatever its own intermediate results (a rank that stopped early would leave the others spinning
+        # in the remaining ones until the device timeout); the verdicts are combined afterwards
+        n, w = 257, self.world_size
+        probe = torch.arange(1, n + 1, dtype=torch.float32, device=f"cuda:{ctx.device_id}") * float(self.rank + 1)
+        torch.cuda.synchronize(ctx.device_id)
+        for mean in (0, 1):
+            v = probe.clone()
             torch.cuda.synchronize(ctx.device_id)
-            for mean in (0, 1):
-                v = probe.clone()
-                torch.cuda.synchronize(ctx.device_id)
-                ok = ok and lib.hp_peer_allreduce_f32(h, C.c_void_p(v.data_ptr()), n, mean) == 0
-                ctx.synchronize()
-                expect = torch.arange(1, n + 1, dtype=torch.float32) * float(w * (w + 1) // 2)
-                if mean:
-                    expect = expect / float(w)
-                ok = ok and bool(torch.equal(v.cpu(), expect))
-            bad, err = C.c_uint32(), C.c_uint32()
-            # ... and the gradient channel itself: both buffer parities, 16-byte system-scope loads of every peer's vector
-            ok = ok and lib.hp_peer_selfcheck(h, C.byref(bad)) == 0 and bad.value == 0
-            ok = ok and lib.hp_peer_status(h, C.byref(err)) == 0 and err.value == 0
+            launched = lib.hp_peer_allreduce_f32(h, C.c_void_p(v.data_ptr()), n, mean) == 0
+            ctx.synchronize()
+            expect = torch.arange(1, n + 1, dtype=torch.float32) * float(w * (w + 1) // 2)
+            if mean:
+                expect = expect / float(w)
+            ok = bool(torch.equal(v.cpu(), expect)) and launched and ok
+        bad, err = C.c_uint32(), C.c_uint32()
+        # ... and the gradient channel itself: both buffer parities, 16-byte system-scope loads of every peer's vector
+        checked = lib.hp_peer_selfcheck(h, C.byref(bad)) == 0
+        ok = ok and checked and bad.value == 0
+        ok = lib.hp_peer_status(h, C.byref(err)) == 0 and err.value == 0 and ok
         if not agree(ok):
             lib.hp_peer_destroy(h)
             return None

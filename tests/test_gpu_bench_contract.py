@@ -17,7 +17,12 @@ def _run(*flags, timeout=600, **extra_env):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], cwd=REPO, env=env, capture_output=True,
                        text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-2000:]
+    if p.returncode != 0:     # the ranks' own messages come first, torchrun's failure banner (long, generic) last
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "bench_contract_failure.log"), "w") as fh:
+            fh.write(p.stdout + "\n==== stderr ====\n" + p.stderr)
+        own = [ln for ln in p.stderr.splitlines() if "elastic" not in ln and not ln.startswith(("E ", " "))]
+        raise AssertionError("\n".join(own[-60:]) + "\n....\n" + p.stderr[-1500:])
     # (the ranks' constructor prints -- the reference's own "Buffer_size: ..." line -- may interleave; the record is the one
     # line that parses as the contract's JSON object)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -60,6 +65,32 @@ def test_plain_shell_multi_rank_launch(batch):
         if d["config"]["exchange"] == "peer-memory":
             assert e["config"]["peer_exchange_form"].startswith("two-phase")
             assert e["config"]["final_losses"] == d["config"]["final_losses"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_plain_shell_launch_rehearses_4_and_8_ranks(world):
+    """BASELINE configs 4 / 5 run on 8 GPUs, which only the driver has: this rehearses the exact code path `bench.py --gpus 4|8`
+    takes there -- self-launch under torch.distributed.run, one process per rank, seed + rank sampler streams, parameter
+    broadcast, per-update gradient exchange, per-cycle normalizer exchange -- with every rank on the one device of the test box
+    (IPC-mapped peer memory exactly as between GPUs; the fabric itself is what cannot be rehearsed).  Nothing is forced, so the
+    transport and form are the DEFAULT ones: peer memory, two-phase (reduce-scatter + all-gather) from 4 ranks.  Then the
+    one-shot form and the torch.distributed fallback: same replicas, and one-shot == two-phase bit for bit."""
+    common = ("--gpus", str(world), "--episodes", "64", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile")
+    d = _run(*common, timeout=900)
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == 256 * world
+    assert d["config"]["exchange"] == "peer-memory", d["config"]
+    assert d["config"]["peer_exchange_form"].startswith("two-phase")
+    assert d["config"]["cycle_mode"] == "hipGraph"
+    assert d["config"]["replicas_bit_identical"] is True and d["config"]["devices_shared_by_ranks"] is True
+    assert abs(d["value"] - world * 256 * 80 / (d["ms_per_step"] * 80e-3)) <= 1e-3 * d["value"]
+    assert all(abs(x) < 1e3 for x in d["config"]["final_losses"])
+    one = _run(*common, timeout=900, RLARM_PEER_PHASES="1")
+    assert one["config"]["peer_exchange_form"].startswith("one-shot") and one["config"]["replicas_bit_identical"] is True
+    assert one["config"]["final_losses"] == d["config"]["final_losses"]          # same rank-ordered float32 sums
+    t = _run(*common, timeout=900, RLARM_COMM="torch")
+    assert t["config"]["exchange"] == "torch.distributed" and t["config"]["replicas_bit_identical"] is True
+    for got, want in zip(t["config"]["final_losses"], d["config"]["final_losses"]):  # another summation order across ranks
+        assert abs(got - want) <= 2e-2 * max(abs(want), 1e-2)
 
 
 def test_multi_rank_launch_survives_a_failing_exchange_on_one_rank():

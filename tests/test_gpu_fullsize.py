@@ -5,7 +5,8 @@ The oracle is fed the same stream; sampled indices are checked through the RNG s
 north-star 1e-5 relative for the first update and the envelope 1e-5 x 1.3^i (capped at 3e-3) along the chained trajectory (two correct fp32
 implementations separate slowly; same bound as tests/test_gpu_update.py).
   config 2: push, buffer 5e5, batch 256, replay_k 4
-  config 3: add_demo (first 1000 episodes from a 1000-episode demo .npz in the get_demo_data schema), batch 1024"""
+  config 3: add_demo (first 1000 episodes from a 1000-episode demo .npz in the get_demo_data schema), batch 1024
+  config 5 per GPU: batch 512 (global 4096 / 8), replay_k 8, 8 fresh episodes per cycle (64 envs / 8 GPUs)"""
 import numpy as np
 import pytest
 import torch
@@ -23,8 +24,9 @@ pytestmark = pytest.mark.gpu
 N_EPISODES = 5000          # buffer_size 5e5 / T 100 (replay_buffer.py:16)
 
 
-@pytest.mark.parametrize("batch,k,n_demo", [(256, 4, 0), (1024, 4, 1000)], ids=["config2_b256", "config3_demo_b1024"])
-def test_train_cycles_on_the_full_buffer_track_the_oracle(batch, k, n_demo, tmp_path):
+@pytest.mark.parametrize("batch,k,n_demo,n_fresh", [(256, 4, 0, 2), (1024, 4, 1000, 2), (512, 8, 0, 8)],
+                         ids=["config2_b256", "config3_demo_b1024", "config5_per_gpu_b512_k8"])
+def test_train_cycles_on_the_full_buffer_track_the_oracle(batch, k, n_demo, n_fresh, tmp_path):
     torch.set_num_threads(8)
     seed, n_cycles, n_batches = 125, 2, 40
     kw = {}
@@ -53,10 +55,10 @@ def test_train_cycles_on_the_full_buffer_track_the_oracle(batch, k, n_demo, tmp_
     on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
     learner = oupd.DDPGLearner(a0, c0)
     for cycle in range(n_cycles):
-        eps = make_episodes(2, seed=100 + cycle, mode="walk")
+        eps = make_episodes(n_fresh, seed=100 + cycle, mode="walk")
         agent.train_cycle(eps, n_batches)
-        slots = st.store_episode(eps, rs)                      # overflow branch: randint(0, size, 2)
-        assert np.array_equal(agent.buffer._dev.last_slots(2), slots)
+        slots = st.store_episode(eps, rs)                      # overflow branch: randint(0, size, n_fresh)
+        assert np.array_equal(agent.buffer._dev.last_slots(n_fresh), slots)
         update_normalizers(on, gn, eps, fp, rs)
         got = agent.last_losses(n_batches)
         for i in range(n_batches):
@@ -69,7 +71,7 @@ def test_train_cycles_on_the_full_buffer_track_the_oracle(batch, k, n_demo, tmp_
         assert state_equal(rng, *rs.get_state()[1:3]), cycle    # every index draw consumed the reference's words
         assert np.array_equal(bits(agent.o_norm.mean), bits(on.mean)) and np.array_equal(bits(agent.g_norm.std), bits(gn.std))
     # the overwritten slots hold the fresh episodes; a demo episode that was not overwritten is intact
-    last = make_episodes(2, seed=100 + n_cycles - 1, mode="walk")
+    last = make_episodes(n_fresh, seed=100 + n_cycles - 1, mode="walk")
     stored = agent.buffer._dev.read("obs", int(slots[-1]), 1)
     assert np.array_equal(stored[0], last[0][-1])
     if n_demo:

@@ -125,6 +125,47 @@ def test_empty_and_invalid_calls_raise_like_the_reference():
         her_sampler("future", 4, reward_type="shaped")   # only compute_reward's two branches run on the device
 
 
+def test_reward_callables_are_probed_not_trusted():
+    """her.py:11,38: the reference CALLS whatever reward_func it is given.  The device computes the goal-distance reward
+    described by (distance_threshold, reward_type); a callable that is anything else must raise at construction, never be
+    silently replaced by sparse / 0.05."""
+    from rl_arm_under_sparse_reward_amd.synthetic import PointMassGoalEnv
+    dev = fresh_rng(3)
+
+    def ref_sparse(thr):
+        return lambda ag, g, info: -(np.linalg.norm(ag - g, axis=-1) > thr).astype(np.float32)
+
+    # plain callables with no bound env: accepted when they ARE the described reward ...
+    assert her_sampler("future", 4, ref_sparse(0.05), rng=dev).distance_threshold == 0.05
+    s = her_sampler("future", 4, ref_sparse(0.07), distance_threshold=0.07, rng=dev)
+    assert s.sq_threshold == pytest.approx(0.07 ** 2, rel=1e-12)
+    her_sampler("future", 4, lambda ag, g, info: -np.linalg.norm(ag - g, axis=-1), reward_type="dense", rng=dev)
+    # ... refused when they are not: another threshold than the default, a shaped reward, float64 instead of float32,
+    # 0.0 instead of -0.0 is the same VALUE but the reference's expression yields -0.0: bits are compared
+    with pytest.raises(NotImplementedError, match="not the goal-distance reward"):
+        her_sampler("future", 4, ref_sparse(0.1), rng=dev)
+    with pytest.raises(NotImplementedError, match="not the goal-distance reward"):
+        her_sampler("future", 4, lambda ag, g, info: -np.linalg.norm(ag - g, axis=-1) ** 2, reward_type="dense", rng=dev)
+    with pytest.raises(NotImplementedError, match="not the goal-distance reward"):
+        her_sampler("future", 4, lambda ag, g, info: -(np.linalg.norm(ag - g, axis=-1) > 0.05).astype(np.float64), rng=dev)
+    with pytest.raises(NotImplementedError, match="could not be evaluated"):
+        her_sampler("future", 4, lambda ag: 0.0, rng=dev)
+    # a bound env method: attributes honoured AND checked against what the method really computes
+    env = PointMassGoalEnv(seed=1, distance_threshold=0.08)
+    assert her_sampler("future", 4, env.compute_reward, rng=dev).distance_threshold == 0.08
+    env.distance_threshold = 0.03            # the attribute now lies about ... nothing: the method reads it, still consistent
+    assert her_sampler("future", 4, env.compute_reward, rng=dev).distance_threshold == 0.03
+
+    class Lying:
+        distance_threshold, reward_type = 0.05, "sparse"
+
+        def compute_reward(self, ag, g, info):
+            return -(np.linalg.norm(ag - g, axis=-1) > 0.2).astype(np.float32)
+
+    with pytest.raises(NotImplementedError, match="not the goal-distance reward"):
+        her_sampler("future", 4, Lying().compute_reward, rng=dev)
+
+
 def test_her_sampler_on_host_episode_dict():
     """her_sampler.sample_her_transitions(episode_batch, B) as ddpg_agent._update_normalizer calls it."""
     eps = make_episodes(2, seed=5, mode="walk")

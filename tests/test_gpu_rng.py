@@ -55,6 +55,27 @@ def test_set_get_state_roundtrip_with_numpy():
     assert np.array_equal(rs2.uniform(size=10), rs.uniform(size=10))
 
 
+def test_state_hand_off_keeps_numpys_cached_gaussian():
+    """learn() hands numpy's global stream to the device for the learner phase and takes it back.  After an ODD number of
+    randn draws numpy holds a cached second normal (has_gauss = 1); randint / random_sample never touch it, so it must
+    survive the round trip -- otherwise an env with an odd number of exploration normals per cycle leaves the reference's
+    stream (ddpg_agent.py:177-183 share np.random with her.py:24-31)."""
+    rs = np.random.RandomState(99)
+    twin = np.random.RandomState(99)
+    rs.randn(3); twin.randn(3)                          # odd count: one normal is cached
+    assert rs.get_state()[3] == 1
+    dev = fresh_rng()
+    dev.set_state(rs.get_state())
+    got = dev.randint(0, 5000, 256)                     # the learner phase draws indices on the device ...
+    assert np.array_equal(got, twin.randint(0, 5000, 256))
+    st = dev.get_state()
+    assert st[3] == 1 and st[4] == rs.get_state()[4]
+    rs.set_state(st)                                    # ... and numpy continues where the reference would be
+    assert np.array_equal(rs.randn(4), twin.randn(4))
+    dev.seed(5)
+    assert dev.get_state()[3] == 0
+
+
 def test_randint_errors_like_numpy():
     dev = fresh_rng(0)
     with pytest.raises(ValueError):

@@ -1,0 +1,271 @@
+"""Teacher-forced parity: EVERY update is held to the north-star bar, not just the first of a chain.
+
+A chained comparison lets two correct float32 trajectories separate (Adam divides by sqrt(v) ~ |g|), so beyond the first
+update it can only be an envelope.  Here the device is restarted from the oracle's exact state before every update --
+online parameters, target networks, Adam exp_avg / exp_avg_sq and step count (hp_agent_set_adam) -- then runs ONE sampled
+update (her.py:13-41 draw + gather on the device, ddpg_agent.py:250-277, torch.optim.Adam step t) and is compared with the
+oracle's update from the same state on the bit-identical minibatch, for 40 consecutive steps (Adam bias corrections of
+steps 1..40, polyak in between):
+
+    both losses     1e-5 relative                                   (BASELINE.json north_star)
+    gradients       1e-4 * max|g| absolute per network against the oracle, AND against the float64 gradient of the same
+                    state: device error <= 2 x the error of torch's own float32 gradient (+ 1e-6 max|g|) -- two float32
+                    gradients are each ~1e-5 max|g| from the exact one after a few steps, so their mutual distance says
+                    little; the distance to float64 says who is right
+    optimizer step  torch.optim.Adam ITSELF, loaded with the oracle's pre-step state and fed the DEVICE's gradient, must
+                    land within 1 float32 ulp of the parameter + 5e-10 (= 5e-7 of lr: torch's CPU kernels fuse some
+                    multiply-adds the device keeps apart) of the device's post-step parameters: pins m / v / bias-correction arithmetic of every step t, in every
+                    optimizer kernel (GEMM epilogue, k_adam_frag4, dw64 epilogue, k_peer_adam, k_peer_adam2)
+    parameters      5e-6 absolute against the ORACLE's post-step parameters on the well-conditioned elements
+                    (|g| >= 1% of max|g|), median 1e-7 over all elements
+
+A step that FAILS the gradient bar while a hidden unit's pre-activation on the differentiated path is below float32
+summation noise (|z| < 2e-7 in float64: ReLU' may take either value in a correct float32 implementation -- observed at step
+2 of batch 256: z = 5e-9, the device's gradient then differs by 5e-5 max|g| from torch's while both losses agree to 1e-7)
+is held to the loss and optimizer checks and a 2e-3 max|g| gradient bound; at most 3 of the 80 (step, network) pairs (12 at batch
+4096: 16x the pre-activations) may use that excuse.
+
+Why not 5e-6 on every element against the oracle: from step 2 on Adam's step is lr * m_hat / (sqrt(v_hat) + eps) with m, v
+mixing this gradient into the history; for an element whose gradient is at rounding level (|g| ~ 1e-9: sums that cancel)
+two correct float32 gradients differ by a large FRACTION of themselves, and the step moves by percents of lr = 1e-3
+(observed 4e-5 at step 2, batch 256).  Gradient-within-tolerance + optimizer-exact-given-the-gradient is the statement
+that holds for every element; it is what the three checks above assert together.
+
+Batch sizes of BASELINE configs 2 / 5 / 3-4 / 4096 with their default engines, and the data-parallel optimizer kernels
+in a 1-rank group."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import ENV_PARAMS, DeviceEpisodeBuffer, fresh_rng, state_equal
+from oracle import ddpg_update as oupd
+from oracle.her_replay import EpisodeStore, future_probability
+from oracle.running_norm import RunningNorm, update_normalizers
+from rl_arm_under_sparse_reward_amd import _lib
+from rl_arm_under_sparse_reward_amd.arguments import Args
+from rl_arm_under_sparse_reward_amd.ddpg_agent import (NET_ACTOR, NET_ACTOR_TARGET, NET_CRITIC, NET_CRITIC_TARGET,
+                                                        ddpg_agent)
+from rl_arm_under_sparse_reward_amd.synthetic import make_episodes
+
+pytestmark = pytest.mark.gpu
+LOSS_RTOL = 1e-5
+PARAM_ATOL = 5e-6
+RELU_NOISE = 2e-7       # |pre-activation| below which two float32 sums of ~300 O(0.1) terms can disagree on the sign
+ADAM_ULPS = 1.0         # in units of (1 ulp of the parameter + 5e-10), see below
+N_STEPS = 40
+
+
+def _adam_flat(optim, params):
+    """torch.optim.Adam state of the oracle in the flat order of utils.py:18-27 (zeros and step 0 before the first step)."""
+    m, v, step = [], [], 0
+    for p in params.values():
+        st = optim.state.get(p, {})
+        m.append(st["exp_avg"] if st else torch.zeros_like(p))
+        v.append(st["exp_avg_sq"] if st else torch.zeros_like(p))
+        step = int(st["step"]) if st else 0
+    return oupd.flatten(m), oupd.flatten(v), step
+
+
+class _AdamTwin:
+    """torch.optim.Adam carrying a copy of the oracle optimizer's state: step_with(flat_grad) applies ONE step of the real
+    third-party optimizer to that gradient and returns the flat parameters."""
+
+    def __init__(self, params, optim, lr):
+        self.params = [p.detach().clone().requires_grad_(True) for p in params.values()]
+        self.opt = torch.optim.Adam(self.params, lr=lr)
+        for mine, theirs in zip(self.params, params.values()):
+            st = optim.state.get(theirs, {})
+            if st:
+                self.opt.state[mine] = {"step": st["step"].clone(), "exp_avg": st["exp_avg"].clone(),
+                                        "exp_avg_sq": st["exp_avg_sq"].clone()}
+
+    def step_with(self, flat_grad):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = torch.from_numpy(np.ascontiguousarray(flat_grad[off:off + n])).reshape(p.shape).clone()
+            off += n
+        self.opt.step()
+        return oupd.flatten(self.params)
+
+
+def _f64_gradients(actor, critic, actor_t, critic_t, x, x_next, actions, r, max_action=0.5, gamma=0.98, action_l2=1.0):
+    """ddpg_agent.py:250-277 in float64 from the same float32 state and minibatch: the yardstick that says how far a CORRECT
+    float32 gradient (torch's) is from the exact one, element by element."""
+    A = {k: v.detach().double().requires_grad_(True) for k, v in actor.items()}
+    Cn = {k: v.detach().double().requires_grad_(True) for k, v in critic.items()}
+    AT = {k: v.detach().double() for k, v in actor_t.items()}
+    CT = {k: v.detach().double() for k, v in critic_t.items()}
+    x, x_next, actions, r = x.double(), x_next.double(), actions.double(), r.double()
+    with torch.no_grad():
+        q_next = oupd.critic_forward(CT, x_next, oupd.actor_forward(AT, x_next, max_action), max_action)
+        target_q = torch.clamp(r + gamma * q_next, -1 / (1 - gamma), 0)
+    critic_loss = (target_q - oupd.critic_forward(Cn, x, actions, max_action)).pow(2).mean()
+    a_real = oupd.actor_forward(A, x, max_action)
+    actor_loss = -oupd.critic_forward(Cn, x, a_real, max_action).mean() + action_l2 * (a_real / max_action).pow(2).mean()
+    ga = torch.autograd.grad(actor_loss, list(A.values()))
+    gc = torch.autograd.grad(critic_loss, list(Cn.values()))
+    flat = lambda ts: np.concatenate([t.detach().numpy().ravel() for t in ts])     # noqa: E731
+
+    # smallest |pre-activation| on each loss's differentiated path: ReLU' jumps at 0, so a hidden unit whose pre-activation
+    # is below float32 summation noise takes EITHER mask in a correct float32 implementation (and its whole row's
+    # gradient contribution moves by percents): such a step cannot be held to a rounding-level gradient bound
+    def min_preact(p, keys, h):
+        lo = float("inf")
+        for k in keys:
+            z = torch.nn.functional.linear(h, p[k + ".weight"], p[k + ".bias"])
+            lo = min(lo, float(z.abs().min()))
+            h = torch.relu(z)
+        return lo
+
+    with torch.no_grad():
+        xa = torch.cat([x, a_real / max_action], dim=1)
+        lo_actor = min(min_preact(A, ("fc1", "fc2", "fc3"), x), min_preact(Cn, ("fc1", "fc2", "fc3"), xa))
+        lo_critic = min_preact(Cn, ("fc1", "fc2", "fc3"), torch.cat([x, actions / max_action], dim=1))
+    return {"actor": flat(ga), "critic": flat(gc), "min_preact": {"actor": lo_actor, "critic": lo_critic}}
+
+
+def _teach(agent, learner):
+    """device state := oracle state (parameters, targets, optimizer moments, step count)."""
+    agent._set_flat(NET_ACTOR, learner.flat("actor"))
+    agent._set_flat(NET_CRITIC, learner.flat("critic"))
+    agent._set_flat(NET_ACTOR_TARGET, learner.flat("actor_target"))
+    agent._set_flat(NET_CRITIC_TARGET, learner.flat("critic_target"))
+    ma, va, sa = _adam_flat(learner.actor_optim, learner.actor)
+    mc, vc, sc = _adam_flat(learner.critic_optim, learner.critic)
+    assert sa == sc
+    agent.set_adam_state(NET_ACTOR, ma, va, sa)
+    agent.set_adam_state(NET_CRITIC, mc, vc, sc)
+    return sa
+
+
+def _run(batch, k, comm=None, n_steps=N_STEPS, n_eps=64):
+    torch.set_num_threads(4)
+    eps = make_episodes(n_eps, seed=3, mode="walk")
+    torch.manual_seed(0)
+    rng = fresh_rng(7)
+    agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100, replay_k=k), None, dict(ENV_PARAMS), comm=comm, rng=rng)
+    a0 = {kk: v.detach().clone() for kk, v in agent.actor_network.state_dict().items()}
+    c0 = {kk: v.detach().clone() for kk, v in agent.critic_network.state_dict().items()}
+    learner = oupd.DDPGLearner(a0, c0)
+    rs = np.random.RandomState(7)
+    st = EpisodeStore(100, 27, 3, 4, n_eps * 100)
+    fp = future_probability("future", k)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    st.store_episode(eps, rs)
+    agent.buffer.store_episode(eps)
+    two = [a[-2:] for a in eps]
+    scratch = DeviceEpisodeBuffer(2, 100, 27, 3, 4)
+    scratch.store(rng, two)
+    _lib.check(agent.lib.hp_norm_update_from_staged(scratch.h, rng.h, agent.o_norm.h, agent.g_norm.h, fp, 200.0))
+    agent.o_norm.recompute_stats(); agent.g_norm.recompute_stats()
+    update_normalizers(on, gn, two, fp, rs)
+    worst_loss, worst_param, worst_grad, worst_adam, worst_vs64, n_ambiguous = 0.0, 0.0, 0.0, 0.0, 0.0, 0
+    for i in range(n_steps):
+        step = _teach(agent, learner)
+        assert step == i
+        m_dev, v_dev, s_dev = agent.get_adam_state(NET_CRITIC)       # the hook round-trips (pack/unpack is lossless)
+        assert s_dev == i and np.array_equal(m_dev, _adam_flat(learner.critic_optim, learner.critic)[0])
+        twins = {"actor": _AdamTwin(learner.actor, learner.actor_optim, 1e-3),
+                 "critic": _AdamTwin(learner.critic, learner.critic_optim, 1e-3)}     # oracle state BEFORE the step
+        agent._update_network(1)
+        got = agent.last_losses(1)[0]
+        tr, _ = st.sample(batch, fp, rs)
+        mb = oupd.minibatch_tensors(tr, on, gn)
+        g64 = _f64_gradients(learner.actor, learner.critic, learner.actor_target, learner.critic_target, *mb)
+        res = learner.update(*mb)
+        for j, name in enumerate(("actor_loss", "critic_loss")):
+            rel = abs(float(got[j]) - res[name]) / max(abs(res[name]), 1e-3)
+            worst_loss = max(worst_loss, rel)
+            assert rel <= LOSS_RTOL, (i, name, got[j], res[name], rel)
+        for slot, name in ((NET_ACTOR, "actor"), (NET_CRITIC, "critic")):
+            g_ref = res[f"{name}_grads"].astype(np.float64)
+            g_dev = agent.get_flat_grads(slot)
+            gmax = float(np.abs(g_ref).max())
+            gerr = float(np.max(np.abs(g_dev - g_ref)))
+            # ... and both against the float64 gradient of the same state: the device may not be further from the exact
+            # gradient than 2x what torch's own float32 arithmetic is (+ 1e-6 max|g| of slack for the luck of one draw)
+            dev64, ref64 = float(np.max(np.abs(g_dev - g64[name]))), float(np.max(np.abs(g_ref - g64[name])))
+            strict = gerr <= 1e-4 * gmax and dev64 <= 2.0 * ref64 + 1e-6 * gmax
+            # a ReLU mask may legitimately differ (see _f64_gradients) -- but only a step that HAS a pre-activation inside
+            # float32 summation noise may use that excuse, and only when the strict bar actually failed
+            ambiguous = (not strict) and g64["min_preact"][name] < RELU_NOISE
+            n_ambiguous += int(ambiguous)
+            if not ambiguous:
+                worst_grad = max(worst_grad, gerr / gmax)
+                worst_vs64 = max(worst_vs64, dev64 / max(ref64, 1e-30))
+                assert gerr <= 1e-4 * gmax, (i, name, "grad vs oracle", gerr, gmax)
+                assert dev64 <= 2.0 * ref64 + 1e-6 * gmax, (i, name, "grad vs float64", dev64, ref64, gmax)
+            else:       # one row's contribution through one unit: a few percent of 1/B of the gradient
+                assert gerr <= 2e-3 * gmax, (i, name, "grad vs oracle (ReLU tie)", gerr, gmax, g64["min_preact"][name])
+            p_dev32 = agent._get_flat(slot)
+            p_twin32 = twins[name].step_with(g_dev)                          # torch.optim.Adam on the device's gradient
+            p_dev = p_dev32.astype(np.float64)
+            # allowed: one ulp of the parameter (final rounding of p + step) + 5e-7 of the step size lr (the step itself is
+            # ~6 float32 operations, and torch's CPU kernels fuse some multiply-adds the device keeps apart): 5e-10
+            allowed = np.spacing(np.abs(p_twin32)).astype(np.float64) + 5e-7 * 1e-3
+            ulps = np.abs(p_dev - p_twin32.astype(np.float64)) / allowed
+            aerr = float(ulps.max())
+            worst_adam = max(worst_adam, aerr)
+            assert aerr <= ADAM_ULPS, (i, name, "adam", aerr)
+            p_ref = learner.flat(name).astype(np.float64)
+            well = np.abs(g_ref) >= 1e-2 * gmax
+            err = float(np.max(np.abs(p_dev - p_ref)[well]))
+            if not ambiguous:
+                worst_param = max(worst_param, err)
+                assert err <= PARAM_ATOL, (i, name, "param", err, int(well.sum()))
+            assert float(np.median(np.abs(p_dev - p_ref))) <= 1e-7, (i, name)
+        assert agent.get_adam_state(NET_ACTOR)[2] == i + 1
+        if i % 10 == 9:            # ddpg_agent.py:149-150 every so often, so that targets != online nets in later steps
+            agent._soft_update_target_network(); learner.soft_update()
+            tgt = agent._get_flat(NET_CRITIC_TARGET).astype(np.float64)
+            assert float(np.max(np.abs(tgt - learner.flat("critic_target")))) <= PARAM_ATOL
+    assert state_equal(rng, *rs.get_state()[1:3])              # the sampler consumed exactly the oracle's words
+    # of 2 x 40 (step, network) pairs: ties that flip a mask are rare events, not an excuse -- their number grows with the
+    # number of pre-activations per update, i.e. with the batch (observed: 1 at batch 256, 9 at 4096)
+    assert n_ambiguous <= 3 * max(1, batch // 1024), n_ambiguous
+    return (worst_loss, worst_grad, worst_adam, worst_param, worst_vs64, n_ambiguous), agent
+
+
+@pytest.mark.parametrize("batch,k", [(256, 4), (512, 8), (1024, 4), (4096, 4)],
+                         ids=["config2_b256", "config5_b512_k8", "config3_4_b1024", "b4096"])
+def test_every_update_meets_the_north_star_bar_single_rank(batch, k, monkeypatch):
+    monkeypatch.setenv("RLARM_KEEP_GRADS", "1")      # the optimizer epilogues also write the gradient out (read by hp_agent_create)
+    worst, agent = _run(batch, k)
+    print(f"teacher-forced batch {batch} k {k} engine {agent.engine()}: worst over 40 steps: loss rel {worst[0]:.2e}, "
+          f"grad / max|g| {worst[1]:.2e} (error vs float64 = {worst[4]:.2f} x torch float32's), optimizer vs torch.optim.Adam {worst[2]:.2f} x (1 ulp + 5e-10), well-conditioned param {worst[3]:.2e}")
+
+
+@pytest.mark.parametrize("transport", ["peer", "peer+2phase", "native", "torch"])
+def test_every_update_meets_the_bar_through_the_data_parallel_optimizer(transport, monkeypatch):
+    """1-rank group, forced exchange: backward -> exchange -> separate optimizer kernel (k_peer_adam; k_peer_reduce_slice +
+    k_peer_adam2; RCCL + k_adam_frag4; torch.distributed + hp_agent_apply), the kernels every rank of a multi-GPU job runs."""
+    import torch.distributed as dist
+    from rl_arm_under_sparse_reward_amd.utils import Communicator
+    if transport.endswith("+2phase"):
+        transport = transport[:-7]
+        monkeypatch.setenv("RLARM_PEER_PHASES", "2")
+    monkeypatch.setenv("RLARM_COMM", transport)
+    monkeypatch.setenv("RLARM_KEEP_GRADS", "1")      # the peer optimizer kernels write the exchanged sum out for get_grads
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = None
+    try:
+        comm = Communicator(0, force=True)
+        worst, agent = _run(256, 4, comm=comm)
+        assert (agent._peer is not None) == (transport == "peer")
+        assert (agent._native_comm is not None) == (transport == "native")
+        _lib.Context.default().synchronize()
+        torch.cuda.synchronize()
+        agent.close_comm()
+        del agent
+    finally:
+        if comm is not None:
+            comm.close()
+        _lib.Context.default().set_stream(None)
+        dist.destroy_process_group()

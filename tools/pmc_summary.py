@@ -6,9 +6,24 @@ pass, tools/gpu_pmc.sh) -> text table on stdout and, with --json PATH, the per-l
 
 MI355X_MICROARCH.md: both counters report KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their
 bytes (x2 correction applied in hbm_bytes_per_launch), WRITE_SIZE is uncalibrated."""
+import glob
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources the counters were taken on (bench.py recomputes it and marks the traffic figure
+    stale when the sources have changed since)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rl_arm_under_sparse_reward_amd", "csrc")
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path):
@@ -49,7 +64,7 @@ def main():
                                  "-- python bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-profile; " + note,
                        "units": "KiB per launch as reported; MI355X_MICROARCH.md: FETCH_SIZE counts wide coalesced reads at "
                                 "half their bytes on gfx950 (x2 correction applied in hbm_bytes_per_launch), WRITE_SIZE "
-                                "uncalibrated", "kernels": kernels}, f, indent=1)
+                                "uncalibrated", "csrc_sha16": csrc_sha16(), "kernels": kernels}, f, indent=1)
         print("wrote", out_json)
 
 
