@@ -536,7 +536,7 @@ def main():
         # overhead inside.  rocprofv3 kernel durations of the same command (profiles/) are that minus the boundary.
         ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
         eng = r.agent.engine()
-        chain_kernel = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32", "slab16": "k_fwd_slab + k_bwd_slab"}.get(eng["engine"], "k_gemm_group")
+        chain_kernel = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32"}.get(eng["engine"], "k_gemm_group")
         dw_kernel = "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam"
         kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
         # HBM traffic needs rocprofv3 --pmc passes around the process (tools/gpu_round3.sh), so it cannot be measured from
@@ -581,7 +581,7 @@ def main():
             # an event pair with nothing in between reads on this stack
             live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
             if name == "chain":
-                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fb_slab32", "k_fwd_slab", "k_bwd_slab"))
+                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fb_slab32"))
             else:   # the ride-along variant runs on all but the last updates of a cycle
                 rp = prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam", 0.0)
             used = max(live, rp)

@@ -345,19 +345,15 @@ int hp_agent_train_cycle(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm 
 /* timing hook for bench.py: average device time (ms) of the kernels tagged `which` over the
  * last recorded region; see DESIGN.md "Measurement". */
 /* diagnostic: microseconds per launch of ONE stage of the update, repeated n times in a captured
- * hipGraph (kind: 0 loss, 1 actor head, 2 forward hidden level, 3 forward first level, 4 q heads,
- * 5 backward hidden level, 6 adam, 8 polyak) -- the per-stage numbers quoted in DESIGN.md */
+ * hipGraph (kind: 6 optimizer kernel, 8 polyak, 10 forward + backward of the active engine, 11 its chain kernel only,
+ * 12 its weight-gradient launch + optimizer only) -- the per-stage numbers quoted in DESIGN.md / bench.py */
 int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_launch);
 /* diagnostic: stage-boundary time stamps (100 MHz ticks) of the slab kernels; only a build with
  * -DSLAB_TIMELINE writes them (tools/ubench/), a production build returns zeros */
 int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);
-/* diagnostic: number of single-launch updates issued so far (chain kernel with the weight-gradient tiles and the
- * optimizer as its second phase) and the sticky error word of their in-kernel hand-off (0 in a healthy run).
- * Synchronises. */
-int hp_agent_fused_status(hp_agent *ag, int64_t *fused_launches, uint32_t *error);
 /* Which kernels hp_agent_sample_and_update / hp_agent_train_cycle run for this agent (chosen at creation from the batch
- * size and the RLARM_* switches): *engine = 0 layer-per-launch, 8 thin row slabs (slab8.h, *slab_rows = 4 / 8 / 16), 16
- * two-kernel 16-row slabs (slab.h), 32 the 32-row engine (slab32.h); *dw_split = 0 for 32 x 32 weight-gradient tiles
+ * size and the RLARM_* switches): *engine = 0 layer-per-launch, 8 thin row slabs (slab8.h, *slab_rows = 4 / 8 / 16),
+ * 32 the 32-row engine (slab32.h); *dw_split = 0 for 32 x 32 weight-gradient tiles
  * (gemm_lds.h), else the number of batch-row slices per 64 x 64 tile (dw64.h).  Any pointer may be null. */
 int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *dw_split);
 int hp_agent_profile(hp_agent *ag, int32_t enable);

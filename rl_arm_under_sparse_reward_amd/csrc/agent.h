@@ -1,0 +1,334 @@
+// agent.h -- the DDPG learner's host-side state and the declarations its translation units share (library-internal, not
+// part of the C ABI):
+//   agent.hip           lifecycle, parameter / optimizer-state access, update sequences, the cycle hipGraph, C ABI
+//   agent_engines.hip   the row-slab engines (slab8.h, slab32.h), weight-gradient launches (gemm_lds.h, dw64.h), optimizer
+//                       and exchange kernels, forward-only entry points
+//   agent_layers.hip    layer-per-launch fallback engine for network shapes the slab engines do not cover
+// Reference: models.py:11-44, ddpg_agent.py:214-277, torch.optim.Adam (ddpg_agent.py:42-43).
+//
+// ---- HBM layout ------------------------------------------------------------------------
+// Parameter "arena" (float32): [actor | critic], each  W1[H][K1] b1[H] W2[H][H] b2[H] W3[H][H]
+// b3[H] W4[16][H] b4[16];  K1 = 32 for the actor, 48 for the critic, rows/cols beyond the real
+// sizes are zero and stay zero (their gradients are exactly zero).  Gradients, Adam m, Adam v
+// and the target networks use the same layout, so Adam and polyak are one elementwise pass.
+// Network inputs are rows of 48 floats: [ x (obs+goal = 30) | 0 0 | a/max_action (4) | 0.. ]:
+// the actor reads columns 0..31, the critic 0..47 (its W1 columns are permuted to match).
+#pragma once
+#include "internal.h"
+
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// engine geometry the host logic needs (the kernels' own headers define the rest)
+#define S8_AHEAD_WGS 4                 // slab8.h: spare workgroups that gather the next update's inputs (2 and 8 measured the same or slower)
+#define S32_ROWS 32                    // slab32.h: rows of a slab
+#define DW_PART (64 * 64 + 64)         // dw64.h: floats of one partial tile in the exchange buffer (accumulators | column sums of dY)
+
+// ------------------------------------------------------------------------------- structures
+struct NetLayout {     // offsets in floats inside one net's arena segment
+    int K1;            // padded input width (multiple of 16)
+    int w1, b1, w2, b2, w3, b3, w4, b4, total;
+};
+
+enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_BIAS = 2, EPI_BIAS_TANH = 3, EPI_MASK = 4 };
+
+struct GemmProb {
+    const float *A, *B;
+    float *C;
+    const float *bias;   // EPI_BIAS*
+    const float *mask;   // EPI_MASK: gate on mask[m][n] > 0
+    float *bias_grad;    // non-null: also emit column sums of the A operand (db) from tile column 0
+    float *C2;           // EPI_BIAS_TANH: raw tanh output (needed by the backward pass)
+    int a_si, a_sk;      // A element strides: output-row index / reduction index
+    int b_sj, b_sk;      // B element strides: output-col index / reduction index
+    int ldc, ldmask, ldc2;
+    int M, N, K;         // output rows, output cols (multiples of 16), reduction length (multiple of 16)
+    int n_store;         // only columns < n_store are written
+    int epi;
+    int tile0, tiles_n;  // first workgroup of this problem, tiles along N
+    float max_action;    // EPI_BIAS_TANH
+};
+
+#define MAX_PROBS 8
+struct GemmGroup {
+    int n;
+    int pipe;   // per-wave LDS-DMA rings for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: workgroup-staged chunks, for A/B)
+    int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
+    int pad_;
+    GemmProb p[MAX_PROBS];
+};
+
+struct Pass {  // hidden activations of one forward pass
+    float *h1, *h2, *h3;
+};
+
+struct AgentDevState {      // small device-resident scalars
+    long long step;         // Adam step counter (both optimizers step together)
+    long long n_logged;     // number of loss pairs written
+    // per-step Adam scalars (torch computes them in Python doubles and narrows where used)
+    float neg_step_actor, neg_step_critic, bc2_sqrt, pad;
+};
+
+struct AdamCfg {
+    double lr_actor, lr_critic, beta1, beta2, eps;
+};
+
+// bias corrections of torch.optim.Adam for the step that is about to be applied
+__device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c) {
+    const double step = (double)st->step;
+    const double bc1 = 1.0 - pow(c.beta1, step);
+    const double bc2 = 1.0 - pow(c.beta2, step);
+    st->neg_step_actor = (float)(-(c.lr_actor / bc1));
+    st->neg_step_critic = (float)(-(c.lr_critic / bc1));
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+
+#define LOSS_LOG 4096
+
+#include "slab_common.h"
+#include "peer.h"
+
+enum { PROF_SAMPLE = 0, PROF_GEMM_FWD = 1, PROF_GEMM_BWD = 2, PROF_LOSS = 3, PROF_ADAM = 4, PROF_PLAN = 5, PROF_DW = 6, PROF_N = 7 };
+
+struct hp_agent {
+    hp_ctx *ctx = nullptr;
+    hp_agent_cfg cfg;
+    int H = 256, B = 0, Mp = 0;
+    int xdim = 0, act_off = 0, ldx = 0;  // obs+goal, column of the action block, row stride of X buffers
+    NetLayout la, lc;                    // actor / critic layouts; critic segment starts at la.total
+    int n_arena = 0;
+    float *params = nullptr, *targets = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float *XA = nullptr, *XP = nullptr, *XT = nullptr, *R = nullptr, *TP = nullptr;
+    float *XA2 = nullptr, *XP2 = nullptr, *XT2 = nullptr, *R2 = nullptr;   // second input set (gather-ahead ping-pong)
+    Pass AT, CT, CA, AP, CP;
+    float *QT = nullptr, *QA = nullptr, *QP = nullptr, *dQA = nullptr, *dQP = nullptr;
+    float *dA3 = nullptr, *dA2 = nullptr, *dA1 = nullptr;  // critic-loss path
+    float *dP3 = nullptr, *dP2 = nullptr, *dP1 = nullptr, *dXP = nullptr;  // actor-loss path through the critic
+    float *dZ = nullptr, *dK3 = nullptr, *dK2 = nullptr, *dK1 = nullptr;   // actor
+    float *loss_log = nullptr;
+    AgentDevState *d_state = nullptr;
+    // row-slab engine: fragment-ordered weight copies (online forward / online dX / target forward), loss partials
+    float *fragF = nullptr, *fragD = nullptr, *fragFT = nullptr, *part = nullptr;
+    unsigned long long *timeline = nullptr;   // debug builds (SLAB_TIMELINE) stamp stage boundaries here
+    bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
+    bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: slab32)
+    bool slab32 = false;   // 32-row slabs on the 32x32x2 MFMA, forward + backward in one kernel (slab32.h: large batches)
+    int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
+    bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
+    // A/B switches, read once in hp_agent_create: RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD, RLARM_FB_PREFETCH (-1 = by size,
+    // 0 = off, 1 = on)
+    bool gemm_xcd = true;
+    int fb_xcd = -1, fb_prefetch = -1;
+    // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
+    bool dw64 = false;                   // RLARM_DW64: default from batch 1536
+    int dw_S = 3;                        // RLARM_DW_SPLIT
+    DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
+    bool keep_grads_dbg = false;   // RLARM_KEEP_GRADS=1 (parity tests): the peer optimizer kernels also write the summed gradients out
+    bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
+    bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
+    DevBuf plan, norm_plan;
+    int plan_batches = 0;
+    DevBuf fwd_ws;          // actor_forward scratch
+    // policy snapshots for a feeder that steps environments while cycles run (hp_agent_policy_snapshot / _act_snapshot)
+    struct PolicySnap {
+        float *params = nullptr, *fragF = nullptr;   // actor segment of the arenas
+        NormDev *on = nullptr, *gn = nullptr;
+        double clip_o = 0, clip_g = 0;
+        int od = 0, gd = 0;
+        hipEvent_t ready = nullptr;
+    } snap[2];
+    int snap_cur = -1, snap_pending = -1;
+    // index plans of later updates drawn on a second stream, concurrently with the chain kernel, when the launch has no
+    // spare CU for a ride-along plan workgroup (enqueue_updates)
+    hipStream_t plan_stream = nullptr;
+    hipEvent_t plan_fork = nullptr, plan_join = nullptr;
+    int plan_side = -1;                  // RLARM_PLAN_SIDE: -1 by occupancy, 0 never, 1 always
+    hipStream_t act_stream = nullptr;
+    hipEvent_t act_done = nullptr;
+    bool act_recorded = false;
+    DevBuf act_ws;
+    PinnedBuf pin;
+    std::vector<void *> owned;
+    // rank exchange inside the library (hp_agent_set_comm); nullptr: single rank, or the caller exchanges
+    hp_comm *comm = nullptr;
+    hp_peer *peer = nullptr;      // one-shot exchange over peer memory (hp_agent_set_peer); takes precedence over comm
+    bool grad_mean = false;       // divide the all-reduced gradients by the world size (default: SUM, like the reference)
+    bool comm_warm = false;       // the collectives of a cycle have each run once outside a capture
+    bool graph_refused = false;   // capturing the cycle with collectives failed once: stay on eager launches
+    // graphs of hp_agent_sample_and_update(n_updates), one per distinct argument set (a training loop that does not use
+    // hp_agent_train_cycle replays its inner loop instead of issuing 2 launches per update)
+    struct UpdGraph {
+        hipGraphExec_t exec;
+        int n_updates;
+        hp_buffer *b;
+        hp_norm *on, *gn;
+        hp_rng *rng;
+        double future_p, sq;
+    };
+    std::vector<UpdGraph> upd_graphs;
+    // cycle graph cache
+    hipGraphExec_t graph = nullptr;
+    hp_buffer *g_buf = nullptr;
+    hp_norm *g_on = nullptr, *g_gn = nullptr;
+    hp_rng *g_rng = nullptr;
+    int64_t g_n_new = -1;
+    int g_n_batches = -1;
+    double g_future_p = -1, g_sq = -1;
+    void *g_stage = nullptr;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double prof_ms[PROF_N] = {0};
+    long long prof_cnt[PROF_N] = {0};
+    long long host_steps = 0;
+};
+
+
+// ------------------------------------------------------------------------------- host-side helpers
+static inline AdamCfg adam_cfg(const hp_agent *a) {
+    return AdamCfg{a->cfg.lr_actor, a->cfg.lr_critic, a->cfg.adam_beta1, a->cfg.adam_beta2, a->cfg.adam_eps};
+}
+
+static inline NetLayout make_layout(int K1, int H) {
+    NetLayout l;
+    l.K1 = K1;
+    int o = 0;
+    l.w1 = o; o += H * K1;
+    l.b1 = o; o += H;
+    l.w2 = o; o += H * H;
+    l.b2 = o; o += H;
+    l.w3 = o; o += H * H;
+    l.b3 = o; o += H;
+    l.w4 = o; o += 16 * H;
+    l.b4 = o; o += 16;
+    l.total = o;
+    return l;
+}
+
+static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Launch {  // builds one grouped launch
+    GemmGroup g;
+    int tiles = 0;
+    Launch() {
+        g.n = 0;
+        g.xcd = 0;
+        g.pad_ = 0;
+    }
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and everything a weight-gradient tile reads
+    // was written by the previous kernel on other XCDs: it comes through the fabric once per XCD that touches it.  In
+    // row-major tile order every XCD reads 9 of the 16 operand panels of every problem (6.75 x the unique bytes in
+    // total); with one 256 x 256 problem per pair of XCDs (half of the row panels each) the fabric carries 1.5 x.
+    void place_on_xcds() {
+        if (g.n < 4) return;
+        for (int i = 0; i < 4; ++i)
+            if (g.p[i].tiles_n != 8 || g.p[i].M != 256 || g.p[i].tile0 != 64 * i) return;
+        g.xcd = 1;
+    }
+    GemmProb &add(int M, int N, int K) {
+        GemmProb &p = g.p[g.n++];
+        memset(&p, 0, sizeof(p));
+        p.M = M; p.N = N; p.K = K;
+        p.n_store = N;
+        p.tiles_n = (N + 31) / 32;
+        p.tile0 = tiles;
+        tiles += ((M + 31) / 32) * p.tiles_n;
+        return p;
+    }
+};
+
+struct ProfScope {
+    hp_agent *a;
+    int which;
+    ProfScope(hp_agent *ag, int w) : a(ag), which(w) {
+        if (a->prof) (void)hipEventRecord(a->ev0, a->ctx->stream);
+    }
+    ~ProfScope() {
+        if (a->prof) {
+            (void)hipEventRecord(a->ev1, a->ctx->stream);
+            (void)hipEventSynchronize(a->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, a->ev0, a->ev1);
+            a->prof_ms[which] += ms;
+            a->prof_cnt[which] += 1;
+        }
+    }
+};
+
+// forward layer Y = act(X W^T + b)
+static inline void add_fwd(Launch &L, const float *X, int ldx, int K, const float *W, const float *bias, float *Y, int ldy,
+                    int M, int N, int epi) {
+    GemmProb &p = L.add(M, N, K);
+    p.A = X; p.a_si = ldx; p.a_sk = 1;
+    p.B = W; p.b_sj = K; p.b_sk = 1;
+    p.C = Y; p.ldc = ldy;
+    p.bias = bias;
+    p.epi = epi;
+}
+
+// dX = (dY W) * relu'(gate)
+static inline void add_dx(Launch &L, const float *dY, int ldy, int Nout, const float *W, int Kin, float *dX, int lddx, int M,
+                   const float *gate, int ldgate) {
+    GemmProb &p = L.add(M, Kin, Nout);
+    p.A = dY; p.a_si = ldy; p.a_sk = 1;
+    p.B = W; p.b_sj = 1; p.b_sk = Kin;
+    p.C = dX; p.ldc = lddx;
+    p.mask = gate; p.ldmask = ldgate;
+    p.epi = gate ? EPI_MASK : EPI_NONE;
+}
+
+// dW = dY^T X, db = column sums of dY
+static inline void add_dw(Launch &L, const float *dY, int ldy, int Nout, const float *X, int ldx, int Kin, float *dW,
+                   float *db, int Mrows) {
+    GemmProb &p = L.add(Nout, Kin, Mrows);
+    p.A = dY; p.a_si = 1; p.a_sk = ldy;
+    p.B = X; p.b_sj = 1; p.b_sk = ldx;
+    p.C = dW; p.ldc = Kin;
+    p.bias_grad = db;
+    p.epi = EPI_NONE;
+}
+
+struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs already staged in XA/XP/XT/R)
+    hp_buffer *b;
+    hp_norm *on, *gn;
+    const PlanRec *plan;
+    double sq;
+    // slab engine: draw a LATER update's index plan in a spare workgroup of this update's kernel
+    hp_rng *rng = nullptr;
+    PlanRec *next_plan = nullptr;
+    double future_p = 0.0;
+    // merged slab8 kernel: input sets ping-pong between updates.  xset = the set this update reads (and, when it
+    // gathers in-kernel, writes); pregathered = a previous launch already filled it; ahead_plan = plan of the NEXT
+    // update, gathered by spare workgroups of this launch into the other set.
+    int xset = 0;
+    bool pregathered = false;
+    const PlanRec *ahead_plan = nullptr;
+    // full chain launch: the plan draw (next_plan) and the look-ahead gather (ahead_plan) ride in the weight-gradient
+    // launch instead of the chain kernel
+    bool ride_in_dw = false;
+    // data-parallel ranks exchanging through peer memory: this update's gradients go straight into the exchange buffer
+    float *grads_out = nullptr;
+};
+
+// ---- defined in agent_engines.hip
+int launch_group(hp_agent *a, const Launch &L, int which);                       // one grouped k_gemm_lds launch
+int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq, int xset = 0,
+                   hipStream_t stream = nullptr);
+int enqueue_relayout(hp_agent *a, bool targets);
+Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, float *grads = nullptr);
+// forwards + losses + backwards of one update.  Inputs: gc == nullptr -> already in XA/XP/XT/R (minibatch API), else sampled
+// (HER gather fused into the chain kernel / k_gather_fused).  fuse_adam: the caller wants the optimizer step applied too;
+// the slab engines then do it in the weight-gradient launch's epilogue and the caller must NOT enqueue Adam again (*fused).
+int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fuse_adam = false, bool *fused = nullptr);
+// only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
+int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
+int enqueue_adam(hp_agent *a);
+int enqueue_polyak(hp_agent *a);
+// utils.sync_grads (utils.py:43-48) + both Adam steps of update u as the peer exchange's optimizer kernel(s) (peer.hip)
+int enqueue_peer_adam(hp_agent *a, int u);
+// ---- defined in agent_layers.hip
+int enqueue_forward_backward_layers(hp_agent *a);
+int layers_enqueue_adam(hp_agent *a);
+int layers_enqueue_polyak(hp_agent *a);

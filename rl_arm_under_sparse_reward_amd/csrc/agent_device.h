@@ -1,0 +1,133 @@
+// agent_device.h -- device-side optimizer / loss-log helpers shared by the kernels of agent_engines.hip
+// (gemm_lds.h and dw64.h epilogues, k_adam_frag*, k_peer_adam*).
+#pragma once
+#include "agent.h"
+
+// canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases
+__host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
+__host__ __device__ __forceinline__ void frag32_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
+
+__host__ __device__ __forceinline__ void frag_offsets_any(const ArenaMap &am, int idx, int &off_f, int &off_d) {
+    if (am.mode == 2) frag32_offsets(am, idx, off_f, off_d);
+    else frag8_offsets(am, idx, off_f, off_d);
+}
+
+// Adam (torch.optim.Adam, _single_tensor_adam, no weight decay / amsgrad) on one arena element, plus the
+// fragment-ordered copies of the slab engines.  Shared by k_adam_frag and the weight-gradient GEMM epilogue
+// (single-rank runs fuse the optimizer into the GEMM; data-parallel runs all-reduce the gradients in between).
+struct AdamFuse {
+    const float *p;                   // parameters the step starts from (canonical arena)
+    float *p_out;                     // ... and where the stepped parameters go (p itself)
+    float *m, *v, *fragF, *fragD;     // fragF / fragD: fragment-ordered copies of p_out
+    const float *grads_base;          // arena origin of the gradient buffer the GEMM writes
+    AgentDevState *st;
+    const float *scal;                // {-lr_actor / bc1, -lr_critic / bc1, sqrt(bc2)} of the step being applied: the three
+                                      // scalars in *st, written by the chain kernel of the same update
+    ArenaMap am;
+    int n_actor;
+    float w, b2, omb2, eps;
+    const float *part;                // per-slab loss partials
+    int nslab, B, act_dim;
+    float action_l2;
+    float *loss_log;
+    int keep_grads;                   // also write the gradient out (the fused epilogue itself does not need it in memory)
+};
+
+__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
+    const float neg_step_size = F.scal[idx < F.n_actor ? 0 : 1];
+    const float bc2_sqrt = F.scal[2];
+    float mi = F.m[idx], vi = F.v[idx];
+    mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
+    vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
+    const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
+    const float pn = __fadd_rn(F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
+    F.p_out[idx] = pn;
+    F.m[idx] = mi;
+    F.v[idx] = vi;
+    int of, od;
+    frag_offsets_any(F.am, idx, of, od);
+    if (of >= 0) F.fragF[of] = pn;
+    if (od >= 0) F.fragD[od] = pn;
+}
+
+// four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
+// latency of p / m / v is paid once, not once per element (scalar version: the store to p[idx] may alias the next
+// element's load, which serialises them)
+struct AdamState4 {   // optimizer state of 4 consecutive elements + the step scalars, fetched ahead of the gradient
+    float4 p, m, v;
+    float neg_step_size, bc2_sqrt;
+};
+__device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, int idx0) {
+    S.neg_step_size = F.scal[idx0 < F.n_actor ? 0 : 1];
+    S.bc2_sqrt = F.scal[2];
+    S.p = *reinterpret_cast<const float4 *>(F.p + idx0);
+    S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
+    S.v = *reinterpret_cast<const float4 *>(F.v + idx0);
+}
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S);
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
+    AdamState4 S;
+    adam_fetch4(S, F, idx0);
+    adam_apply4(F, idx0, g, S);
+}
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S) {
+    const float neg_step_size = S.neg_step_size;
+    const float bc2_sqrt = S.bc2_sqrt;
+    const float4 p4 = S.p, m4 = S.m, v4 = S.v;
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mm[j] = __fadd_rn(mm[j], __fmul_rn(F.w, __fsub_rn(g[j], mm[j])));
+        vv[j] = __fadd_rn(__fmul_rn(vv[j], F.b2), __fmul_rn(__fmul_rn(F.omb2, g[j]), g[j]));
+        const float sq = __fsqrt_rn(vv[j]);
+        const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
+        pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(neg_step_size, mm[j]), denom));
+    }
+    *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (F.am.mode == 1 || F.am.mode == 2) {
+        // slab8 / slab32 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's
+        // row length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
+        int of, od;
+        if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
+        else frag32_offsets(F.am, idx0, of, od);
+        if (of >= 0) *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (od >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) F.fragD[od + 4 * j] = pp[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int of, od;
+            frag_offsets_any(F.am, idx0 + j, of, od);
+            if (of >= 0) F.fragF[of] = pp[j];
+            if (od >= 0) F.fragD[od] = pp[j];
+        }
+    }
+}
+
+// loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic)
+__device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
+    const int lane = threadIdx.x;
+    float tc = 0.f, tq = 0.f, tl = 0.f;
+    for (int s = lane; s < F.nslab; s += 64) {   // agent-scope loads of write-through stores of the chain kernel
+        tc += __hip_atomic_load(F.part + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tq += __hip_atomic_load(F.part + F.nslab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tl += __hip_atomic_load(F.part + 2 * F.nslab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        tc += __shfl_down(tc, o);
+        tq += __shfl_down(tq, o);
+        tl += __shfl_down(tl, o);
+    }
+    if (lane == 0) {
+        const float invB = 1.0f / (float)F.B;
+        const long long k = F.st->n_logged;
+        F.loss_log[(k % LOSS_LOG) * 2 + 0] = -(tq * invB) + F.action_l2 * (tl / (float)(F.B * F.act_dim));
+        F.loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
+        F.st->n_logged = k + 1;
+    }
+}

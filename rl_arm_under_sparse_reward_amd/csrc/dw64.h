@@ -25,7 +25,6 @@
 #define DW_BLK 512                     // floats of one ring block: 4 rows x 64 columns of A, then of B
 #define DW_RING 4                      // blocks per wave (power of two): 3 in flight
 #define DW_LDS_FLOATS (8 * DW_RING * DW_BLK + 4 * 64)   // rings (64 KB; later the partial tiles) + column sums
-#define DW_PART (64 * 64 + 64)         // floats of one partial tile in the exchange buffer: accumulators | column sums of dY
 #define DW_RED_LD 68                   // floats per row of a quarter in LDS (16-byte aligned rows, 3 x 64 x 68 x 4 B = 52 KB)
 
 #ifdef SLAB_TIMELINE   // debug build: first and last tile workgroup stamp the 100 MHz wall clock (g_gemm_tl of gemm_lds.h)
@@ -49,7 +48,7 @@ struct Dw64Args {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 // one LDS-DMA wave instruction: 64 lanes x 16 B -> 1 KB at `dst` (4 rows of 64 floats).  Inline assembly for the reason
-// given at gl_stage_kmajor_async: the compiler would drain the transfer in front of the next LDS read.
+// given at gl_dma (gemm_lds.h): the compiler would drain the transfer in front of the next LDS read.
 __device__ __forceinline__ void dw_dma(float *dst, const float *src) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");

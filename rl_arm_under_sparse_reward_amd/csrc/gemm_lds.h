@@ -41,7 +41,6 @@ __device__ unsigned long long g_gemm_tl[32];
 #endif
 
 // stage one 32 x kc operand chunk into LDS.  `valid` = number of real rows/cols (16 or 32).
-template <int AUX = 0>
 __device__ __forceinline__ void gl_stage(float *lds, const float *base, long long s_idx, long long s_k, int valid,
                                          int kc, bool rowk) {
     const int tid = threadIdx.x;
@@ -68,8 +67,7 @@ __device__ __forceinline__ void gl_stage(float *lds, const float *base, long lon
             const int k = rowp ^ ((rowp >> 3) & 1);
             int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
             gch = gch < nchunk ? gch : nchunk - 1;
-            // AUX = 16 (sc1): operands another workgroup of the SAME launch published write-through (fused update kernel)
-            __builtin_amdgcn_global_load_lds(base + k * s_k + 4 * gch, lds + R * 32, 16, 0, AUX);
+            __builtin_amdgcn_global_load_lds(base + k * s_k + 4 * gch, lds + R * 32, 16, 0, 0);
         }
     }
 }
@@ -83,39 +81,16 @@ __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag,
     return make_float4(p[((k0 + 0) ^ x) * 32], p[((k0 + 1) ^ x) * 32], p[((k0 + 2) ^ x) * 32], p[((k0 + 3) ^ x) * 32]);
 }
 
-// k-major staging of gl_stage with the transfer written as inline assembly.  The compiler tracks the builtin's LDS write
-// and, alias scopes or not, puts s_waitcnt vmcnt(0) in front of the first LDS read that follows it -- which would drain
-// the chunk in flight before the products of the previous one start.  The pipeline below orders the two itself: a
-// chunk is only read after the vmcnt(0) + barrier at the top of the step that consumes it.  (M0 holds the LDS base of
+// LDS-DMA issued from inline assembly: the compiler tracks the builtin's LDS write and, alias scopes or not, puts
+// s_waitcnt vmcnt(0) in front of the first LDS read that follows it -- which would drain the blocks in flight before the
+// products of the previous one start.  The ring below orders the two itself with counted waits.  (M0 holds the LDS base of
 // the transfer; hipcc reloads M0 in front of every instruction of its own that reads it.)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-template <int AUX = 0>
-__device__ __forceinline__ void gl_stage_kmajor_async(float *lds, const float *base, long long s_k, int valid, int kc) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nchunk = valid >> 2;
-    for (int R = 8 * wave; R < kc; R += 8 * GL_WAVES) {
-        const int rowp = R + (lane >> 3);
-        const int k = rowp ^ ((rowp >> 3) & 1);
-        int gch = (lane & 7) ^ (((k >> 2) & 1) << 2);
-        gch = gch < nchunk ? gch : nchunk - 1;
-        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(lds + R * 32));
-        if constexpr (AUX == 16)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
-                         : "memory", "m0");
-        else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(base + k * s_k + 4 * gch)
-                         : "memory", "m0");
-    }
-}
-// one LDS-DMA wave instruction (64 lanes x 16 B -> 1 KB at dst), issued from assembly for the same reason
-template <int AUX = 0>
+// one LDS-DMA wave instruction (64 lanes x 16 B -> 1 KB at dst)
 __device__ __forceinline__ void gl_dma(float *dst, const float *src) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
-    if constexpr (AUX == 16)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(src) : "memory", "m0");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -146,11 +121,9 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 // one launch and one cold pass over p/m/v less per update.  Data-parallel runs use ADAM = false + k_adam_frag so the
 // gradients can be all-reduced in between.
 // One 32 x 32 output tile.  bx = the tile's index in the group's launch order (blockIdx.x of the stand-alone kernels);
-// lds / bsum = GL_LDS_FLOATS / GL_WAVES * 32 floats of workgroup LDS.  AUX = cache policy of the operand staging loads
-// (16 = sc1 for operands published by other workgroups of the same launch); FIRST = this workgroup's first tile
-// (the fused kernel walks several tiles and finalises the loss elsewhere).
+// lds / bsum = GL_LDS_FLOATS / GL_WAVES * 32 floats of workgroup LDS.
 #define GL_LDS_FLOATS (2 * GL_OPERAND_FLOATS)
-template <bool ADAM, int AUX = 0>
+template <bool ADAM>
 __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F, int bx, float *lds, float (*bsum)[32],
                                           bool finalize_loss) {
     int pi = 0;
@@ -202,12 +175,13 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     bool ring_path = false;
     f32x16 cr;
     float asr = 0.f;
-    if (grp.pipe && !a_rowk && !b_rowk && p.K >= GL_RING_MIN_K) {
+    if (!a_rowk && !b_rowk && p.K >= GL_RING_MIN_K) {
         // Weight gradients of a large minibatch (reduction = batch rows > 256).  Every wave owns blocks of 8 batch rows (block
         // i of wave w: rows 64 i + 8 w .. + 7), brings them in through its OWN ring of 4 blocks (A rows | B rows, 2 KB, one
         // LDS-DMA instruction per operand) and accumulates the whole 32 x 32 tile on v_mfma_f32_32x32x2: no barrier in the
         // loop, 3 blocks in flight per wave.  The version before (128-row chunks staged by the workgroup, double buffered, one
-        // barrier per chunk) waited 1.4-1.75 us per chunk for its transfer: 11-14 us for the 1024 rows of batch 1024.
+        // barrier per chunk; RLARM_GEMM_PIPE=0 until round 3) waited 1.4-1.75 us per chunk for its transfer: 11-14 us for the
+        // 1024 rows of batch 1024.
         ring_path = true;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cr[r] = 0.f;
@@ -220,14 +194,14 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         const long long stepA = 64LL * p.a_sk, stepB = 64LL * p.b_sk;
         const int nblk = (p.K - 8 * wave + 63) >> 6;   // K is a multiple of 8
         for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) {
-            gl_dma<AUX>(ring + (i2 & 3) * 512, srcA + i2 * stepA);
-            gl_dma<AUX>(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
+            gl_dma(ring + (i2 & 3) * 512, srcA + i2 * stepA);
+            gl_dma(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
         }
         for (int i2 = 0; i2 < nblk; ++i2) {
             const int ahead = i2 + 3;
             if (ahead < nblk) {   // into the slot of block i2 - 1, whose operands the MFMAs of the previous turn have consumed
-                gl_dma<AUX>(ring + (ahead & 3) * 512, srcA + ahead * stepA);
-                gl_dma<AUX>(ring + (ahead & 3) * 512 + 256, srcB + ahead * stepB);
+                gl_dma(ring + (ahead & 3) * 512, srcA + ahead * stepA);
+                gl_dma(ring + (ahead & 3) * 512 + 256, srcB + ahead * stepB);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 const int rem = nblk - 1 - i2;
@@ -248,8 +222,8 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     for (int k0 = 0; k0 < p.K; k0 += GL_KC) {
         const int kc = (p.K - k0) < GL_KC ? (p.K - k0) : GL_KC;
         if (k0 > 0) __syncthreads();  // previous chunk fully consumed
-        gl_stage<AUX>(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
-        gl_stage<AUX>(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
+        gl_stage(ldsA, Abase + (long long)k0 * p.a_sk, p.a_si, p.a_sk, vm, kc, a_rowk);
+        gl_stage(ldsB, Bbase + (long long)k0 * p.b_sk, p.b_sj, p.b_sk, vn, kc, b_rowk);
         __syncthreads();
         GL_STAMP(1);
         gl_products(ldsA, ldsB, a_rowk, b_rowk, kc, wave, i, q, c00, c01, c10, c11, as0, as1);

@@ -25,7 +25,6 @@
 // every engine (tests/test_gpu_update.py).
 #pragma once
 
-#define S32_ROWS 32
 #define S32_THREADS 512
 #define S32_WAVES 8
 #define S32_LD 260

@@ -1,7 +1,7 @@
 // slab8.h -- row-slab engine on v_mfma_f32_4x4x1_16b_f32, S8_ROWS = 4 * S8_NRG (4, 8 or 16) batch rows per workgroup;
 // included by agent.hip once per slab height (the name dates from its 8-row first version).
 //
-// Why a second slab engine: with 16-row slabs on the 16x16x4 MFMA (slab.h) a 256x256 layer costs a workgroup 1024
+// Why thin slabs: with 16-row slabs on the 16x16x4 MFMA (the first slab engine, removed in round 3) a 256x256 layer costs a workgroup 1024
 // MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The 4x4x1 instruction (16
 // independent 4x4 outer products per issue, measured 8.7 cycles = 92 % of the 16x16x4 FLOP rate,
 // tools/ubench/mfma4x4.hip) lets a slab be as thin as 4 rows: lane l of a wavefront owns output column 64*cg + l,
@@ -27,9 +27,6 @@
 #define S8_WAVES 8
 #define S8_LD 260
 #define S8_LDX 52
-#ifndef S8_AHEAD_WGS
-#define S8_AHEAD_WGS 4   // spare workgroups that gather the next update's inputs (2 and 8 measured the same or slower)
-#endif
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
 #define S8_TSTAMP(tl, k) do { if ((tl) && threadIdx.x == 0) (tl)[k] = wall_clock64(); } while (0)
@@ -66,32 +63,10 @@ __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int i
     if (layer >= 2) off_d = base + w0 + frag8_dx_index(n, k, N);
 }
 
-// ---- fused single-launch update: the weight-gradient tiles (+ Adam) run as a second phase of k_fb_slab8 -------------
-// Every workgroup of the launch turns into a tile worker once ALL chain workgroups have published their outputs; the
-// workgroups that hold no chain (idle CUs at small batches) are already waiting.  What this removes from an update: one
-// kernel boundary, the cold start of the stand-alone tile kernel and the end-of-kernel write-back of the chain kernel.
-// Hand-off (cdna_hip_programming.md Guideline 16, form R1): chain outputs are stored WRITE-THROUGH (sc1), every storing
-// wave drains its stores (vmcnt(0)), one lane bumps a device-scope counter; consumers poll that one word relaxed and
-// read the operands with sc1 loads (LDS-DMA, aux = 16).  No workgroup ever waits for a tile worker, so a launch whose
-// workgroups are not all resident still terminates; every spin is bounded.
-struct FuseSync {                      // zeroed by k_seq_begin at the start of every update sequence
-    unsigned long long chains_done;    // chain workgroups that have published (monotonic within the sequence)
-    unsigned int error;                // a bounded spin gave up (never in a healthy run; hp_agent_fused_status reads it)
-    unsigned int pad;
-};
-struct FuseArgs {
-    int on;                            // 0: chains only (the tile kernel follows as its own launch)
-    int u;                             // index of this update in its sequence: poll target = (u + 1) * chains
-    int n_tiles;
-    int pad;
-    FuseSync *sync;
-    const GemmGroup *grp;              // the eight weight-gradient problems, in device memory: the tile code indexes the
-                                       // problem table dynamically, which on a by-value kernel argument would copy the whole
-                                       // argument block to scratch in every workgroup's prologue
-    AdamFuse adam;                     // optimizer epilogue: reads the chains' parameter set, writes the other one
-};
-#define S8_SPIN_LIMIT 40000            // x (s_sleep + one L2 round trip) ~ 40 ms
-
+// Chain outputs are stored WRITE-THROUGH (sc1): neutral on its own (40.8 vs 41.1 us/update), and what the split
+// weight-gradient kernel's partial-tile exchange (dw64.h) needs.  (Round 2 also ran the weight-gradient tiles as a second
+// phase of this kernel -- one launch per update: 48.2 vs 40.8 us, removed in round 3; DESIGN.md 3.2,
+// profiles/r02_fused_single_launch.txt.)
 __device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -104,7 +79,6 @@ __device__ __forceinline__ void wt_store4(float *p, const float4 v) {
 struct FbSlabArgs {
     FwdSlabArgs f;
     BwdSlabArgs b;
-    FuseArgs fuse;
     // Spare workgroups behind the 2 * nslab chain workgroups: n_plan (0/1) draws the index plan of a LATER update
     // (b.next_plan), n_ahead gather the NEXT update's network inputs from its already drawn plan into the other input
     // set, so that the next launch starts from a coalesced load instead of two dependent memory latencies
@@ -429,7 +403,7 @@ __device__ __forceinline__ void s8_load(float *l, int ld, int width, const float
     }
 }
 
-// HER gather for the rows of a slab (same arithmetic as slab_gather / k_gather_fused); one wavefront per row
+// HER gather for the rows of a slab (same arithmetic as k_gather_fused); one wavefront per row
 // this thread's row of the index plan: the first load of the kernel (everything else in the gather depends on it).
 // Unconditional (rows past the batch re-read the last record, plan_any is never null): a load under a branch is
 // merged with its default through a register copy, which makes the compiler wait for it on the spot.
@@ -603,40 +577,6 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
     }
 }
 
-// Second phase of the fused launch (FuseArgs): publish (chain workgroups), wait for every chain, then this workgroup's
-// share of the weight-gradient tiles with the optimizer in their epilogue.  worker / n_workers: this workgroup's index
-// among the workgroups that take part (all but the index-plan workgroup).  lds / bsum: GL_LDS_FLOATS / 8 x 32 floats.
-__device__ __forceinline__ void s8_phase2(const FuseArgs &U, bool chain_wg, int n_chains, int worker, int n_workers,
-                                          float *lds, float (*bsum)[32], unsigned long long *tl) {
-    S8_TSTAMP(tl, 27);
-    if (chain_wg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its write-through stores have completed
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&U.sync->chains_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) {   // one lane polls one word, relaxed; bounded
-        const unsigned long long target = (unsigned long long)(U.u + 1) * (unsigned long long)n_chains;
-        unsigned spins = 0;
-        while (__hip_atomic_load(&U.sync->chains_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > S8_SPIN_LIMIT) {
-                __hip_atomic_store(&U.sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    S8_TSTAMP(tl, 28);
-    __syncthreads();
-    S8_TSTAMP(tl, 29);
-    if (worker == n_workers - 1 && threadIdx.x < 64) loss_finalize(U.adam);
-    int done = 0;
-    for (int t = worker; t < U.n_tiles; t += n_workers, ++done) {
-        if (done) __syncthreads();   // the previous tile's epilogue was still reading the LDS images
-        gemm_tile<true, 16>(*U.grp, &U.adam, t, lds, bsum, false);
-        S8_TSTAMP(tl, done ? 31 : 30);
-    }
-}
-
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_slab8(const FbSlabArgs P) {
     const FwdSlabArgs &A = P.f;
     const BwdSlabArgs &Bk = P.b;
@@ -723,7 +663,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (; off < ns[r]; off += step) acc += rs[r][off];
             }
             if (acc == 1.2345678e-33f) dq[0] = acc;   // keeps the loads; never true in practice, harmless if it is
-        }   // (workgroups past the warmers exist only in a fused launch: pure tile workers on CUs that hold no chain)
+        }
     } else {
     S8_TSTAMP(tl, 0);
     const SlabNetPtrs &on = A.online;
@@ -835,8 +775,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             wt_store(Bk.dQA + (row0 + tid) * 16, keep_g);
             if (tid == 0) wt_store(Bk.part + slab, keep_a);
         }
-        if (!P.fuse.on && slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
-            Bk.st->step += 1;                         // (fused launch: per-sequence table, k_seq_begin / k_seq_end)
+        if (slab == 0 && tid == 0) {   // Adam step scalars for the optimizer kernel that follows
+            Bk.st->step += 1;
             adam_prepare(Bk.st, Bk.adam);
         }
         S8_TSTAMP(tl, 22);
@@ -976,15 +916,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     S8_TSTAMP(tl, 21);
     }
-    }
-    if (P.fuse.on) {
-        // every workgroup but the index-plan one becomes a tile worker; the weight ring (>= 80 KB) holds the operand images
-        const bool chain_wg = (int)blockIdx.x < 2 * nslab;
-        const int worker = chain_wg ? (int)blockIdx.x : (int)blockIdx.x - P.n_plan;
-        const int n_workers = (int)gridDim.x - P.n_plan;
-        static_assert(sizeof(wring) >= GL_LDS_FLOATS * sizeof(float), "weight ring too small for the tile images");
-        s8_phase2(P.fuse, chain_wg, 2 * nslab, worker, n_workers, reinterpret_cast<float *>(&wring[0][0][0]),
-                  reinterpret_cast<float(*)[32]>(pbuf), tl);
     }
 }
 

@@ -38,7 +38,7 @@ for net, n in ((0, 140548), (1, 140801), (2, 140548), (3, 140801)):
 eps = make_episodes(2, seed=3)
 d = C.c_double
 def chain():
-    names = {0: "k_loss", 1: "k_actor_head", 2: "fwd hidden level (3x256^3)", 3: "fwd first level", 4: "q heads", 5: "bwd hidden level", 6: "adam", 8: "polyak", 10: "forward+backward (active engine)"}
+    names = {6: "adam", 8: "polyak", 10: "forward+backward (active engine)", 11: "chain kernel", 12: "weight gradients + optimizer"}
     for k, nm in names.items():
         v = C.c_double(); _lib.check(lib.hp_agent_debug_chain(h, k, 200, C.byref(v))); print(f"[chain] {nm}: {v.value:.2f} us/launch")
 chain()
