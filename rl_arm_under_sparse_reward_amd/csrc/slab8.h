@@ -30,9 +30,11 @@
 #ifdef SLAB_TIMELINE
 #define S8_STAMP(k) do { if (slab == 0 && threadIdx.x == 0) A.tl[chain * 32 + (k)] = wall_clock64(); } while (0)
 #define S8_TSTAMP(tl, k) do { if ((tl) && threadIdx.x == 0) (tl)[k] = wall_clock64(); } while (0)
+#define S8_WSTAMP(tl, k) do { if ((tl) && (threadIdx.x & 63) == 0) (tl)[(k) + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
 #else
 #define S8_STAMP(k) do { } while (0)
 #define S8_TSTAMP(tl, k) do { } while (0)
+#define S8_WSTAMP(tl, k) do { } while (0)
 #endif
 
 __host__ __device__ __forceinline__ int frag8_fwd_index(int n, int k, int K) {
@@ -88,6 +90,11 @@ struct FbSlabArgs {
     int n_pref;      // L2-warmer workgroups (a multiple of 8: the same number on every XCD)
     GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
     float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
+    // pair engine (slab8_pair.h): exchange buffers [chain workgroups][2][8 x 256], one flag per workgroup (64 B apart),
+    // sticky error word (1: a poll timed out, 2: the partner ran on another XCD)
+    float *pair_exch;
+    unsigned long long *pair_flags;
+    unsigned int *pair_err;
 };
 
 // Rollout-side policy call (hp_agent_act / hp_agent_actor_forward): one 4-row slab per workgroup through the actor
@@ -577,6 +584,55 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
     }
 }
 
+// L2 warmer `widx` (of P.n_pref: a multiple of 8, the same number on every XCD) of this workgroup's XCD: touches the weight
+// fragments the XCD's chains will stream, in the order they use them, one dword per 128-byte line, so that the chains find them
+// in their L2 instead of behind the fabric
+__device__ __forceinline__ void s8_l2_warm(const FbSlabArgs &P, int widx, float *sink) {
+    const FwdSlabArgs &A = P.f;
+    const int tid = threadIdx.x;
+    // L2 warmer of this workgroup's XCD: touches the weight fragments the XCD's chains will stream, in the order
+    // they use them, one dword per 128-byte line, so that the chains find them in their L2 instead of behind the fabric
+    const int side = P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2;
+    const int na = A.la.total, nall = na + A.lc.total;
+    const float *r0 = side == 1 ? A.online.wf : A.target.wf;
+    const int n0 = nall;
+    const float *r1 = side == 1 ? A.online.wd + na : A.online.wf + (side == 0 ? na : 0);
+    const int n1 = side == 2 ? nall : A.lc.total;
+    const float *r2 = side == 1 ? A.online.wd : A.online.wd + (side == 0 ? na : 0);
+    const int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
+    const float *rs[3] = {r0, r1, r2};
+    const int ns[3] = {n0, n1, n2};
+    const int per = P.n_pref >> 3, mine = widx >> 3;   // warmers per XCD, my index
+    float acc = 0.f;
+    if (tid < 256) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
+        const int grp = tid >> 6, i = tid & 63;
+        const float *canon = (grp >> 1) ? A.online.canon : A.target.canon;
+        const NetLayout &l = (grp & 1) ? A.lc : A.la;
+        const float *net = canon + ((grp & 1) ? na : 0);
+        const int tail = (l.total - l.w4 + 31) >> 5;
+        int o = -1;
+        if (i < 8) o = l.b1 + 32 * i;
+        else if (i < 16) o = l.b2 + 32 * (i - 8);
+        else if (i < 24) o = l.b3 + 32 * (i - 16);
+        else if (i - 24 < tail) o = l.w4 + 32 * (i - 24);
+        if (o >= 0 && o < l.total) acc += net[o];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int step = per * S8_THREADS * 32;
+        int off = (mine * S8_THREADS + tid) * 32;
+        for (; off + 7 * step < ns[r]; off += 8 * step) {   // 8 lines in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = rs[r][off + u * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; off < ns[r]; off += step) acc += rs[r][off];
+    }
+    if (acc == 1.2345678e-33f) sink[0] = acc;   // keeps the loads; never true in practice, harmless if it is
+}
+
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_slab8(const FbSlabArgs P) {
     const FwdSlabArgs &A = P.f;
     const BwdSlabArgs &Bk = P.b;
@@ -622,47 +678,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         } else if (extra < P.n_plan + P.n_ahead) {
             s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, extra - P.n_plan, P.n_ahead);
         } else if (extra < P.n_plan + P.n_ahead + P.n_pref) {
-            // L2 warmer of this workgroup's XCD: touches the weight fragments the XCD's chains will stream, in the order
-            // they use them, one dword per 128-byte line, so that the chains find them in their L2 instead of behind the fabric
-            const int side = P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2;
-            const int na = A.la.total, nall = na + A.lc.total;
-            const float *r0 = side == 1 ? A.online.wf : A.target.wf;
-            const int n0 = nall;
-            const float *r1 = side == 1 ? A.online.wd + na : A.online.wf + (side == 0 ? na : 0);
-            const int n1 = side == 2 ? nall : A.lc.total;
-            const float *r2 = side == 1 ? A.online.wd : A.online.wd + (side == 0 ? na : 0);
-            const int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
-            const float *rs[3] = {r0, r1, r2};
-            const int ns[3] = {n0, n1, n2};
-            const int per = P.n_pref >> 3, mine = (extra - P.n_plan - P.n_ahead) >> 3;   // warmers per XCD, my index
-            float acc = 0.f;
-            if (tid < 256) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
-                const int grp = tid >> 6, i = tid & 63;
-                const float *canon = (grp >> 1) ? A.online.canon : A.target.canon;
-                const NetLayout &l = (grp & 1) ? A.lc : A.la;
-                const float *net = canon + ((grp & 1) ? na : 0);
-                const int tail = (l.total - l.w4 + 31) >> 5;
-                int o = -1;
-                if (i < 8) o = l.b1 + 32 * i;
-                else if (i < 16) o = l.b2 + 32 * (i - 8);
-                else if (i < 24) o = l.b3 + 32 * (i - 16);
-                else if (i - 24 < tail) o = l.w4 + 32 * (i - 24);
-                if (o >= 0 && o < l.total) acc += net[o];
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int step = per * S8_THREADS * 32;
-                int off = (mine * S8_THREADS + tid) * 32;
-                for (; off + 7 * step < ns[r]; off += 8 * step) {   // 8 lines in flight per lane
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = rs[r][off + u * step];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += v[u];
-                }
-                for (; off < ns[r]; off += step) acc += rs[r][off];
-            }
-            if (acc == 1.2345678e-33f) dq[0] = acc;   // keeps the loads; never true in practice, harmless if it is
+            s8_l2_warm(P, extra - P.n_plan - P.n_ahead, dq);
         }
     } else {
     S8_TSTAMP(tl, 0);
@@ -918,6 +934,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     }
 }
+
+#include "slab8_pair.h"
 
 #if S8_NRG == 1
 // actions = max_action * tanh(actor(normalise(obs | g)))  (ddpg_agent._preproc_inputs :163-171, models.py:19-26): the actor
