@@ -160,11 +160,13 @@ def test_updates_track_oracle_over_a_cycle(batch, k, engine="", monkeypatch=None
         tr, _ = st.sample(batch, fp, rs)
         res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
         # Update 0 starts from identical state on both sides: the north-star bar, 1e-5 relative (observed <= 1.2e-7; the
-        # golden tests above hold every engine to it as well).  From then on the comparison is CHAINED and two correct fp32
+        # golden tests above hold every engine to it as well, and tests/test_gpu_teacher_forced.py holds EVERY update of a
+        # 40-step sequence to it by restarting the device from the oracle's state).  This test is the secondary drift
+        # monitor: the comparison from update 1 on is CHAINED and two correct fp32
         # trajectories separate: Adam's first steps divide by sqrt(v) ~ |g|, so a last-bit difference in a near-zero gradient
         # moves that weight by a full lr, and the difference then grows geometrically (observed ~1.15-1.2x per update at
         # lr 1e-3).  When such an event happens depends on the (batch, replay_k, summation order) triple, not on which kernel is
-        # "more right": tests/drift_check.py over batches 384..4096 x replay_k 4/8 x the kernels kept in the tree reads 1.5e-7
+        # "more right": tools/debug/drift_check.py over batches 384..4096 x replay_k 4/8 x the kernels kept in the tree reads 1.5e-7
         # at update 40 for most triples and 4e-6 .. 1.1e-3 for about one in five (batch 512 / k 8: event at update 6 ->
         # 1.1e-3 with the per-wave-ring weight-gradient loop, event at update 29 -> 7e-6 with the chunked one; batch 1024 / k 4:
         # 2.2e-5 with both; batch 3072: 1.1e-5 at update 4).  The envelope: 1e-5 x 1.3^i, capped at 3e-3.
@@ -612,7 +614,7 @@ def test_other_env_shapes_track_oracle(obs_dim, goal_dim, act_dim, T):
     x = np.random.RandomState(1).normal(size=(9, obs_dim + goal_dim)).astype(np.float32)
     want = oupd.actor_forward({k: v.detach() for k, v in learner.actor.items()}, torch.from_numpy(x), 0.5).numpy()
     # six chained Adam steps: a weight whose gradient is at rounding level moves by +-lr either way, so the policies of two
-    # correct fp32 implementations differ by a few 1e-5 on outputs of ~3e-2 (tests/shape_probe.py: 1.5e-8 with one
+    # correct fp32 implementations differ by a few 1e-5 on outputs of ~3e-2 (tools/debug/shape_probe.py: 1.5e-8 with one
     # summation order of the weight-gradient kernel, 2.7e-5 with another, losses within 1e-4 in both)
     assert np.allclose(agent.actor_network(x), want, rtol=1e-3, atol=1e-4)
 

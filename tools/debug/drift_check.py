@@ -1,9 +1,10 @@
 """Largest relative loss deviation from the torch-CPU oracle over 40 chained updates (what the tracking tests bound).
 Test infrastructure (it runs the body of test_updates_track_oracle_over_a_cycle and reports instead of asserting):
-    RLARM_ENGINE=slab32 python tests/drift_check.py 3072"""
+    RLARM_ENGINE=slab32 python tools/debug/drift_check.py 3072"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(_REPO, "tests"))
+sys.path.insert(0, _REPO)
 import numpy as np, torch
 import test_gpu_update as T
 batch = int(sys.argv[1])

@@ -1,5 +1,6 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(_REPO, "tests")); sys.path.insert(0, _REPO)
 import numpy as np, torch
 import test_gpu_update as T
 src = open(T.__file__).read()
