@@ -45,7 +45,7 @@ def _recompute_emulating_ranks(ranks):
         _lib.check(lib.hp_norm_recompute_end(nz.h))
 
 
-@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])     # 4 / 8: the reference run on 4 / 8 stub ranks (tools/gen_golden.py)
 @pytest.mark.parametrize("size", [27, 3])
 def test_normalizer_golden_bits(world, size):
     g = load_golden("normalizer.npz")

@@ -112,6 +112,33 @@ def _worker(rank, world, port, out_dir, transport="torch"):
            "rng_equal": bool(np.array_equal(rng.get_state()[1], rs.get_state()[1]) and rng.get_state()[2] == rs.get_state()[2]),
            "o_mean": np.asarray(agent.o_norm.mean), "oracle_o_mean": np.asarray(on.mean)}
     if peer:
+        # normalizer._mpi_average (normalizer.py:60-64) through the peer mailboxes, on stand-alone normalizers fed the golden
+        # recipe: the rank-ordered sum / world must give the reference's bits (tests/golden/normalizer.npz w{world}_*, the
+        # reference run on `world` stub ranks)
+        from conftest import load_golden
+        from rl_arm_under_sparse_reward_amd.normalizer import normalizer as dev_normalizer
+        g = load_golden("normalizer.npz")
+
+        def golden_inputs(step, size):
+            rs_ = np.random.RandomState(1000 + 17 * rank + step)
+            n_ = [100, 100, 37, 250, 1, 100][step % 6]
+            scale = [1.0, 30.0, 1e-3, 250.0, 1.0, 5.0][step % 6]
+            return rs_.normal(0.3 * (rank + 1), scale, size=(n_, size))
+
+        golden_ok = True
+        for size in (27, 3):
+            nz = dev_normalizer(size, default_clip_range=5, std_dtype=str(g["std_dtype"]), comm=comm)
+            i = 0
+            for step in range(6):
+                nz.update(np.clip(golden_inputs(step, size), -200, 200))
+                if step % 2 == 1 or step == 4:
+                    nz.recompute_stats()
+                    for nm in ("mean", "std", "total_sum", "total_sumsq", "total_count"):
+                        ref = g[f"w{world}_d{size}_r{i}_{nm}"]
+                        got = np.asarray(getattr(nz, nm))
+                        golden_ok = golden_ok and got.dtype == ref.dtype and np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+                    i += 1
+        out["normalizer_golden_ok"] = bool(golden_ok)
         # the whole cycle as ONE hipGraph with the exchange inside (gradients per update, normalizer sums once)
         import ctypes as C
         more = make_episodes(2, seed=70 + rank, mode="walk")
@@ -181,6 +208,7 @@ def test_peer_exchange_keeps_ranks_identical_through_graph_cycles(two_ranks):
     if r0["transport"] == "torch":
         pytest.skip("peer-memory transport only")
     for r1 in two_ranks[1:]:
+        assert r0["normalizer_golden_ok"] and r1["normalizer_golden_ok"]   # _mpi_average through the mailboxes: reference bits
         assert r0["cycle_mode"] == 1 and r1["cycle_mode"] == 1          # the cycle, exchange included, replays as a hipGraph
         assert r0["peer_error"] == 0 and r1["peer_error"] == 0
         assert np.array_equal(r0["actor_after_cycles"].view(np.uint8), r1["actor_after_cycles"].view(np.uint8))

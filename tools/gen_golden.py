@@ -352,11 +352,12 @@ def _norm_inputs(rank, step, size):
 
 
 def gen_normalizer(ref, out):
-    """F5: float32 bit patterns of the running normalizer, world size 1 and 2."""
+    """F5: float32 bit patterns of the running normalizer, world sizes 1, 2, 4 and 8 (stub ranks; the 8-GPU BASELINE
+    configs 4 / 5 exchange their statistics exactly like this)."""
     from oracle.running_norm import RunningNorm
 
     payload = {}
-    for world in (1, 2):
+    for world in (1, 2, 4, 8):
         for size in (27, 3):
             def body(rank, size=size):
                 nz = ref.normalizer.normalizer(size=size, default_clip_range=5)
