@@ -115,11 +115,6 @@ struct hp_agent {
     bool slab = true;      // a row-slab engine (false: layer-per-launch engine)
     bool slab8 = true;     // thin slabs on the 4x4x1 MFMA (false: slab32)
     bool slab32 = false;   // 32-row slabs on the 32x32x2 MFMA, forward + backward in one kernel (slab32.h: large batches)
-    bool pair = false;     // thin slabs carried by PAIRS of workgroups on one XCD (slab8_pair.h: 8 rows per pair, each member
-                           // streams half of every 256 x 256 layer); RLARM_PAIR, batch <= 512
-    float *pair_exch = nullptr;                // [chain workgroups][2][8 x 256] partial sums
-    unsigned long long *pair_flags = nullptr;  // one epoch word per chain workgroup, 64 B apart
-    unsigned int *pair_err = nullptr;          // sticky: 1 a poll timed out, 2 the partner ran on another XCD
     int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     // A/B switches, read once in hp_agent_create: RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD, RLARM_FB_PREFETCH (-1 = by size,
@@ -318,11 +313,9 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
 };
 
 // workgroups of the chain kernel that carry chains (the spare ones -- index plan, look-ahead gather, L2 warmers -- follow)
-static inline int chain_wgs(const hp_agent *a) { return a->pair ? 4 * (a->Mp / 8) : 2 * (a->Mp / a->s8_rows); }
+static inline int chain_wgs(const hp_agent *a) { return 2 * (a->Mp / a->s8_rows); }
 
 // ---- defined in agent_engines.hip
-// do workgroups b and b ^ 8 of a launch share an XCD on this device?  (probe launch; what the pair engine relies on)
-int probe_pair_placement(hp_agent *a, bool *ok);
 int launch_group(hp_agent *a, const Launch &L, int which);                       // one grouped k_gemm_lds launch
 int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq, int xset = 0,
                    hipStream_t stream = nullptr);

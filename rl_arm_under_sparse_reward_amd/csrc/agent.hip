@@ -291,24 +291,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->gather_ahead = !(ah && ah[0] == '0');
         // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
         // 1024 (256 chains) they ran after them, 87.6 vs 76.1 us/update
-        // pairs of workgroups per chain (slab8_pair.h): opt-in while it is being measured
-        a->pair = a->slab8 && tri("RLARM_PAIR") == 1 && 4 * (a->Mp / 8) <= cus && !getenv("RLARM_SLAB_ROWS");
-        if (a->pair) a->s8_rows = 8;
         const int chains = chain_wgs(a);
         if (!ah && chains + 1 + S8_AHEAD_WGS > cus) a->gather_ahead = false;
-    }
-    if (st == HP_OK && a->pair) {
-        bool ok = false;
-        if (probe_pair_placement(a, &ok) != HP_OK || !ok) {
-            a->pair = false;   // workgroups b and b ^ 8 do not share an XCD here: the standard thin-slab engine
-            const int cus = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
-            a->s8_rows = 2 * (a->Mp / 4) <= cus ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
-        } else {
-            const size_t wgs = (size_t)chain_wgs(a);
-            if (st == HP_OK) st = dev_alloc(a, &a->pair_exch, wgs * 2 * 8 * 256);
-            if (st == HP_OK) st = dev_alloc(a, &a->pair_flags, wgs * 8);
-            if (st == HP_OK) st = dev_alloc(a, &a->pair_err, 16);
-        }
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
@@ -551,13 +535,6 @@ int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
     HP_CHECK_HIP(hipMemcpyAsync(&h, a->d_state, sizeof(h), hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipMemcpyAsync(log.data(), a->loss_log, log.size() * 4, hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
-    if (a->pair) {   // the pair engine's in-kernel exchange: a bounded poll gave up, or a pair was split across XCDs
-        unsigned int perr = 0;
-        HP_CHECK_HIP(hipMemcpyAsync(&perr, a->pair_err, 4, hipMemcpyDeviceToHost, s));
-        HP_CHECK_HIP(hipStreamSynchronize(s));
-        HP_REQUIRE(perr == 0, HP_ERR_STATE, "pair engine: exchange error %u (1: a partner never arrived, 2: partners on different "
-                   "XCDs) -- the updates since are invalid; set RLARM_PAIR=0", perr);
-    }
     HP_REQUIRE(h.n_logged >= n_last, HP_ERR_STATE, "hp_agent_get_losses: only %lld updates logged", h.n_logged);
     for (int i = 0; i < n_last; ++i) {
         const long long k = h.n_logged - n_last + i;
@@ -721,7 +698,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
 
 int hp_agent_engine(hp_agent *a, int32_t *engine, int32_t *slab_rows, int32_t *dw_split) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_engine: null handle");
-    if (engine) *engine = !a->slab ? 0 : (a->slab8 ? (a->pair ? 9 : 8) : 32);
+    if (engine) *engine = !a->slab ? 0 : (a->slab8 ? 8 : 32);
     if (slab_rows) *slab_rows = !a->slab ? 0 : (a->slab8 ? a->s8_rows : S32_ROWS);
     if (dw_split) *dw_split = a->dw64 ? a->dw_S : 0;
     return HP_OK;

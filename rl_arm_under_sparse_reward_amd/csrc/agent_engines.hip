@@ -305,34 +305,7 @@ __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, 
     out[idx] = X[(long long)r * ld + act_off + c] * max_action;   // stored value is actions / max_action
 }
 
-// XCC id of every workgroup of a 256-workgroup launch (pair engine: do b and b ^ 8 share an XCD?)
-__global__ void k_xcc_probe(unsigned *xcc) {
-    if (threadIdx.x == 0) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcc[blockIdx.x] = id & 0xfu;
-    }
-}
-
 // ------------------------------------------------------------------------------- host side
-int probe_pair_placement(hp_agent *a, bool *ok) {
-    *ok = false;
-    unsigned *d = nullptr;
-    HP_CHECK_HIP(hipMalloc((void **)&d, 256 * 4));
-    unsigned h[256];
-    bool good = true;
-    for (int rep = 0; rep < 2 && good; ++rep) {
-        hipLaunchKernelGGL(k_xcc_probe, dim3(256), dim3(S8_THREADS), 0, a->ctx->stream, d);
-        hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, a->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(d); HP_CHECK_HIP(e); }
-        for (int b = 0; b < 256; ++b) good = good && h[b] == h[b ^ 8] && h[b] == h[b & 7];
-    }
-    (void)hipFree(d);
-    *ok = good;
-    return HP_OK;
-}
-
 int launch_group(hp_agent *a, const Launch &L, int which) {
     ProfScope ps(a, which);
     hipLaunchKernelGGL(k_gemm_lds, dim3(L.tiles), dim3(GL_THREADS), 0, a->ctx->stream, L.g);
@@ -423,7 +396,6 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
     hipStream_t s = a->ctx->stream;
     const int nslab = Mp / (a->slab8 ? a->s8_rows : S32_ROWS);
     FbSlabArgs P;
-    P.pair_exch = a->pair_exch; P.pair_flags = a->pair_flags; P.pair_err = a->pair_err;
     const int xs = gc ? gc->xset : 0;
     float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
     const SlabNetPtrs online = SlabNetPtrs{a->fragF, a->fragD, a->params};
@@ -486,7 +458,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         // chains split across XCD halves: measured (us/update, split vs not) 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256,
         // 46.6 vs 46.6 at 384, 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
         const int n_chain = chain_wgs(a);
-        P.xcd_split = a->pair ? 1 : ((nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count));
+        P.xcd_split = (nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count);
         P.ahead = P.f.gs;
         P.aXT = P.aXA = P.aXP = nullptr;
         if (gc && gc->ahead_plan && !ride_dw) {   // next update's inputs into the other set
@@ -501,9 +473,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         P.n_pref = (a->fb_prefetch >= 0 ? a->fb_prefetch == 1
                                         : n_chain + P.n_plan + P.n_ahead + 8 <= a->ctx->cu_count) ? 8 : 0;
         const unsigned grid = n_chain + P.n_plan + P.n_ahead + P.n_pref;
-        if (a->pair)
-            hipLaunchKernelGGL(s8r8::k_fb_pair8, dim3(grid), dim3(S8_THREADS), 0, s, P);
-        else if (a->s8_rows == 4)
+        if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
         else if (a->s8_rows == 8)
             hipLaunchKernelGGL(s8r8::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);

@@ -90,11 +90,6 @@ struct FbSlabArgs {
     int n_pref;      // L2-warmer workgroups (a multiple of 8: the same number on every XCD)
     GatherSrc ahead;             // ahead.plan = plan of the next update; ahead.R = its reward vector
     float *aXT, *aXA, *aXP;      // its input sets (the chains of THIS launch use f.XT / f.XA / f.XP)
-    // pair engine (slab8_pair.h): exchange buffers [chain workgroups][2][8 x 256], one flag per workgroup (64 B apart),
-    // sticky error word (1: a poll timed out, 2: the partner ran on another XCD)
-    float *pair_exch;
-    unsigned long long *pair_flags;
-    unsigned int *pair_err;
 };
 
 // Rollout-side policy call (hp_agent_act / hp_agent_actor_forward): one 4-row slab per workgroup through the actor
@@ -934,8 +929,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     }
 }
-
-#include "slab8_pair.h"
 
 #if S8_NRG == 1
 // actions = max_action * tanh(actor(normalise(obs | g)))  (ddpg_agent._preproc_inputs :163-171, models.py:19-26): the actor

@@ -339,7 +339,7 @@ class ddpg_agent:
         'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 3'} at 4096."""
         e, r, d = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.hp_agent_engine(self.h, C.byref(e), C.byref(r), C.byref(d)))
-        return {"engine": {0: "layers", 8: "slab8", 9: "slab8 pairs", 32: "slab32"}[e.value], "slab_rows": r.value,
+        return {"engine": {0: "layers", 8: "slab8", 32: "slab32"}[e.value], "slab_rows": r.value,
                 "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32"}
 
     def policy_snapshot(self):

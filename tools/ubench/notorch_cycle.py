@@ -60,11 +60,6 @@ for ch, nm in ((0, "fwd T | merged critic side"), (1, "fwd A | merged actor side
     v = [tl[ch * 32 + k] for k in range(32)]
     if v[0]:
         print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(32) if v[k]))
-if tl[64]:   # per-wave stamps of one column-split / reduction-split layer of the pair engine (slab8_pair.h)
-    t0 = tl[8]
-    for nm, b0, b1 in (("C layer", 64, 72), ("K layer", 80, 88)):
-        print(f"[timeline pair {nm} per wave, us after stamp 8] start " + " ".join(f"{(tl[b0 + w] - t0) / 100:.2f}" for w in range(8)) +
-              " | products done " + " ".join(f"{(tl[b1 + w] - t0) / 100:.2f}" for w in range(8)))
 for base, nm in ((160, "dW gemm first wg"), (176, "dW gemm last wg")):
     v = [tl[base + k] for k in range(8)]
     if v[0]:
