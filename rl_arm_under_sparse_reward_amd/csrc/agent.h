@@ -310,6 +310,9 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     bool ride_in_dw = false;
     // data-parallel ranks exchanging through peer memory: this update's gradients go straight into the exchange buffer
     float *grads_out = nullptr;
+    // last update of a training cycle: the optimizer launch also applies the soft update of both target networks
+    // (ddpg_agent.py:149-150) to the parameters it has just stepped -- no separate polyak launch
+    bool polyak_after = false;
 };
 
 // workgroups of the chain kernel that carry chains (the spare ones -- index plan, look-ahead gather, L2 warmers -- follow)
@@ -327,10 +330,12 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
 int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fuse_adam = false, bool *fused = nullptr);
 // only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
-int enqueue_adam(hp_agent *a);
+int enqueue_adam(hp_agent *a, bool polyak_after = false);   // polyak_after: see GatherCtx (slab engines; returns whether via *folded)
 int enqueue_polyak(hp_agent *a);
 // utils.sync_grads (utils.py:43-48) + both Adam steps of update u as the peer exchange's optimizer kernel(s) (peer.hip)
-int enqueue_peer_adam(hp_agent *a, int u);
+int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after = false);
+// can the optimizer launches of this agent apply the soft target update themselves?  (slab engines: yes)
+static inline bool polyak_foldable(const hp_agent *a) { return a->slab; }
 // ---- defined in agent_layers.hip
 int enqueue_forward_backward_layers(hp_agent *a);
 int layers_enqueue_adam(hp_agent *a);

@@ -4,6 +4,8 @@
 // Reference: ddpg_agent.py:143-150 (cycle), :225-277 (_update_network), utils.py:6-69 (exchange), torch.optim.Adam.
 #include "agent.h"
 
+#include <functional>
+
 static void drop_graph(hp_agent *a);
 
 static int ensure_plan(hp_agent *a, int n_batches) {
@@ -28,8 +30,16 @@ static int check_handles(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
 
 // n_updates x (sample + update); the index plan for all of them is drawn by one kernel up front
 // (nothing else consumes the stream in between, exactly like the reference's inner loop).
+// Cycle mode (`cyc` != nullptr, hp_agent_train_cycle): the first plans are drawn TOGETHER with the normalizer's index plan
+// (one launch, k_draw_plan2), `cyc->between` enqueues the normalizer update behind that launch, and the last update's optimizer
+// launch also applies the soft target update where the engine can (cyc->polyak_folded tells the caller).
+struct CycleOpts {
+    PlanRec *norm_plan;
+    std::function<int()> between;
+    bool polyak_folded = false;
+};
 static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq,
-                           int n_updates, bool with_adam) {
+                           int n_updates, bool with_adam, CycleOpts *cyc = nullptr) {
     // slab engine: only the first minibatch's indices are drawn up front; update u draws the plan of update u+1 in
     // a spare workgroup of its backward kernel (same stream order of draws, so the same indices).  Layer engine:
     // one kernel draws all of them (nothing else consumes the stream in between, like the reference's inner loop).
@@ -56,9 +66,16 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const int lead = ahead ? 2 : 1;
     {
         ProfScope ps(a, PROF_PLAN);
-        HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, ride ? (n_updates < lead ? n_updates : lead) : n_updates,
-                               future_p, a->plan.as<PlanRec>()));
+        const int first = ride ? (n_updates < lead ? n_updates : lead) : n_updates;
+        if (cyc)   // ddpg_agent._update_normalizer's plan (T transitions of the staged episodes), then the first minibatch plans
+            HP_TRY(rng_launch_plan2(rng, b->staged_n, b->T, b->T, cyc->norm_plan, b->d_meta, a->B, first, future_p,
+                                    a->plan.as<PlanRec>()));
+        else
+            HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, first, future_p, a->plan.as<PlanRec>()));
     }
+    if (cyc && cyc->between) HP_TRY(cyc->between());
+    const bool fold = cyc && with_adam && polyak_foldable(a);
+    if (cyc) cyc->polyak_folded = fold;
     // Where the plan of update u + lead is drawn: by a spare workgroup of update u's own launch while that launch leaves
     // a CU free -- or, when the chains occupy every CU (batch 1024: 256 chain workgroups; the 16-row engine beyond), by
     // k_draw_plan on a second stream next to the chain kernel.  A workgroup appended to a full launch only starts when
@@ -116,6 +133,8 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             if (u + 1 < n_updates && !side_gather) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
         gc.ride_in_dw = dw_ride;
+        const bool last_fold = fold && u == n_updates - 1;
+        gc.polyak_after = last_fold;
         const bool via_peer = with_adam && a->peer != nullptr;
         if (via_peer) gc.grads_out = peer_grad_buffer(a->peer, u + 1);   // epoch base is even: parity of epoch base + u + 1
         bool fused = false;
@@ -123,14 +142,14 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         if (via_peer) {
             // utils.sync_grads (utils.py:43-48) + both Adam steps in ONE kernel: every rank reads the peers' gradient
             // vectors over xGMI, sums them in rank order and steps (peer.hip)
-            HP_TRY(enqueue_peer_adam(a, u));
+            HP_TRY(enqueue_peer_adam(a, u, last_fold));
         } else if (with_adam) {
             // utils.sync_grads (utils.py:43-48): SUM over ranks between backward and the optimizer step; one
             // all-reduce covers both networks (the reference sends the actor's and the critic's separately)
             if (a->comm)
                 HP_TRY(a->grad_mean ? comm_allreduce_mean_f32(a->comm, a->grads, (size_t)a->n_arena)
                                     : comm_allreduce_sum_f32(a->comm, a->grads, (size_t)a->n_arena));
-            if (!fused) HP_TRY(enqueue_adam(a));
+            if (!fused) HP_TRY(enqueue_adam(a, last_fold));
         }
     }
     if (join_pending) HP_CHECK_HIP(hipStreamWaitEvent(a->ctx->stream, a->plan_join, 0));
@@ -555,32 +574,37 @@ int hp_agent_soft_update(hp_agent *a) {
 // device part of one cycle after the episodes are staged: slots+scatter happen in buffer_stage_and_store
 static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
                               double sq, int n_batches, PlanRec *norm_plan) {
-    // ddpg_agent._update_normalizer (:187-212)
-    HP_TRY(rng_launch_plan(rng, nullptr, b->staged_n, b->T, b->T, 1, future_p, norm_plan));
-    if (!a->comm && !a->peer) {   // single rank: update + recompute_stats of both normalizers in one launch
-        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, true));
-    } else if (a->peer) {
-        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
-        HP_TRY(norm_launch_begin(on));
-        HP_TRY(norm_launch_begin(gn));
-        // normalizer._mpi_average (normalizer.py:60-64) through the mailboxes
-        HP_TRY(peer_allreduce_small(a->peer, on->d->sync, (size_t)(2 * on->size + 1), true));
-        HP_TRY(peer_allreduce_small(a->peer, gn->d->sync, (size_t)(2 * gn->size + 1), true));
-        HP_TRY(norm_launch_end(on));
-        HP_TRY(norm_launch_end(gn));
-    } else {
-        HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
-        HP_TRY(norm_launch_begin(on));
-        HP_TRY(norm_launch_begin(gn));
-        // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
-        HP_TRY(comm_allreduce_mean_f32(a->comm, on->d->sync, (size_t)(2 * on->size + 1)));
-        HP_TRY(comm_allreduce_mean_f32(a->comm, gn->d->sync, (size_t)(2 * gn->size + 1)));
-        HP_TRY(norm_launch_end(on));
-        HP_TRY(norm_launch_end(gn));
-    }
+    // ddpg_agent._update_normalizer (:187-212) behind the merged index draw, then the updates (:145-147), then the soft target
+    // update (:149-150) -- inside the last optimizer launch where the engine can, as its own launch otherwise
+    CycleOpts cyc;
+    cyc.norm_plan = norm_plan;
+    cyc.between = [=]() -> int {
+        if (!a->comm && !a->peer) {   // single rank: update + recompute_stats of both normalizers in one launch
+            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, true));
+        } else if (a->peer) {
+            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
+            HP_TRY(norm_launch_begin(on));
+            HP_TRY(norm_launch_begin(gn));
+            // normalizer._mpi_average (normalizer.py:60-64) through the mailboxes
+            HP_TRY(peer_allreduce_small(a->peer, on->d->sync, (size_t)(2 * on->size + 1), true));
+            HP_TRY(peer_allreduce_small(a->peer, gn->d->sync, (size_t)(2 * gn->size + 1), true));
+            HP_TRY(norm_launch_end(on));
+            HP_TRY(norm_launch_end(gn));
+        } else {
+            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
+            HP_TRY(norm_launch_begin(on));
+            HP_TRY(norm_launch_begin(gn));
+            // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
+            HP_TRY(comm_allreduce_mean_f32(a->comm, on->d->sync, (size_t)(2 * on->size + 1)));
+            HP_TRY(comm_allreduce_mean_f32(a->comm, gn->d->sync, (size_t)(2 * gn->size + 1)));
+            HP_TRY(norm_launch_end(on));
+            HP_TRY(norm_launch_end(gn));
+        }
+        return HP_OK;
+    };
     // ddpg_agent.py:145-150
-    HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq, n_batches, true));
-    HP_TRY(enqueue_polyak(a));
+    HP_TRY(enqueue_updates(a, b, on, gn, rng, future_p, sq, n_batches, true, &cyc));
+    if (!cyc.polyak_folded) HP_TRY(enqueue_polyak(a));
     return HP_OK;
 }
 

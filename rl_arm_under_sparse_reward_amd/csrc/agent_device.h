@@ -31,6 +31,10 @@ struct AdamFuse {
     float action_l2;
     float *loss_log;
     int keep_grads;                   // also write the gradient out (the fused epilogue itself does not need it in memory)
+    // soft update of the target networks folded into this step (last update of a cycle; nullptr otherwise):
+    // tgt = (1 - polyak) * p_new + polyak * tgt (ddpg_agent.py:220-222), fragFT = forward-fragment copy of the targets
+    float *tgt, *fragFT;
+    float polyak, one_minus;
 };
 
 __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
@@ -49,6 +53,11 @@ __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi)
     frag_offsets_any(F.am, idx, of, od);
     if (of >= 0) F.fragF[of] = pn;
     if (od >= 0) F.fragD[od] = pn;
+    if (F.tgt) {   // same expression as k_polyak_frag
+        const float t = __fadd_rn(__fmul_rn(F.one_minus, pn), __fmul_rn(F.polyak, F.tgt[idx]));
+        F.tgt[idx] = t;
+        if (of >= 0) F.fragFT[of] = t;
+    }
 }
 
 // four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
@@ -87,6 +96,14 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
     *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    float tt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (F.tgt) {   // same expression as k_polyak_frag, on the parameters just stepped
+        const float4 t4 = *reinterpret_cast<const float4 *>(F.tgt + idx0);
+        const float told[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tt[j] = __fadd_rn(__fmul_rn(F.one_minus, pp[j]), __fmul_rn(F.polyak, told[j]));
+        *reinterpret_cast<float4 *>(F.tgt + idx0) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+    }
     if (F.am.mode == 1 || F.am.mode == 2) {
         // slab8 / slab32 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's
         // row length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
@@ -94,6 +111,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
         else frag32_offsets(F.am, idx0, of, od);
         if (of >= 0) *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (of >= 0 && F.tgt) *reinterpret_cast<float4 *>(F.fragFT + of) = make_float4(tt[0], tt[1], tt[2], tt[3]);
         if (od >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) F.fragD[od + 4 * j] = pp[j];
@@ -105,6 +123,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
             frag_offsets_any(F.am, idx0 + j, of, od);
             if (of >= 0) F.fragF[of] = pp[j];
             if (od >= 0) F.fragD[od] = pp[j];
+            if (of >= 0 && F.tgt) F.fragFT[of] = tt[j];
         }
     }
 }

@@ -325,6 +325,10 @@ int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const Pl
 }
 
 static AdamFuse adam_fuse(hp_agent *a);
+static void fold_polyak(hp_agent *a, AdamFuse &F) {   // the optimizer launch also steps the targets (GatherCtx::polyak_after)
+    F.tgt = a->targets; F.fragFT = a->fragFT;
+    F.polyak = (float)a->cfg.polyak; F.one_minus = (float)(1.0 - a->cfg.polyak);
+}
 
 static ArenaMap arena_map(const hp_agent *a) {
     ArenaMap am;
@@ -520,6 +524,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
+                if (gc && gc->polyak_after) fold_polyak(a, F);
                 hipLaunchKernelGGL(k_dw64_adam, dim3(grid), dim3(DW_THREADS), 0, s, L.g, F, R, X);
             } else {
                 hipLaunchKernelGGL(k_dw64, dim3(grid), dim3(DW_THREADS), 0, s, L.g, R, X);
@@ -531,6 +536,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
+                if (gc->polyak_after) fold_polyak(a, F);
                 hipLaunchKernelGGL(k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
             } else {
                 hipLaunchKernelGGL(k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
@@ -542,6 +548,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             // the ~6.7 MB this kernel leaves dirty in L2 for the end-of-kernel write-back
             AdamFuse F = adam_fuse(a);
             F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
+            if (gc && gc->polyak_after) fold_polyak(a, F);
             hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
@@ -556,6 +563,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.p = a->params; F.p_out = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
     F.grads_base = a->grads; F.st = a->d_state; F.scal = &a->d_state->neg_step_actor; F.am = arena_map(a); F.n_actor = a->la.total;
     F.keep_grads = 1;
+    F.tgt = nullptr; F.fragFT = nullptr; F.polyak = 0.f; F.one_minus = 0.f;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : S32_ROWS); F.B = a->B;
@@ -564,14 +572,16 @@ static AdamFuse adam_fuse(hp_agent *a) {
     return F;
 }
 
-int enqueue_adam(hp_agent *a) {
+int enqueue_adam(hp_agent *a, bool polyak_after) {
     ProfScope ps(a, PROF_ADAM);
     const int n = a->n_arena;
     if (a->slab) {
+        AdamFuse F = adam_fuse(a);
+        if (polyak_after) fold_polyak(a, F);
         if (n % 4 == 0 && a->la.total % 4 == 0)
-            hipLaunchKernelGGL(k_adam_frag4, dim3((n / 4 + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n / 4);
+            hipLaunchKernelGGL(k_adam_frag4, dim3((n / 4 + 255) / 256), dim3(256), 0, a->ctx->stream, F, a->grads, n / 4);
         else
-            hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, adam_fuse(a), a->grads, n);
+            hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, F, a->grads, n);
         HP_CHECK_HIP(hipGetLastError());
         return HP_OK;
     }
@@ -606,8 +616,9 @@ int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc, bool fuse_adam, b
     return enqueue_forward_backward_layers(a);
 }
 
-int enqueue_peer_adam(hp_agent *a, int u) {
+int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after) {
     AdamFuse F = adam_fuse(a);
+    if (polyak_after) fold_polyak(a, F);
     F.grads_base = a->grads;
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;   // RLARM_KEEP_GRADS=1: hp_agent_get_grads then returns the exchanged sum
     ProfScope ps(a, PROF_ADAM);

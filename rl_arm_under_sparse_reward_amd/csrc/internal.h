@@ -221,6 +221,9 @@ int comm_allreduce_mean_f32(hp_comm *c, float *dev, size_t n);   // normalizer.p
 int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,
                     int32_t n_batches, double future_p, PlanRec *d_plan, hipStream_t stream = nullptr);
 int rng_launch_slots(hp_rng *rng, hp_buffer *buf, int64_t n_new, int64_t *d_slots);
+// normalizer plan (batch_first transitions out of n_first staged episodes) + the first n_batches minibatch plans, one launch
+int rng_launch_plan2(hp_rng *rng, int64_t n_first, int32_t T, int64_t batch_first, PlanRec *d_plan_first,
+                     const BufMeta *d_meta, int64_t batch, int32_t n_batches, double future_p, PlanRec *d_plan);
 
 // buffer.hip
 int buffer_launch_gather_dict(hp_buffer *buf, const PlanRec *d_plan, int64_t batch, double sq_threshold,

@@ -192,10 +192,9 @@ __device__ __forceinline__ void mt_draw_double(MtWg &g, long long count, Emit em
 // her.py:24-33 for `n_batches` consecutive minibatches (shared by k_draw_plan and the plan workgroup that rides
 // along with the backward slab kernel): plan[b*batch + i] = (e, t, future_t, her).  Must be executed by exactly
 // MT_THREADS threads of one workgroup (threadIdx.x < MT_THREADS); `ring` = uint32[4][624], `ibuf` = int[MT_IBUF] in LDS.
-__device__ __forceinline__ void mt_her_plan(MtState *st, long long n_eps, int T, long long batch, int n_batches,
-                                            double future_p, PlanRec *plan, uint32_t (*ring)[MT_N], int *ibuf) {
-    MtWg g;
-    mt_load(g, st, ring, ibuf);
+// the draws of mt_her_plan on a stream already loaded into LDS (several plans in one kernel: k_draw_plan2)
+__device__ __forceinline__ void mt_her_draw(MtWg &g, long long n_eps, int T, long long batch, int n_batches, double future_p,
+                                            PlanRec *plan) {
     if (n_eps <= 0 || T <= 0) return;  // host refuses this case (ValueError: high <= 0)
     for (int b = 0; b < n_batches; ++b) {
         PlanRec *p = plan + (long long)b * batch;
@@ -210,5 +209,13 @@ __device__ __forceinline__ void mt_her_plan(MtState *st, long long n_eps, int T,
         });
         __syncthreads();
     }
+}
+
+__device__ __forceinline__ void mt_her_plan(MtState *st, long long n_eps, int T, long long batch, int n_batches,
+                                            double future_p, PlanRec *plan, uint32_t (*ring)[MT_N], int *ibuf) {
+    MtWg g;
+    mt_load(g, st, ring, ibuf);
+    if (n_eps <= 0 || T <= 0) return;  // host refuses this case (ValueError: high <= 0)
+    mt_her_draw(g, n_eps, T, batch, n_batches, future_p, plan);
     mt_store(g, st);
 }

@@ -14,6 +14,21 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_plan(MtState *st, const Buf
     mt_her_plan(st, n_eps, T, batch, n_batches, future_p, plan, ring, ibuf);
 }
 
+// Cycle boundary: the index plan of ddpg_agent._update_normalizer (:187-212: T transitions out of the n_first episodes staged
+// by the last store) and the first plans of the n_batches updates that follow (:145-147), drawn back to back from ONE load of
+// the stream -- the same words in the same order as two k_draw_plan launches, one launch and one state round trip less.
+__global__ __launch_bounds__(MT_THREADS) void k_draw_plan2(MtState *st, long long n_first, int T, long long batch_first,
+                                                          PlanRec *plan_first, const BufMeta *meta, long long batch,
+                                                          int n_batches, double future_p, PlanRec *plan) {
+    __shared__ uint32_t ring[4][MT_N];
+    __shared__ int ibuf[MT_IBUF];
+    MtWg g;
+    mt_load(g, st, ring, ibuf);
+    mt_her_draw(g, n_first, T, batch_first, 1, future_p, plan_first);
+    mt_her_draw(g, meta->current_size, T, batch, n_batches, future_p, plan);
+    mt_store(g, st);
+}
+
 // replay_buffer._get_storage_idx (replay_buffer.py:57-71); updates the device counters.
 __global__ __launch_bounds__(MT_THREADS) void k_draw_slots(MtState *st, BufMeta *meta, long long size, int T,
                                                           long long inc, long long *slots) {
@@ -66,6 +81,14 @@ int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int
                     int32_t n_batches, double future_p, PlanRec *d_plan, hipStream_t stream) {
     hipLaunchKernelGGL(k_draw_plan, dim3(1), dim3(MT_THREADS), 0, stream ? stream : rng->ctx->stream, rng->d_state, d_meta,
                        (long long)n_eps_fixed, (int)T, (long long)batch, (int)n_batches, future_p, d_plan);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+int rng_launch_plan2(hp_rng *rng, int64_t n_first, int32_t T, int64_t batch_first, PlanRec *d_plan_first,
+                     const BufMeta *d_meta, int64_t batch, int32_t n_batches, double future_p, PlanRec *d_plan) {
+    hipLaunchKernelGGL(k_draw_plan2, dim3(1), dim3(MT_THREADS), 0, rng->ctx->stream, rng->d_state, (long long)n_first, (int)T,
+                       (long long)batch_first, d_plan_first, d_meta, (long long)batch, (int)n_batches, future_p, d_plan);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
