@@ -6,11 +6,6 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/r03; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.log 2>&1; tail -1 $O/bench_driver_style.log > $O/bench_n1_b256_driver_style.json
-python bench.py --steps 4000 --warmup 400 > $O/bench_b256.log 2>&1; tail -1 $O/bench_b256.log > $O/bench_n1_b256.json
-python bench.py --batch 1024 --steps 2000 --warmup 200 --cpu-seconds 10 > $O/bench_b1024.log 2>&1; tail -1 $O/bench_b1024.log > $O/bench_n1_b1024.json
-python bench.py --batch 512 --replay-k 8 --steps 2000 --warmup 200 --cpu-seconds 10 > $O/bench_b512k8.log 2>&1; tail -1 $O/bench_b512k8.log > $O/bench_n1_b512_k8.json
-python bench.py --batch 4096 --steps 800 --warmup 80 --no-cpu-baseline > $O/bench_b4096.log 2>&1; tail -1 $O/bench_b4096.log > $O/bench_n1_b4096.json
 for cfg in "256 4 2000 400" "1024 4 800 80" "512 8 800 80" "4096 4 400 80"; do set -- $cfg; B=$1; K=$2; S=$3; W=$4
   CMD="python bench.py --batch $B --replay-k $K --steps $S --warmup $W --no-cpu-baseline --no-profile"
   d=$O/trace_b$B; mkdir -p $d
@@ -27,6 +22,15 @@ for cfg in "256 4" "512 8" "1024 4" "4096 4"; do set -- $cfg; B=$1; K=$2
   done
   python tools/pmc_summary.py $O/pmc_FETCH_SIZE_b$B/pmc_results.db $O/pmc_WRITE_SIZE_b$B/pmc_results.db --json $O/pmc_traffic_b$B.json --note "batch $B replay_k $K" > $O/pmc_fetch_write_b$B.txt 2>&1
 done
+# the bench lines come AFTER the counter passes: roofline.traffic is read from profiles/r03_pmc_traffic_b*.json and checked against
+# the kernel sources' fingerprint (traffic_stale)
+for B in 256 512 1024 4096; do cp $O/pmc_traffic_b$B.json profiles/r03_pmc_traffic_b$B.json; done
+for cfg in "256 4" "512 8" "1024 4" "4096 4"; do set -- $cfg; cp $O/kernel_trace_b$1_k$2.txt profiles/r03_kernel_trace_b$1_k$2.txt; done
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.log 2>&1; tail -1 $O/bench_driver_style.log > $O/bench_n1_b256_driver_style.json
+python bench.py --steps 4000 --warmup 400 > $O/bench_b256.log 2>&1; tail -1 $O/bench_b256.log > $O/bench_n1_b256.json
+python bench.py --batch 1024 --steps 2000 --warmup 200 --cpu-seconds 10 > $O/bench_b1024.log 2>&1; tail -1 $O/bench_b1024.log > $O/bench_n1_b1024.json
+python bench.py --batch 512 --replay-k 8 --steps 2000 --warmup 200 --cpu-seconds 10 > $O/bench_b512k8.log 2>&1; tail -1 $O/bench_b512k8.log > $O/bench_n1_b512_k8.json
+python bench.py --batch 4096 --steps 800 --warmup 80 --no-cpu-baseline > $O/bench_b4096.log 2>&1; tail -1 $O/bench_b4096.log > $O/bench_n1_b4096.json
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY"; do
   i=$((i+1)); d=$O/pmcs_$i; mkdir -p $d
