@@ -1,0 +1,33 @@
+"""Fixed cost of one hp_agent_sample_and_update(n) call (cached hipGraph of n updates) on an idle GPU: wall time from the call
+to the end of ctx.synchronize(), minus n x the steady-state update.  How much of the driver's 20-step region is launch latency,
+and does it grow with the number of graph nodes?"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import argparse
+import numpy as np
+import bench
+a = argparse.Namespace(gpus=1, steps=20, warmup=5, batch=256, episodes=5000, replay_k=4, feeder_episodes=0, feeder_envs=0,
+                       feeder_workers=8, no_cpu_baseline=True, no_profile=True, cpu_seconds=1.0)
+r = bench.Runner(a, 0, 1)
+ag = r.agent
+r.run_steps(40); r.sync()
+# steady state: 400 updates back to back
+ag._update_network(40); r.sync()
+t0 = time.perf_counter()
+for _ in range(10): ag._update_network(40)
+r.sync()
+steady = 1e6 * (time.perf_counter() - t0) / 400
+print(f"steady state {steady:.2f} us/update")
+for n in (1, 2, 3, 5, 10, 20, 40):
+    ag._update_network(n); r.sync()          # graph for this n is cached now
+    ts = []
+    for rep in range(9):
+        time.sleep(0.002)                    # idle GPU, like a caller that waited for the previous result
+        t0 = time.perf_counter()
+        ag._update_network(n)
+        t1 = time.perf_counter()
+        r.ctx.synchronize()
+        t2 = time.perf_counter()
+        ts.append((1e6 * (t1 - t0), 1e6 * (t2 - t0)))
+    enq = float(np.median([x[0] for x in ts])); tot = float(np.median([x[1] for x in ts]))
+    print(f"n={n:3d}: call returns after {enq:6.1f} us, done after {tot:7.1f} us -> fixed cost {tot - n * steady:6.1f} us ({(tot - n * steady) / n:5.2f} us/update)")
