@@ -68,7 +68,8 @@ struct AgentDevState {      // small device-resident scalars
     long long step;         // Adam step counter (both optimizers step together)
     long long n_logged;     // number of loss pairs written
     // per-step Adam scalars (torch computes them in Python doubles and narrows where used)
-    float neg_step_actor, neg_step_critic, bc2_sqrt, pad;
+    float neg_step_actor, neg_step_critic, bc2_sqrt;
+    unsigned open_timeouts; // k_cycle_open: hand-off polls that gave up (always 0; reported by hp_agent_get_losses)
 };
 
 struct AdamCfg {
@@ -170,6 +171,10 @@ struct hp_agent {
     std::vector<UpdGraph> upd_graphs;
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
+    unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
+    bool cycle_open = true;              // RLARM_CYCLE_OPEN=0: slots / scatter / plans / normalizer as separate launches
+    bool g_open = false;
+    void *g_slots = nullptr;
     hp_buffer *g_buf = nullptr;
     hp_norm *g_on = nullptr, *g_gn = nullptr;
     hp_rng *g_rng = nullptr;
@@ -332,6 +337,10 @@ int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fu
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
 int enqueue_adam(hp_agent *a, bool polyak_after = false);   // polyak_after: see GatherCtx (slab engines; returns whether via *folded)
 int enqueue_polyak(hp_agent *a);
+// cycle_open.hip: slots + scatter + normalizer update + first minibatch plans of a cycle as one launch
+bool cycle_open_fits(const hp_agent *a, int64_t n_new);
+int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, PlanRec *norm_plan, int n_first,
+                      double future_p, bool recompute);
 // utils.sync_grads (utils.py:43-48) + both Adam steps of update u as the peer exchange's optimizer kernel(s) (peer.hip)
 int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after = false);
 // can the optimizer launches of this agent apply the soft target update themselves?  (slab engines: yes)

@@ -35,7 +35,9 @@ static int check_handles(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
 // launch also applies the soft target update where the engine can (cyc->polyak_folded tells the caller).
 struct CycleOpts {
     PlanRec *norm_plan;
-    std::function<int()> between;
+    bool open;                       // slots, scatter, normalizer update and the draws as ONE launch (cycle_open.hip)
+    bool recompute;                  // single rank: recompute_stats inside the normalizer update
+    std::function<int()> between;    // what follows the draws and precedes the first update
     bool polyak_folded = false;
 };
 static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq,
@@ -67,7 +69,9 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     {
         ProfScope ps(a, PROF_PLAN);
         const int first = ride ? (n_updates < lead ? n_updates : lead) : n_updates;
-        if (cyc)   // ddpg_agent._update_normalizer's plan (T transitions of the staged episodes), then the first minibatch plans
+        if (cyc && cyc->open)
+            HP_TRY(cycle_open_launch(a, b, on, gn, rng, cyc->norm_plan, first, future_p, cyc->recompute));
+        else if (cyc)   // ddpg_agent._update_normalizer's plan (T transitions of the staged episodes), then the first minibatch plans
             HP_TRY(rng_launch_plan2(rng, b->staged_n, b->T, b->T, cyc->norm_plan, b->d_meta, a->B, first, future_p,
                                     a->plan.as<PlanRec>()));
         else
@@ -301,6 +305,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->fb_prefetch = tri("RLARM_FB_PREFETCH");
         a->upd_graph_ok = tri("RLARM_UPDATE_GRAPH") != 0;
         a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
+        a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
         if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
         // weight gradients: 64 x 64 tiles with split batch rows (dw64.h) where the 32 x 32 tiles are L2-bound
         // (us/update, 32 x 32 tiles vs dw64: 56.6 / 58.9 at batch 1024, 85.8 / 85.1 at 1536, 93.9 / 92.2 at 2048, 146 / 128 at 4096)
@@ -314,6 +319,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         if (!ah && chains + 1 + S8_AHEAD_WGS > cus) a->gather_ahead = false;
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
+    if (st == HP_OK) st = dev_alloc(a, &a->open_sync, 4);
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
     if (st == HP_OK && a->dw64) {
         Launch L = build_dw_group(a, a->XA, a->XP);
@@ -554,6 +560,8 @@ int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
     HP_CHECK_HIP(hipMemcpyAsync(&h, a->d_state, sizeof(h), hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipMemcpyAsync(log.data(), a->loss_log, log.size() * 4, hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_REQUIRE(h.open_timeouts == 0u, HP_ERR_STATE, "hp_agent_get_losses: %u hand-off polls of the cycle-opening launch gave up "
+               "(k_cycle_open): the cycles since are not valid", h.open_timeouts);
     HP_REQUIRE(h.n_logged >= n_last, HP_ERR_STATE, "hp_agent_get_losses: only %lld updates logged", h.n_logged);
     for (int i = 0; i < n_last; ++i) {
         const long long k = h.n_logged - n_last + i;
@@ -571,18 +579,20 @@ int hp_agent_soft_update(hp_agent *a) {
 
 }  // extern "C" (re-opened below)
 
-// device part of one cycle after the episodes are staged: slots+scatter happen in buffer_stage_and_store
+// device part of one cycle after the episodes are staged.  open: slots + scatter are part of it (k_cycle_open); otherwise they
+// happened in buffer_stage_and_store
 static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p,
-                              double sq, int n_batches, PlanRec *norm_plan) {
+                              double sq, int n_batches, PlanRec *norm_plan, bool open) {
     // ddpg_agent._update_normalizer (:187-212) behind the merged index draw, then the updates (:145-147), then the soft target
     // update (:149-150) -- inside the last optimizer launch where the engine can, as its own launch otherwise
     CycleOpts cyc;
     cyc.norm_plan = norm_plan;
+    cyc.open = open;
+    cyc.recompute = !a->comm && !a->peer;   // single rank: update + recompute_stats of both normalizers in one launch
     cyc.between = [=]() -> int {
-        if (!a->comm && !a->peer) {   // single rank: update + recompute_stats of both normalizers in one launch
-            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, true));
+        if (!open) HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, !a->comm && !a->peer));
+        if (!a->comm && !a->peer) {
         } else if (a->peer) {
-            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
             HP_TRY(norm_launch_begin(on));
             HP_TRY(norm_launch_begin(gn));
             // normalizer._mpi_average (normalizer.py:60-64) through the mailboxes
@@ -591,7 +601,6 @@ static int enqueue_cycle_tail(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
             HP_TRY(norm_launch_end(on));
             HP_TRY(norm_launch_end(gn));
         } else {
-            HP_TRY(norm_launch_update_from_plan(on, gn, b, norm_plan, b->T, a->cfg.clip_obs, false));
             HP_TRY(norm_launch_begin(on));
             HP_TRY(norm_launch_begin(gn));
             // normalizer._mpi_average (normalizer.py:60-64) on sum | sumsq | count of each normalizer
@@ -661,17 +670,20 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
     HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_train_cycle: profiling mode uses the eager path (hp_agent_profile(0) first)");
     HP_TRY(peer_check_alive(a->peer, "hp_agent_train_cycle"));
     hipStream_t s = a->ctx->stream;
-    // 1. episodes -> pinned -> device staging, slots, scatter (eager: the source pointers change per call)
-    HP_TRY(buffer_stage_and_store(b, rng, obs, ag_host, g, actions, n_new));
+    // 1. episodes -> pinned -> device staging (eager: the source pointers change per call); slots and scatter: part of the
+    // opening launch of the graph, or eager launches as well when that launch is switched off / would not fit the CUs
+    const bool open = a->cycle_open && cycle_open_fits(a, n_new);
+    if (open) HP_TRY(buffer_stage_for_cycle(b, obs, ag_host, g, actions, n_new));
+    else HP_TRY(buffer_stage_and_store(b, rng, obs, ag_host, g, actions, n_new));
     // 2. everything else is one graph; rebuild when a baked-in argument changes
     const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
                       a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&
-                      a->g_sq == sq_threshold && a->g_stage == b->st_obs.p;
+                      a->g_sq == sq_threshold && a->g_stage == b->st_obs.p && a->g_slots == b->st_slots.p && a->g_open == open;
     if (s == hipStreamLegacy) a->graph_refused = true;   // the legacy default stream cannot be captured: eager launches
     if (a->graph_refused) {   // see below
         HP_TRY(ensure_plan(a, n_batches));
         HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
-        HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>()));
+        HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>(), open));
         a->host_steps += n_batches;
         return HP_OK;
     }
@@ -690,7 +702,7 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
         HP_CHECK_HIP(hipStreamSynchronize(s));
         hipGraph_t graph = nullptr;
         HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int st = enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>());
+        int st = enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>(), open);
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (st == HP_OK && e == hipSuccess) {
             e = hipGraphInstantiate(&a->graph, graph, nullptr, nullptr, 0);
@@ -707,13 +719,15 @@ int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp
             // ordinary launches from now on; the other ranks see the same sequence of collectives either way.
             (void)hipGetLastError();
             a->graph_refused = true;
-            HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>()));
+            HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>(), open));
             a->host_steps += n_batches;
             return HP_OK;
         }
         a->g_buf = b; a->g_on = on; a->g_gn = gn; a->g_rng = rng;
         a->g_n_new = n_new; a->g_n_batches = n_batches; a->g_future_p = future_p; a->g_sq = sq_threshold;
         a->g_stage = b->st_obs.p;
+        a->g_slots = b->st_slots.p;
+        a->g_open = open;
     }
     HP_CHECK_HIP(hipGraphLaunch(a->graph, s));
     a->host_steps += n_batches;

@@ -10,7 +10,7 @@
 //
 // Built with -ffp-contract=off: the reward must round exactly like numpy's
 // (x0*x0 + x1*x1) + x2*x2 in float64, so no multiply-add may be fused.
-#include "internal.h"
+#include "store_device.h"
 
 #include <cmath>
 
@@ -91,17 +91,8 @@ __global__ __launch_bounds__(256) void k_store_scatter(const long long *__restri
                                                        long long ep_g, long long ep_act) {
     // STORE_PARTS workgroups per episode, each a strided share of its values: one or two copies per thread instead of a
     // loop of fifteen dependent-latency iterations (the copy of 2 episodes was 9.6 us of every cycle)
-    const long long i = blockIdx.x / STORE_PARTS;
-    const int part = blockIdx.x % STORE_PARTS;
-    const long long slot = slots[i];
-    int dup = 0;
-    for (long long j = i + 1 + threadIdx.x; j < n_new; j += blockDim.x) dup |= (slots[j] == slot);
-    if (__syncthreads_or(dup)) return;
-    const long long t0 = (long long)part * blockDim.x + threadIdx.x, step = (long long)STORE_PARTS * blockDim.x;
-    for (long long k = t0; k < ep_obs; k += step) obs[slot * ep_obs + k] = s_obs[i * ep_obs + k];
-    for (long long k = t0; k < ep_ag; k += step) ag[slot * ep_ag + k] = s_ag[i * ep_ag + k];
-    for (long long k = t0; k < ep_g; k += step) g[slot * ep_g + k] = s_g[i * ep_g + k];
-    for (long long k = t0; k < ep_act; k += step) act[slot * ep_act + k] = s_act[i * ep_act + k];
+    store_scatter_share([&](long long j) { return slots[j]; }, blockIdx.x / STORE_PARTS, blockIdx.x % STORE_PARTS, STORE_PARTS,
+                        n_new, s_obs, s_ag, s_g, s_act, obs, ag, g, act, ep_obs, ep_ag, ep_g, ep_act);
 }
 
 // ------------------------------------------------------------------------------ launchers
@@ -160,6 +151,15 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
                        (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
     HP_CHECK_HIP(hipGetLastError());
     // host mirror of replay_buffer.py:68 and :43
+    b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
+    b->n_transitions_stored += (int64_t)b->T * n_new;
+    return HP_OK;
+}
+
+int buffer_stage_for_cycle(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
+                           int64_t n_new) {
+    HP_TRY(b->st_slots.ensure(n_new * 8));
+    HP_TRY(buffer_stage(b, obs, ag, g, actions, n_new));
     b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
     b->n_transitions_stored += (int64_t)b->T * n_new;
     return HP_OK;

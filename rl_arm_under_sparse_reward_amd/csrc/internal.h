@@ -230,6 +230,9 @@ int buffer_launch_gather_dict(hp_buffer *buf, const PlanRec *d_plan, int64_t bat
                               double *d_out, float *d_r, double *d_r64);
 int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const double *ag, const double *g,
                            const double *actions, int64_t n_new);
+// the staging half alone (+ the host mirror of the counters): slots and scatter follow in k_cycle_open (cycle_open.hip)
+int buffer_stage_for_cycle(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
+                           int64_t n_new);
 
 // norm.hip
 int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,

@@ -189,23 +189,50 @@ __device__ __forceinline__ void mt_draw_double(MtWg &g, long long count, Emit em
     }
 }
 
+// Stores of a draw's results.  WT: write-through (agent-scope relaxed atomic = sc1 store), for results that ANOTHER workgroup of
+// the same launch reads after a flag (k_cycle_open); plain otherwise (the reader is a later launch).
+template <bool WT> __device__ __forceinline__ void mt_put(int *p, int v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void mt_put(long long *p, long long v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// replay_buffer._get_storage_idx (replay_buffer.py:57-71) for `inc` new episodes on top of `cur` stored ones: consecutive slots
+// while the buffer has room, uniform random ones for the overflow (the only branch that consumes the stream).
+template <bool WT = false>
+__device__ __forceinline__ void mt_draw_slots(MtWg &g, long long cur, long long size, long long inc, long long *slots) {
+    if (cur + inc <= size) {
+        for (long long i = threadIdx.x; i < inc; i += MT_THREADS) mt_put<WT>(slots + i, cur + i);
+    } else if (cur < size) {
+        const long long head = size - cur, overflow = inc - head;
+        for (long long i = threadIdx.x; i < head; i += MT_THREADS) mt_put<WT>(slots + i, cur + i);
+        mt_draw_bounded(g, (uint32_t)(cur - 1), overflow, [&](long long i, uint32_t v) { mt_put<WT>(slots + head + i, (long long)v); });
+    } else {
+        mt_draw_bounded(g, (uint32_t)(size - 1), inc, [&](long long i, uint32_t v) { mt_put<WT>(slots + i, (long long)v); });
+    }
+}
+
 // her.py:24-33 for `n_batches` consecutive minibatches (shared by k_draw_plan and the plan workgroup that rides
 // along with the backward slab kernel): plan[b*batch + i] = (e, t, future_t, her).  Must be executed by exactly
 // MT_THREADS threads of one workgroup (threadIdx.x < MT_THREADS); `ring` = uint32[4][624], `ibuf` = int[MT_IBUF] in LDS.
 // the draws of mt_her_plan on a stream already loaded into LDS (several plans in one kernel: k_draw_plan2)
+template <bool WT = false>
 __device__ __forceinline__ void mt_her_draw(MtWg &g, long long n_eps, int T, long long batch, int n_batches, double future_p,
                                             PlanRec *plan) {
     if (n_eps <= 0 || T <= 0) return;  // host refuses this case (ValueError: high <= 0)
     for (int b = 0; b < n_batches; ++b) {
         PlanRec *p = plan + (long long)b * batch;
-        mt_draw_bounded(g, (uint32_t)(n_eps - 1), batch, [&](long long i, uint32_t v) { p[i].e = (int)v; });
-        mt_draw_bounded(g, (uint32_t)(T - 1), batch, [&](long long i, uint32_t v) { p[i].t = (int)v; });
-        mt_draw_double(g, batch, [&](long long i, double u) { p[i].her = (u < future_p) ? 1 : 0; });
+        mt_draw_bounded(g, (uint32_t)(n_eps - 1), batch, [&](long long i, uint32_t v) { mt_put<WT>(&p[i].e, (int)v); });
+        mt_draw_bounded(g, (uint32_t)(T - 1), batch, [&](long long i, uint32_t v) { mt_put<WT>(&p[i].t, (int)v); });
+        mt_draw_double(g, batch, [&](long long i, double u) { mt_put<WT>(&p[i].her, (u < future_p) ? 1 : 0); });
         __syncthreads();  // p[i].t may have been written by another thread
         mt_draw_double(g, batch, [&](long long i, double u) {
             int t = p[i].t;
             double off = u * (double)(T - t);  // her.py:31 (float64 * int64)
-            p[i].fut = t + 1 + (int)off;       // her.py:32-33 (astype(int) truncates)
+            mt_put<WT>(&p[i].fut, t + 1 + (int)off);   // her.py:32-33 (astype(int) truncates)
         });
         __syncthreads();
     }

@@ -35,19 +35,13 @@ __global__ __launch_bounds__(MT_THREADS) void k_draw_slots(MtState *st, BufMeta 
     __shared__ uint32_t ring[4][MT_N];
     __shared__ int ibuf[MT_IBUF];
     const long long cur = meta->current_size;
-    if (cur + inc <= size) {
-        for (long long i = threadIdx.x; i < inc; i += MT_THREADS) slots[i] = cur + i;
+    if (cur + inc <= size) {   // no draw: the stream is not even loaded
+        MtWg g{};
+        mt_draw_slots(g, cur, size, inc, slots);
     } else {
         MtWg g;
         mt_load(g, st, ring, ibuf);
-        if (cur < size) {
-            const long long head = size - cur, overflow = inc - head;
-            for (long long i = threadIdx.x; i < head; i += MT_THREADS) slots[i] = cur + i;
-            mt_draw_bounded(g, (uint32_t)(cur - 1), overflow,
-                            [&](long long i, uint32_t v) { slots[head + i] = (long long)v; });
-        } else {
-            mt_draw_bounded(g, (uint32_t)(size - 1), inc, [&](long long i, uint32_t v) { slots[i] = (long long)v; });
-        }
+        mt_draw_slots(g, cur, size, inc, slots);
         mt_store(g, st);
     }
     __syncthreads();
