@@ -48,15 +48,21 @@ struct GemmProb {
     int n_store;         // only columns < n_store are written
     int epi;
     int tile0, tiles_n;  // first workgroup of this problem, tiles along N
+    int ks, part0;       // ks > 1: the reduction of every tile is split over ks workgroups (slice-major behind tile0) that meet
+                         // through GemmGroup::part / ticket, entries part0 + tile (gemm_lds.h, ring path only)
     float max_action;    // EPI_BIAS_TANH
 };
 
 #define MAX_PROBS 8
+#define GL_PART (32 * 32 + 32)   // floats of one partial tile in the split-reduction exchange (gemm_lds.h): the tile, then its column sums
+#define GL_MAX_SPLIT_TILES 64
 struct GemmGroup {
     int n;
     int pipe;   // per-wave LDS-DMA rings for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: workgroup-staged chunks, for A/B)
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
     int pad_;
+    float *part;                  // split tiles: GL_PART floats per (tile, slice)
+    unsigned long long *ticket;   // split tiles: arrival counter per tile, monotonic over the life of the agent
     GemmProb p[MAX_PROBS];
 };
 
@@ -172,6 +178,9 @@ struct hp_agent {
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
     unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
+    int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
+    float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)
+    unsigned long long *gl_ticket = nullptr;
     bool cycle_open = true;              // RLARM_CYCLE_OPEN=0: slots / scatter / plans / normalizer as separate launches
     bool g_open = false;
     void *g_slots = nullptr;
@@ -221,6 +230,18 @@ struct Launch {  // builds one grouped launch
         g.n = 0;
         g.xcd = 0;
         g.pad_ = 0;
+        g.part = nullptr;
+        g.ticket = nullptr;
+    }
+    int split_tiles = 0;   // tiles whose reduction is split (entries of part / ticket in use)
+    // split the reduction of the problem added last over `ks` workgroups per tile
+    void split_last(int ks) {
+        GemmProb &p = g.p[g.n - 1];
+        const int nt = tiles - p.tile0;
+        p.ks = ks;
+        p.part0 = split_tiles;
+        split_tiles += nt;
+        tiles += (ks - 1) * nt;
     }
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and everything a weight-gradient tile reads
     // was written by the previous kernel on other XCDs: it comes through the fabric once per XCD that touches it.  In
@@ -237,6 +258,7 @@ struct Launch {  // builds one grouped launch
         memset(&p, 0, sizeof(p));
         p.M = M; p.N = N; p.K = K;
         p.n_store = N;
+        p.ks = 1;
         p.tiles_n = (N + 31) / 32;
         p.tile0 = tiles;
         tiles += ((M + 31) / 32) * p.tiles_n;

@@ -320,6 +320,19 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->open_sync, 4);
+    if (st == HP_OK && a->slab) {   // split narrow weight-gradient tiles (gemm_lds.h): 4 slices from 768 batch rows (us/update with
+        // 1 / 2 / 4 / 8 slices: 58.6 / 57.1 / 55.6 / 60.0 at batch 1024; 47.7 / 48.2 / 48.2 / 52.4 at 512 k8; 40.6 / 41.9 / 42.7 / - at 256;
+        // 1 vs 4 slices: 54.2 / 53.1 at 768, 55.6 / 54.1 at 896, 82.1 / 78.9 at 1152, 83.6 / 79.2 at 1280)
+        const char *e = getenv("RLARM_DW_KSPLIT");
+        a->dw_ksplit = e ? atoi(e) : (a->Mp >= 768 ? 4 : 1);
+        if (a->dw_ksplit < 1 || a->dw_ksplit > 8) a->dw_ksplit = 1;
+        const int H = a->H;
+        const int narrow = 2 * ((H + 31) / 32) + ((H + 31) / 32) * (((a->lc.K1 + 31) / 32) + ((a->la.K1 + 31) / 32));
+        if (narrow <= GL_MAX_SPLIT_TILES) {
+            st = dev_alloc(a, &a->gl_part, (size_t)GL_MAX_SPLIT_TILES * 8 * GL_PART);
+            if (st == HP_OK) st = dev_alloc(a, &a->gl_ticket, GL_MAX_SPLIT_TILES);
+        }
+    }
     if (st == HP_OK) st = dev_alloc(a, &a->timeline, 192);
     if (st == HP_OK && a->dw64) {
         Launch L = build_dw_group(a, a->XA, a->XP);

@@ -150,3 +150,12 @@ __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
         F.st->n_logged = k + 1;
     }
 }
+
+// write-through (sc1) stores: visible to other XCDs once drained (s_waitcnt vmcnt(0)); readers use agent-scope loads
+__device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store4(float *p, const float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}

@@ -360,10 +360,20 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
     add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
     add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
     add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+    // the narrow problems (heads, first layers: 40 tiles at the reference shapes) follow as second workgroups on CUs that
+    // already hold a 256 x 256 tile; with a long reduction their batch rows are split over ks workgroups each, so that no CU
+    // carries two full tiles (gemm_lds.h)
+    const int ks = (!a->dw64 && a->gl_part && a->dw_ksplit > 1 && Mp >= GL_RING_MIN_K) ? a->dw_ksplit : 1;   // ring path only
     add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+    if (ks > 1) L.split_last(ks);
     add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+    if (ks > 1) L.split_last(ks);
     add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+    if (ks > 1) L.split_last(ks);
     add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+    if (ks > 1) L.split_last(ks);
+    L.g.part = a->gl_part;
+    L.g.ticket = a->gl_ticket;
     if (a->gemm_xcd) L.place_on_xcds();
     return L;
 }

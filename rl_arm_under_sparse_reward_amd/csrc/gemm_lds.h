@@ -133,7 +133,12 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     const bool placed = grp.xcd && bx < 256;   // Launch::place_on_xcds
     if (placed) pi = (bx & 7) >> 1;
     const GemmProb &p = grp.p[pi];
-    const int t = bx - p.tile0;
+    int t = bx - p.tile0, slice = 0;
+    if (p.ks > 1) {   // slice-major: the slices of a tile are a whole problem apart in the launch order
+        const int nt = ((p.M + 31) >> 5) * p.tiles_n;
+        slice = t / nt;
+        t -= slice * nt;
+    }
     int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     if (placed) {   // XCD x = bx & 7: problem x / 2, row-panel half x % 2, all 8 column panels
         const int slot = bx >> 3;
@@ -189,10 +194,14 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         const int h = lane >> 5, l = lane & 31;
         const int rsub = lane >> 3, chunk = lane & 7;
         const int gchA = chunk < (vm >> 2) ? chunk : (vm >> 2) - 1, gchB = chunk < (vn >> 2) ? chunk : (vn >> 2) - 1;
-        const float *srcA = Abase + (long long)(8 * wave + rsub) * p.a_sk + 4 * gchA;
-        const float *srcB = Bbase + (long long)(8 * wave + rsub) * p.b_sk + 4 * gchB;
+        // a split tile's workgroup walks its slice of the batch rows (whole turns of 64 rows)
+        const int kslice = p.ks > 1 ? (((p.K + p.ks - 1) / p.ks + 63) & ~63) : p.K;
+        const int k_begin = slice * kslice;
+        const int k_len = (k_begin + kslice < p.K ? k_begin + kslice : p.K) - k_begin;   // may be <= 0 for a trailing slice
+        const float *srcA = Abase + (long long)(k_begin + 8 * wave + rsub) * p.a_sk + 4 * gchA;
+        const float *srcB = Bbase + (long long)(k_begin + 8 * wave + rsub) * p.b_sk + 4 * gchB;
         const long long stepA = 64LL * p.a_sk, stepB = 64LL * p.b_sk;
-        const int nblk = (p.K - 8 * wave + 63) >> 6;   // K is a multiple of 8
+        const int nblk = k_len > 8 * wave ? (k_len - 8 * wave + 63) >> 6 : 0;   // K is a multiple of 8
         for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) {
             gl_dma(ring + (i2 & 3) * 512, srcA + i2 * stepA);
             gl_dma(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
@@ -262,23 +271,62 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     }
     __syncthreads();
     GL_STAMP(3);
+    float sb = 0.f;
     if (want_bias_grad && tid < vm) {
-        float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < GL_WAVES; ++w) s += bsum[w][tid];
-        p.bias_grad[m0 + tid] = s;
-        if (ADAM) adam_apply(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, s);
+        for (int w = 0; w < GL_WAVES; ++w) sb += bsum[w][tid];
+    }
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (etile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = erow * 33 + ecol + j;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < GL_WAVES; ++w) s += lds[w * (32 * 33) + o];
+            v[j] = s;
+        }
+    }
+    if (ring_path && p.ks > 1) {
+        // Split reduction (the narrow problems of a large minibatch: without it 40 CUs carry two full tiles and the launch is as
+        // long as those): every slice writes its partial tile write-through, takes a ticket, and the LAST one to arrive sums the
+        // ks partials in slice order and runs the epilogue -- nobody waits, the order of the sum is fixed (dw64.h has the same
+        // hand-off: sc1 stores, drained, one relaxed agent-scope atomic; the reader uses agent-scope loads).
+        float *mine = grp.part + ((size_t)(p.part0 + t) * p.ks + slice) * GL_PART;
+        if (tid < 256) wt_store4(mine + erow * 32 + ecol, make_float4(v[0], v[1], v[2], v[3]));
+        if (tid < 32) wt_store(mine + 1024 + tid, sb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have completed
+        __syncthreads();                                   // (also: every read of bsum above is done)
+        int *flag = reinterpret_cast<int *>(&bsum[0][0]);
+        if (tid == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(grp.ticket + p.part0 + t, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = ((old + 1ull) % (unsigned long long)p.ks == 0ull) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!*flag) return;   // somebody else finishes this tile
+        const float *q = grp.part + (size_t)(p.part0 + t) * p.ks * GL_PART;
+        for (int sl = 0; sl < p.ks; ++sl) {
+            const float *src = q + (size_t)sl * GL_PART;
+            if (tid < 256) {
+                const unsigned long long *s2 = reinterpret_cast<const unsigned long long *>(src + erow * 32 + ecol);
+                const unsigned long long lo = __hip_atomic_load(s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float w[4] = {__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                                    __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = sl ? v[j] + w[j] : w[j];
+            }
+            if (tid < 32) {
+                const float b = __hip_atomic_load(src + 1024 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sb = sl ? sb + b : b;
+            }
+        }
+    }
+    if (want_bias_grad && tid < vm) {
+        p.bias_grad[m0 + tid] = sb;
+        if (ADAM) adam_apply(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, sb);
     }
     if (!etile) return;
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int o = erow * 33 + ecol + j;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < GL_WAVES; ++w) s += lds[w * (32 * 33) + o];
-        v[j] = s;
-    }
     switch (p.epi) {
         case EPI_BIAS_RELU:
 #pragma unroll

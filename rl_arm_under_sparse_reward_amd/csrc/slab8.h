@@ -65,17 +65,10 @@ __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int i
     if (layer >= 2) off_d = base + w0 + frag8_dx_index(n, k, N);
 }
 
-// Chain outputs are stored WRITE-THROUGH (sc1): neutral on its own (40.8 vs 41.1 us/update), and what the split
-// weight-gradient kernel's partial-tile exchange (dw64.h) needs.  (Round 2 also ran the weight-gradient tiles as a second
-// phase of this kernel -- one launch per update: 48.2 vs 40.8 us, removed in round 3; DESIGN.md 3.2,
+// Chain outputs are stored WRITE-THROUGH (wt_store, agent_device.h): neutral on its own (40.8 vs 41.1 us/update), and what the
+// split weight-gradient kernels' partial-tile exchange (dw64.h, gemm_lds.h) needs.  (Round 2 also ran the weight-gradient tiles
+// as a second phase of this kernel -- one launch per update: 48.2 vs 40.8 us, removed in round 3; DESIGN.md 3.2,
 // profiles/r02_fused_single_launch.txt.)
-__device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wt_store4(float *p, const float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-}
 
 // arguments of k_fb_slab8 (both row counts)
 struct FbSlabArgs {
