@@ -941,4 +941,18 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
     return HP_OK;
 }
 
+#ifdef SLAB_TIMELINE
+// time-line builds only (not part of the ABI): stage stamps of every workgroup of the last 32 x 32-tile launch
+int hp_debug_gemm_wg_timeline(uint64_t *out4096) {
+    HP_CHECK_HIP(hipDeviceSynchronize());
+    HP_CHECK_HIP(hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_gemm_tl_wg), 512 * 8 * 8));
+    return HP_OK;
+}
+int hp_debug_gemm_blk_timeline(uint64_t *out512) {   // [wave][block]{landed, issued} of one workgroup's product loop
+    HP_CHECK_HIP(hipDeviceSynchronize());
+    HP_CHECK_HIP(hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_gemm_tl_blk), 8 * 32 * 2 * 8));
+    return HP_OK;
+}
+#endif
+
 }  // extern "C"

@@ -35,8 +35,17 @@
 
 #ifdef SLAB_TIMELINE   // debug build: first and last workgroup stamp the 100 MHz wall clock at stage boundaries
 __device__ unsigned long long g_gemm_tl[32];
-#define GL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_gemm_tl[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_gemm_tl_blk[8][32][2];   // workgroup GL_BLK_WG's product loop: [wave][block]{operands landed, MFMAs issued}
+#ifndef GL_BLK_WG
+#define GL_BLK_WG 100
+#endif
+#define GL_BLK_STAMP(i, j) do { if (blockIdx.x == GL_BLK_WG && (threadIdx.x & 63) == 0 && (i) < 32) g_gemm_tl_blk[wave][(i)][(j)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_gemm_tl_wg[512][8];   // every tile workgroup's stamps (hp_debug_gemm_wg_timeline, time-line builds only)
+#define GL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_gemm_tl[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); \
+                          if (threadIdx.x == 0 && blockIdx.x < 512) g_gemm_tl_wg[blockIdx.x][(k)] = wall_clock64(); \
+                          if (threadIdx.x == 0 && blockIdx.x == 0 && (k) < 2) g_gemm_tl[24 + (k)] = __builtin_readcyclecounter(); } while (0)   /* shader cycles over the product loop */
 #else
+#define GL_BLK_STAMP(i, j) do { } while (0)
 #define GL_STAMP(k) do { } while (0)
 #endif
 
@@ -146,6 +155,8 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         tn = slot & 7;
     }
     const int m0 = tm * 32, n0 = tn * 32;
+    // (`wave` stays a vector value on purpose: with readfirstlane the ring loop below gets scalar branches and measured -0.9 us/update at
+    // batch 512 k8 / -0.3 at 384 but +0.5 at 768, +0.7 at 1024 and +2 at 1024 without the split tiles; profiles/r03_dw_tile_timeline.txt)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
     if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
@@ -218,6 +229,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
                 else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            GL_BLK_STAMP(i2, 0);
             const float *blk = ring + (i2 & 3) * 512 + h * 32 + l;
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
@@ -225,6 +237,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
                 cr = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, cr, 0, 0, 0);
                 asr += av;
             }
+            GL_BLK_STAMP(i2, 1);
         }
         GL_STAMP(1);
     } else

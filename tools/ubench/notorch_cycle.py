@@ -69,8 +69,36 @@ if os.environ.get("RLARM_ENGINE") == "slab32" or int(os.environ.get("BATCH", "25
     base = tl[96]
     for w in range(8):
         print(f"[timeline slab32 layer wave {w}] " + " ".join(f"{k}:{(tl[96 + 4 * w + k] - base) / 100:.2f}" for k in range(4)) + f" after-sync:{(tl[128 + 4 * w] - base) / 100:.2f}")
+if tl[160 + 24] and tl[160 + 25] and tl[161] > tl[160]:
+    print(f"[timeline dW] shader clock over workgroup 0's product loop: {100.0 * (tl[160 + 25] - tl[160 + 24]) / (tl[161] - tl[160]):.0f} MHz")
 for k, nm in ((9, "K loop"), (11, "ticket"), (13, "end")):
     if tl[160 + k]: print(f"[timeline dW latest {nm}] {((tl[160 + k] >> 12) - tl[160]) / 100:.1f} us by workgroup {tl[160 + k] & 4095}")
+if hasattr(lib, "hp_debug_gemm_wg_timeline") or True:
+    try:
+        fn = lib.hp_debug_gemm_wg_timeline        # time-line builds only
+        wg = (C.c_uint64 * 4096)(); fn.restype = C.c_int; fn(wg)
+        t0s = [wg[8 * b] for b in range(512) if wg[8 * b]]
+        if t0s:
+            base = min(t0s)
+            import statistics as st
+            def col(k, sel): return [(wg[8 * b + k] - base) / 100 for b in sel if wg[8 * b + k] and wg[8 * b]]
+            groups = (("256 x 256 tiles (wg 0-255)", range(0, 256)), ("narrow tiles (wg 256+)", range(256, 512)))
+            for nm, sel in groups:
+                for k, kn in ((0, "start"), (1, "products done"), (3, "LDS sums ready"), (4, "exchange / sums done"), (5, "end")):
+                    c = col(k, sel)
+                    if c: print(f"[dW per-workgroup] {nm:28s} {kn:20s} n={len(c):3d} min {min(c):6.2f} median {st.median(c):6.2f} max {max(c):6.2f}")
+    except AttributeError:
+        pass
+try:
+    fn = lib.hp_debug_gemm_blk_timeline
+    bk = (C.c_uint64 * 512)(); fn.restype = C.c_int; fn(bk)
+    base = min(v for v in bk if v) if any(bk) else 0
+    for w in range(8):
+        row = [(bk[(w * 32 + i) * 2] , bk[(w * 32 + i) * 2 + 1]) for i in range(32)]
+        if row[0][0]:
+            print(f"[dW block loop wave {w}] " + " ".join(f"{(a - base) / 100:.2f}/{(b - base) / 100:.2f}" for a, b in row if a))
+except AttributeError:
+    pass
 floor("after cycles")
 # eager path
 _lib.check(lib.hp_agent_sample_and_update(h, buf.h, on.h, gn.h, rng.h, 0.8, squared_threshold(0.05), 40)); ctx.synchronize()
