@@ -197,18 +197,22 @@ def test_split_weight_gradient_kernel_tracks_oracle(batch, split, monkeypatch):
     test_updates_track_oracle_over_a_cycle(batch, 4)
 
 
-@pytest.mark.parametrize("n_batches", [5, 1, 2])     # 1 and 2: shorter than the two-update lead of the index plans
-def test_train_cycle_graph_equals_eager_bitwise(n_batches, monkeypatch):
-    """The cached hipGraph cycle, the call-by-call path with its cached per-call graphs and the same path on plain
-    eager launches must produce identical bits."""
+@pytest.mark.parametrize("n_batches,n_eps,n_new", [(5, 16, 2), (1, 16, 2), (2, 16, 2),   # 1 and 2: shorter than the two-update lead of the index plans
+                                                   (3, 64, 2),      # room in the buffer: replay_buffer.py:59-61, no slot draw
+                                                   (3, 200, 130)])  # more episodes per cycle than k_cycle_open has workgroups for
+def test_train_cycle_graph_equals_eager_bitwise(n_batches, n_eps, n_new, monkeypatch):
+    """The cached hipGraph cycle (its opening launch k_cycle_open included: slots, scatter, normalizer, first plans), the
+    call-by-call path with its cached per-call graphs and the same path on plain eager launches must produce identical bits
+    -- with a buffer that overflows in the first cycle (replay_buffer.py:62-67), one that has room, and a wave of episodes
+    too large for the opening launch (separate launches then)."""
     outs = []
     for mode in ("eager", "update_graph", "cycle_graph"):
         monkeypatch.setenv("RLARM_UPDATE_GRAPH", "0" if mode == "eager" else "1")   # read by hp_agent_create
         torch.manual_seed(0)                                        # same initial weights in every run
-        agent, rng = make_agent(batch=256, n_eps=16, seed=11)       # small buffer: cycles overflow it
+        agent, rng = make_agent(batch=256, n_eps=n_eps, seed=11)    # n_eps = 16: small buffer, cycles overflow it
         agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
-        for cycle in range(4):
-            eps = make_episodes(2, seed=100 + cycle, mode="walk")
+        for cycle in range(4 if n_new < 100 else 2):
+            eps = make_episodes(n_new, seed=100 + cycle, mode="walk")
             if mode == "cycle_graph":
                 agent.train_cycle(eps, n_batches=n_batches)
             else:
@@ -217,8 +221,8 @@ def test_train_cycle_graph_equals_eager_bitwise(n_batches, monkeypatch):
                 agent._update_network(n_batches)
                 agent._soft_update_target_network()
         outs.append((agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_ACTOR_TARGET),
-                     agent.last_losses(4 * n_batches), agent.o_norm.mean, agent.g_norm.std, rng.get_state()[1], rng.get_state()[2],
-                     agent.buffer.buffers["ag"], agent.buffer.current_size))
+                     agent.last_losses((4 if n_new < 100 else 2) * n_batches), agent.o_norm.mean, agent.g_norm.std, rng.get_state()[1],
+                     rng.get_state()[2], agent.buffer.buffers["ag"], agent.buffer.buffers["obs"], agent.buffer.current_size))
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
