@@ -583,7 +583,8 @@ def main():
             if name == "chain":
                 rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fb_slab32"))
             else:   # the ride-along variant runs on all but the last updates of a cycle
-                rp = prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam", 0.0)
+                rp = (prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam_ride_u")
+                      or prof_avg.get("k_gemm_lds_adam") or prof_avg.get("k_gemm_lds_adam_u", 0.0))   # _u: scalar wave index (batch 257..640)
             used = max(live, rp)
             tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
             per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "live_event_pair_minus_empty_us": round(live, 3),

@@ -60,7 +60,7 @@ struct GemmGroup {
     int n;
     int pipe;   // per-wave LDS-DMA rings for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: workgroup-staged chunks, for A/B)
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
-    int pad_;
+    int uni;    // ring loop with the wave index in a scalar register (gemm_lds.h)
     float *part;                  // split tiles: GL_PART floats per (tile, slice)
     unsigned long long *ticket;   // split tiles: arrival counter per tile, monotonic over the life of the agent
     GemmProb p[MAX_PROBS];
@@ -178,6 +178,7 @@ struct hp_agent {
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
     unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
+    int gl_uni = -1;                     // RLARM_GEMM_UNI=0|1 overrides the choice by reduction length (gemm_lds.h)
     int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
     float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)
     unsigned long long *gl_ticket = nullptr;
@@ -229,7 +230,7 @@ struct Launch {  // builds one grouped launch
     Launch() {
         g.n = 0;
         g.xcd = 0;
-        g.pad_ = 0;
+        g.uni = 0;
         g.part = nullptr;
         g.ticket = nullptr;
     }

@@ -109,12 +109,12 @@ struct RideArgs {
     float max_action;
 };
 
-template <bool ADAM>
+template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, int tiles) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
     __shared__ float bsum[GL_WAVES][32];
     if ((int)blockIdx.x < tiles) {
-        gemm_tile<ADAM>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
+        gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
         return;
     }
     const int extra = (int)blockIdx.x - tiles;
@@ -136,6 +136,14 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride(const GemmGroup gr
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(const GemmGroup grp, const AdamFuse F, const RideArgs R,
                                                                    int tiles) {
     gemm_ride_body<true>(grp, &F, R, tiles);
+}
+
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride_u(const GemmGroup grp, const RideArgs R, int tiles) {
+    gemm_ride_body<false, true>(grp, nullptr, R, tiles);
+}
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(const GemmGroup grp, const AdamFuse F, const RideArgs R,
+                                                                     int tiles) {
+    gemm_ride_body<true, true>(grp, &F, R, tiles);
 }
 
 // Large minibatches: 64 x 64 tiles with the batch rows split over workgroups (dw64.h), same riders behind the tiles
@@ -308,7 +316,7 @@ __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, 
 // ------------------------------------------------------------------------------- host side
 int launch_group(hp_agent *a, const Launch &L, int which) {
     ProfScope ps(a, which);
-    hipLaunchKernelGGL(k_gemm_lds, dim3(L.tiles), dim3(GL_THREADS), 0, a->ctx->stream, L.g);
+    hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_u : k_gemm_lds, dim3(L.tiles), dim3(GL_THREADS), 0, a->ctx->stream, L.g);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -374,6 +382,7 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
     if (ks > 1) L.split_last(ks);
     L.g.part = a->gl_part;
     L.g.ticket = a->gl_ticket;
+    L.g.uni = a->gl_uni >= 0 ? a->gl_uni : (Mp > 256 && Mp <= 640 ? 1 : 0);   // gemm_lds.h, note at `wave`
     if (a->gemm_xcd) L.place_on_xcds();
     return L;
 }
@@ -547,9 +556,9 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 if (gc->polyak_after) fold_polyak(a, F);
-                hipLaunchKernelGGL(k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
             } else {
-                hipLaunchKernelGGL(k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
             }
             HP_CHECK_HIP(hipGetLastError());
         } else if (fuse_adam) {
@@ -559,7 +568,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             AdamFuse F = adam_fuse(a);
             F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
             if (gc && gc->polyak_after) fold_polyak(a, F);
-            hipLaunchKernelGGL(k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
             HP_TRY(launch_group(a, L, PROF_DW));

@@ -132,7 +132,9 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 // One 32 x 32 output tile.  bx = the tile's index in the group's launch order (blockIdx.x of the stand-alone kernels);
 // lds / bsum = GL_LDS_FLOATS / GL_WAVES * 32 floats of workgroup LDS.
 #define GL_LDS_FLOATS (2 * GL_OPERAND_FLOATS)
-template <bool ADAM>
+// UNI: the wave index lives in a scalar register, so the ring loop below gets scalar branches instead of exec-mask ones
+// (GemmGroup::uni, set for reductions of at most 640 rows: see the note at `wave` below).
+template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F, int bx, float *lds, float (*bsum)[32],
                                           bool finalize_loss) {
     int pi = 0;
@@ -155,9 +157,11 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         tn = slot & 7;
     }
     const int m0 = tm * 32, n0 = tn * 32;
-    // (`wave` stays a vector value on purpose: with readfirstlane the ring loop below gets scalar branches and measured -0.9 us/update at
-    // batch 512 k8 / -0.3 at 384 but +0.5 at 768, +0.7 at 1024 and +2 at 1024 without the split tiles; profiles/r03_dw_tile_timeline.txt)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    // How the wave index is held decides how the two waves of a SIMD fall into step in the ring loop below, and the better form
+    // depends on the length of the reduction (us/update, same box, three alternating runs each; bit-identical results):
+    // scalar (readfirstlane) vs vector: 44.4 / 44.8 at batch 384, 46.8 / 47.7 at 512 k8, 53.5 / 53.0 at 768, 56.3 / 55.6 at 1024
+    // (61.8 / 58.5 there without the split narrow tiles), 40.7 / 40.7 at 256.  Both are compiled as kernels of their own (k_gemm_lds*_u); the launch picks (GemmGroup::uni).
+    const int tid = threadIdx.x, wave = UNI ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
     if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
@@ -389,15 +393,21 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     GL_STAMP(5);
 }
 
-template <bool ADAM>
+template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
-    gemm_tile<ADAM>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
+    gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam(const GemmGroup grp, const AdamFuse F) {
     gemm_lds_body<true>(grp, &F);
+}
+// the same kernels with the wave index in a scalar register (gemm_tile's UNI; kernels of their own so that each form keeps
+// its own register allocation: both forms inside one kernel cost either of them 0.3-0.6 us/update)
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_u(const GemmGroup grp) { gemm_lds_body<false, true>(grp, nullptr); }
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_u(const GemmGroup grp, const AdamFuse F) {
+    gemm_lds_body<true, true>(grp, &F);
 }
