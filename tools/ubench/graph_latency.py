@@ -10,6 +10,9 @@ a = argparse.Namespace(gpus=1, steps=20, warmup=5, batch=256, episodes=5000, rep
                        feeder_workers=8, no_cpu_baseline=True, no_profile=True, cpu_seconds=1.0)
 r = bench.Runner(a, 0, 1)
 ag = r.agent
+import torch
+ts_stream = torch.cuda.Stream()
+r.ctx.set_stream(ts_stream.cuda_stream)         # the library's launches and torch's events on one stream
 r.run_steps(40); r.sync()
 # steady state: 400 updates back to back
 ag._update_network(40); r.sync()
@@ -21,13 +24,20 @@ print(f"steady state {steady:.2f} us/update")
 for n in (1, 2, 3, 5, 10, 20, 40):
     ag._update_network(n); r.sync()          # graph for this n is cached now
     ts = []
+    evs = []
     for rep in range(9):
         time.sleep(0.002)                    # idle GPU, like a caller that waited for the previous result
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record(ts_stream)
         ag._update_network(n)
+        e1.record(ts_stream)
         t1 = time.perf_counter()
         r.ctx.synchronize()
         t2 = time.perf_counter()
         ts.append((1e6 * (t1 - t0), 1e6 * (t2 - t0)))
+        evs.append(1e3 * e0.elapsed_time(e1))
     enq = float(np.median([x[0] for x in ts])); tot = float(np.median([x[1] for x in ts]))
-    print(f"n={n:3d}: call returns after {enq:6.1f} us, done after {tot:7.1f} us -> fixed cost {tot - n * steady:6.1f} us ({(tot - n * steady) / n:5.2f} us/update)")
+    ev = float(np.median(evs))
+    print(f"n={n:3d}: call returns after {enq:6.1f} us, done after {tot:7.1f} us -> fixed cost {tot - n * steady:6.1f} us ({(tot - n * steady) / n:5.2f} us/update); "
+          f"event pair around the call on the stream: {ev:7.1f} us = {ev / n:5.2f} us/update on the GPU; host-only part {tot - ev:5.1f} us")
