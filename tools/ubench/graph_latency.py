@@ -41,3 +41,13 @@ for n in (1, 2, 3, 5, 10, 20, 40):
     ev = float(np.median(evs))
     print(f"n={n:3d}: call returns after {enq:6.1f} us, done after {tot:7.1f} us -> fixed cost {tot - n * steady:6.1f} us ({(tot - n * steady) / n:5.2f} us/update); "
           f"event pair around the call on the stream: {ev:7.1f} us = {ev / n:5.2f} us/update on the GPU; host-only part {tot - ev:5.1f} us")
+
+# a reference-style inner loop: one _update_network() call per minibatch (ddpg_agent.py:145-147), calls issued back to back
+for n in (1, 2, 4):
+    ag._update_network(n); r.sync()
+    t0 = time.perf_counter()
+    for _ in range(400 // n): ag._update_network(n)
+    t1 = time.perf_counter()
+    r.sync()
+    t2 = time.perf_counter()
+    print(f"loop of _update_network({n}) calls: {1e6 * (t2 - t0) / 400:.2f} us/update (host issues a call every {1e6 * (t1 - t0) / (400 // n):.1f} us)")
