@@ -178,6 +178,7 @@ struct hp_agent {
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
     unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
+    int adam_wt = -1;                    // RLARM_ADAM_WT=0|1 overrides write-through optimizer stores (default: up to 768 batch rows)
     int gl_uni = -1;                     // RLARM_GEMM_UNI=0|1 overrides the choice by reduction length (gemm_lds.h)
     int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
     float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)

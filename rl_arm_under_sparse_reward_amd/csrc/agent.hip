@@ -307,6 +307,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
         a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
         a->gl_uni = tri("RLARM_GEMM_UNI");
+        a->adam_wt = tri("RLARM_ADAM_WT");
         if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
         // weight gradients: 64 x 64 tiles with split batch rows (dw64.h) where the 32 x 32 tiles are L2-bound
         // (us/update, 32 x 32 tiles vs dw64: 56.6 / 58.9 at batch 1024, 85.8 / 85.1 at 1536, 93.9 / 92.2 at 2048, 146 / 128 at 4096)

@@ -35,6 +35,7 @@ struct AdamFuse {
     // tgt = (1 - polyak) * p_new + polyak * tgt (ddpg_agent.py:220-222), fragFT = forward-fragment copy of the targets
     float *tgt, *fragFT;
     float polyak, one_minus;
+    int wt;                           // write-through stores for the stepped state (adam_apply4)
 };
 
 __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
@@ -58,6 +59,18 @@ __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi)
         F.tgt[idx] = t;
         if (of >= 0) F.fragFT[of] = t;
     }
+}
+
+// write-through (sc1) stores: visible to other XCDs once drained (s_waitcnt vmcnt(0)); readers use agent-scope loads
+__device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store4(float *p, const float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    // s_nop 1 INSIDE the string: the store reads its data registers a few cycles after issue and hipcc pads nothing behind an
+    // asm statement -- without it the next instruction may overwrite x before the store has read it (cdna_hip_programming.md
+    // 5.7 item 1; found when an experiment put this store in front of arithmetic that reused the registers: NaNs)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 
 // four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
@@ -93,9 +106,20 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
         pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(neg_step_size, mm[j]), denom));
     }
-    *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    // F.wt (small minibatches): write-through stores.  The optimizer leaves 5.6 MB dirty in the L2s, which the end of the kernel
+    // has to write back before the next launch may start; written through while other workgroups still multiply, that tail is
+    // gone: 40.7 -> 40.1 us/update at batch 256.  At batch 1024 / 4096 the launch is long enough to hide the write-back itself
+    // and the stores only add traffic under load (55.6 -> 55.8, 127.5 -> 129.0): plain stores there.  (System scope, sc0 sc1,
+    // measured 44.5 vs 41.8 in round 2: agent scope is what the other XCDs need.)
+    if (F.wt) {
+        wt_store4(F.p_out + idx0, make_float4(pp[0], pp[1], pp[2], pp[3]));
+        wt_store4(F.m + idx0, make_float4(mm[0], mm[1], mm[2], mm[3]));
+        wt_store4(F.v + idx0, make_float4(vv[0], vv[1], vv[2], vv[3]));
+    } else {
+        *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
     float tt[4] = {0.f, 0.f, 0.f, 0.f};
     if (F.tgt) {   // same expression as k_polyak_frag, on the parameters just stepped
         const float4 t4 = *reinterpret_cast<const float4 *>(F.tgt + idx0);
@@ -110,11 +134,17 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         int of, od;
         if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
         else frag32_offsets(F.am, idx0, of, od);
-        if (of >= 0) *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (of >= 0) {
+            if (F.wt) wt_store4(F.fragF + of, make_float4(pp[0], pp[1], pp[2], pp[3]));
+            else *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        }
         if (of >= 0 && F.tgt) *reinterpret_cast<float4 *>(F.fragFT + of) = make_float4(tt[0], tt[1], tt[2], tt[3]);
         if (od >= 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) F.fragD[od + 4 * j] = pp[j];
+            for (int j = 0; j < 4; ++j) {
+                if (F.wt) wt_store(F.fragD + od + 4 * j, pp[j]);
+                else F.fragD[od + 4 * j] = pp[j];
+            }
         }
     } else {
 #pragma unroll
@@ -149,13 +179,4 @@ __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
         F.loss_log[(k % LOSS_LOG) * 2 + 1] = tc * invB;
         F.st->n_logged = k + 1;
     }
-}
-
-// write-through (sc1) stores: visible to other XCDs once drained (s_waitcnt vmcnt(0)); readers use agent-scope loads
-__device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wt_store4(float *p, const float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
 }
