@@ -473,7 +473,12 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256),
                                           # 32-row engine + split weight-gradient tiles: look-ahead on a second stream / in front of
                                           # every launch
-                                          ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560)])
+                                          ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560),
+                                          # round 3: the cycle's opening work as four launches instead of k_cycle_open; the other
+                                          # loop-control form of the weight-gradient tiles; optimizer stores plain / write-through
+                                          ("RLARM_CYCLE_OPEN=0", 256), ("RLARM_CYCLE_OPEN=0", 1024), ("RLARM_GEMM_UNI=1", 256),
+                                          ("RLARM_GEMM_UNI=0", 512), ("RLARM_GEMM_UNI=1", 1024), ("RLARM_ADAM_WT=0", 256),
+                                          ("RLARM_ADAM_WT=1", 1024), ("RLARM_ADAM_WT=1", 3072)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
