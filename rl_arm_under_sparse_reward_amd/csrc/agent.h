@@ -58,7 +58,6 @@ struct GemmProb {
 #define GL_MAX_SPLIT_TILES 64
 struct GemmGroup {
     int n;
-    int pipe;   // per-wave LDS-DMA rings for k-major operands with K > 256 (RLARM_GEMM_PIPE=0: workgroup-staged chunks, for A/B)
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
     int uni;    // ring loop with the wave index in a scalar register (gemm_lds.h)
     float *part;                  // split tiles: GL_PART floats per (tile, slice)

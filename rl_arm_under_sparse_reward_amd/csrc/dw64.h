@@ -1,4 +1,4 @@
-// dw64.h -- weight gradients of a LARGE minibatch (+ the optimizer epilogue), included by agent.hip.
+// dw64.h -- weight gradients of a LARGE minibatch (+ the optimizer epilogue), included by agent_engines.hip.
 //
 // dW = dY^T X over B batch rows (ddpg_agent.py:262-271 through autograd: fc*.weight.grad, fc*.bias.grad).  gemm_lds.h
 // gives every 32 x 32 output tile to one workgroup that walks ALL the batch rows: 8 flop per operand byte, and beyond

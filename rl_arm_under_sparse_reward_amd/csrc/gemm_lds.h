@@ -1,4 +1,4 @@
-// gemm_lds.h -- grouped FP32-MFMA GEMM, LDS-staged operands (included by agent.hip).
+// gemm_lds.h -- grouped FP32-MFMA GEMM, LDS-staged operands (included by agent_engines.hip; the layer-per-launch engine of agent_layers.hip launches it through launch_group).
 //
 // Why a second kernel: the first version fed v_mfma_f32_16x16x4_f32 straight from global memory
 // with one dword per lane, i.e. 16 rows x 16 B per wave-instruction for K-contiguous operands.
@@ -200,7 +200,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         // i of wave w: rows 64 i + 8 w .. + 7), brings them in through its OWN ring of 4 blocks (A rows | B rows, 2 KB, one
         // LDS-DMA instruction per operand) and accumulates the whole 32 x 32 tile on v_mfma_f32_32x32x2: no barrier in the
         // loop, 3 blocks in flight per wave.  The version before (128-row chunks staged by the workgroup, double buffered, one
-        // barrier per chunk; RLARM_GEMM_PIPE=0 until round 3) waited 1.4-1.75 us per chunk for its transfer: 11-14 us for the
+        // barrier per chunk; removed in round 3) waited 1.4-1.75 us per chunk for its transfer: 11-14 us for the
         // 1024 rows of batch 1024.
         ring_path = true;
 #pragma unroll

@@ -2,7 +2,7 @@
 // backward (dX) of a chain in one kernel (the structure of slab8.h's k_fb_slab8).  Included by agent.hip.
 //
 // Why a third slab shape.  From 2048 rows per GPU on, the update stops being a latency chain and becomes matrix work:
-// 11.3 GFLOP at batch 4096 = 72 us of FP32 MFMA.  The 16-row engine on the 16x16x4 MFMA (slab.h) reads three LDS operands
+// 11.3 GFLOP at batch 4096 = 72 us of FP32 MFMA.  The 16-row engine on the 16x16x4 MFMA (slab.h, removed in round 3) reads three LDS operands
 // of 1 KiB for every 64 matrix-pipe cycles per wave, which with 8 waves is more than the LDS delivers, and runs 768 + 512
 // workgroups of one per CU whose epilogues idle the pipes (44 % / 40 %, profiles/r02_kernel_trace_b4096_k4.txt).  On the
 // 32x32x2 instruction a wavefront owns a 32 x 32 output tile: each of the 8 waves of a workgroup computes 32 columns of a
@@ -73,7 +73,7 @@ __host__ __device__ __forceinline__ void frag32_offsets(const ArenaMap &am, int 
 
 namespace s32 {
 
-__device__ __forceinline__ void sync() {   // barrier that leaves global loads / DMA in flight (see slab.h)
+__device__ __forceinline__ void sync() {   // barrier that leaves global loads / DMA in flight (__syncthreads() would also drain them: s_waitcnt vmcnt(0))
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

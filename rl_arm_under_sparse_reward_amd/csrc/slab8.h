@@ -1,5 +1,5 @@
 // slab8.h -- row-slab engine on v_mfma_f32_4x4x1_16b_f32, S8_ROWS = 4 * S8_NRG (4, 8 or 16) batch rows per workgroup;
-// included by agent.hip once per slab height (the name dates from its 8-row first version).
+// included by agent_engines.hip once per slab height (the name dates from its 8-row first version).
 //
 // Why thin slabs: with 16-row slabs on the 16x16x4 MFMA (the first slab engine, removed in round 3) a 256x256 layer costs a workgroup 1024
 // MFMAs = 3.4 us of its CU's matrix pipes, and at batch 256 only 48 workgroups exist.  The 4x4x1 instruction (16
@@ -117,7 +117,7 @@ namespace S8_NS {
 
 typedef unsigned short s8_mask_t;   // ReLU mask of one column: bit r = row r of the slab
 
-__device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (see slab.h)
+__device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (__syncthreads() would also drain them: s_waitcnt vmcnt(0))
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
