@@ -14,15 +14,29 @@ import sqlite3
 import sys
 
 
+_COMMENT_OR_STRING = None
+
+
+def _code_only(text):
+    """The source without comments and with runs of white space collapsed: editing a comment must not make committed counter
+    files read as stale."""
+    global _COMMENT_OR_STRING
+    import re
+    if _COMMENT_OR_STRING is None:
+        _COMMENT_OR_STRING = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"', re.S)
+    text = _COMMENT_OR_STRING.sub(lambda m: m.group(0) if m.group(0).startswith('"') else " ", text)
+    return " ".join(text.split())
+
+
 def csrc_sha16():
-    """Fingerprint of the kernel sources the counters were taken on (bench.py recomputes it and marks the traffic figure
-    stale when the sources have changed since)."""
+    """Fingerprint of the kernel sources the counters were taken on, comments and white space aside (bench.py recomputes it and
+    marks the traffic figure stale when the code has changed since)."""
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rl_arm_under_sparse_reward_amd", "csrc")
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
         h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
+        with open(path, "r", encoding="utf-8", errors="replace") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 
