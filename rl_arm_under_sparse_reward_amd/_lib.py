@@ -144,6 +144,60 @@ PROTOTYPES = {
 _lib = None
 _lock = threading.Lock()
 
+# ---- deferred updates --------------------------------------------------------------------------------------------------
+# The reference's inner loop calls `_update_network()` once per minibatch (ddpg_agent.py:145-147).  Issued one by one, every call
+# is a graph of its own that draws its index plan in a launch in front and gathers its minibatch inside the chain kernel: 51 us
+# per update at batch 256.  The mirror therefore only COUNTS argument-less `_update_network()` calls and issues them together --
+# one hp_agent_sample_and_update(n): 40.5 us per update -- as soon as anything else touches the library: every entry point goes
+# through the proxy below, which first issues what is pending.  Nothing can observe the difference except a clock: parameters,
+# losses, the random stream and the buffer are only reachable through library calls, and n updates in one call are bit for bit
+# n calls of one update (tests/test_gpu_update.py).  RLARM_DEFER_UPDATES=0 switches it off.
+pending_lock = threading.RLock()
+_pending = []            # objects with a `_flush_updates()` method and work outstanding
+_NO_FLUSH = {"hp_last_error", "hp_abi_version"}
+
+
+def register_pending(obj):
+    with pending_lock:
+        if not any(o is obj for o in _pending):
+            _pending.append(obj)
+
+
+def unregister_pending(obj):
+    with pending_lock:
+        _pending[:] = [o for o in _pending if o is not obj]
+
+
+def flush_pending():
+    """Issue every deferred update now (called by the library proxy in front of any other entry point)."""
+    if not _pending:
+        return
+    with pending_lock:
+        todo, _pending[:] = list(_pending), []
+        for o in todo:
+            o._flush_updates()
+
+
+class _Library:
+    """The ctypes library with one addition: pending deferred updates are issued in front of any other call."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        fn = getattr(object.__getattribute__(self, "_cdll"), name)     # AttributeError for unknown symbols, like ctypes
+        if name in _NO_FLUSH or not name.startswith("hp_"):
+            return fn
+
+        def call(*args):
+            if _pending:
+                flush_pending()
+            return fn(*args)
+
+        call.__name__ = name
+        object.__setattr__(self, name, call)       # next access is a plain attribute hit
+        return call
+
 
 def load(path: str | None = None):
     """dlopen the in-tree HIP library and attach prototypes.  Raises if it is not built."""
@@ -170,8 +224,8 @@ def load(path: str | None = None):
             raise HpError("librlarm_hip.so does not export: " + ", ".join(missing) + " -- rebuild it")
         if lib.hp_abi_version() != 1:
             raise HpError("librlarm_hip.so ABI version mismatch")
-        _lib = lib
-        return lib
+        _lib = _Library(lib)
+        return _lib
 
 
 def check(status: int):

@@ -129,6 +129,8 @@ class ddpg_agent:
                                  comm=self.comm)
         self._norm_stage = None          # staging buffer of _update_normalizer(episode_batch)
         import threading
+        self._pending_updates = 0              # argument-less _update_network() calls not issued yet (_lib.py: deferred updates)
+        self._defer_updates = os.environ.get("RLARM_DEFER_UPDATES", "1") != "0"
         self._stage_lock = threading.RLock()   # orders "store a wave, then sample ITS staged episodes" across feeder threads
         self.success_rates = []
         self.model_path = os.path.join(self.args.save_dir, self.args.env_name)
@@ -238,8 +240,32 @@ class ddpg_agent:
     def _handles(self):
         return (self.h, self.buffer._dev.h, self.o_norm.h, self.g_norm.h, self.rng.h)
 
-    def _update_network(self, n_updates=1):
-        """ddpg_agent.py:225-277, `n_updates` times back to back (the reference's inner loop :145-147)."""
+    def _update_network(self, n_updates=None):
+        """ddpg_agent.py:225-277.  `_update_network(n)`: n updates back to back, issued now.  `_update_network()` -- the
+        reference's call form, once per minibatch in its inner loop (:145-147) -- is only counted and issued together with the
+        calls that follow it, as soon as anything else touches the library or `n_batches` of them have come (_lib.py,
+        "deferred updates"): the same updates bit for bit, 40.5 instead of 51 us each at batch 256."""
+        if n_updates is None:
+            if self._defer_updates and (not self.comm.active or self._native_comm is not None or self._peer is not None):
+                with _lib.pending_lock:
+                    self._pending_updates += 1
+                    if self._pending_updates >= int(self.args.n_batches):
+                        self._flush_updates()
+                    else:
+                        _lib.register_pending(self)
+                return
+            n_updates = 1
+        self._flush_updates()
+        self._issue_updates(int(n_updates))
+
+    def _flush_updates(self):
+        with _lib.pending_lock:
+            n, self._pending_updates = self._pending_updates, 0
+            _lib.unregister_pending(self)
+            if n:
+                self._issue_updates(n)
+
+    def _issue_updates(self, n_updates):
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
         if not self.comm.active or self._native_comm is not None or self._peer is not None:
             # single rank, or the library exchanges the gradients itself between backward and Adam

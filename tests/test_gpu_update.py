@@ -641,3 +641,36 @@ def test_default_engine_table(batch, want):
     agent, _ = make_agent(batch=batch, n_eps=8, seed=1)
     e = agent.engine()
     assert (e["engine"], e["slab_rows"], e["weight_grad"]) == want
+
+
+def test_argumentless_update_calls_are_deferred_and_batched_with_the_same_bits(monkeypatch):
+    """The reference's inner loop calls `_update_network()` once per minibatch (ddpg_agent.py:145-147).  The mirror counts such
+    calls and issues them together when anything else touches the library (_lib.py, "deferred updates"): the interleaving below --
+    updates, a look at the random stream, more updates, a store, an update, the losses -- must leave exactly the bits of the same
+    sequence issued call by call (RLARM_DEFER_UPDATES=0), and nothing may stay pending behind an observation."""
+    outs = []
+    for defer in ("1", "0"):
+        monkeypatch.setenv("RLARM_DEFER_UPDATES", defer)
+        torch.manual_seed(0)
+        agent, rng = make_agent(batch=256, n_eps=32, seed=21, n_batches=8)
+        agent.buffer.store_episode(make_episodes(20, seed=9, mode="walk"))
+        for _ in range(3):
+            agent._update_network()
+        if defer == "1":
+            assert agent._pending_updates == 3            # counted, not issued
+        mid_state = rng.get_state()[1].copy()             # any library call issues them first
+        assert agent._pending_updates == 0
+        for _ in range(2):
+            agent._update_network()
+        agent.buffer.store_episode(make_episodes(2, seed=77, mode="walk"))   # the store must come AFTER those two updates
+        assert agent._pending_updates == 0
+        for _ in range(11):                               # n_batches = 8: the first 8 go out on their own, 3 stay pending
+            agent._update_network()
+        if defer == "1":
+            assert agent._pending_updates == 3
+        agent._soft_update_target_network()
+        losses = agent.last_losses(16)
+        outs.append((mid_state, agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_CRITIC_TARGET), losses,
+                     rng.get_state()[1], rng.get_state()[2]))
+    for a, b in zip(*outs):
+        assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))

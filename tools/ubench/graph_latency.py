@@ -51,3 +51,10 @@ for n in (1, 2, 4):
     r.sync()
     t2 = time.perf_counter()
     print(f"loop of _update_network({n}) calls: {1e6 * (t2 - t0) / 400:.2f} us/update (host issues a call every {1e6 * (t1 - t0) / (400 // n):.1f} us)")
+
+# the reference's own call form: argument-less calls are counted by the mirror and issued together (_lib.py, deferred updates)
+ag._update_network(40); r.sync()
+t0 = time.perf_counter()
+for _ in range(400): ag._update_network()
+r.sync()
+print(f"loop of argument-less _update_network() calls (deferred, issued 40 at a time): {1e6 * (time.perf_counter() - t0) / 400:.2f} us/update")
