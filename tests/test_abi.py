@@ -62,3 +62,32 @@ def test_squared_threshold_matches_oracle():
     from rl_arm_under_sparse_reward_amd.her import squared_threshold
     for thr in (0.05, 0.01, 0.1, 1.0, 0.049999999, 3.3e-3):
         assert squared_threshold(thr) == squared_distance_threshold(thr)
+
+
+def test_pending_updates_are_issued_in_front_of_any_other_library_call():
+    """_lib.py "deferred updates": the library proxy issues whatever is pending before it forwards a call -- except the two
+    entry points error handling itself needs.  No device involved: the forwarded call may fail, the order is what counts."""
+    import ctypes as C
+    from rl_arm_under_sparse_reward_amd import _lib
+    lib = _lib.load()
+    calls = []
+
+    class Pending:
+        def _flush_updates(self):
+            calls.append("flush")
+
+    p = Pending()
+    _lib.register_pending(p)
+    _lib.register_pending(p)                   # registering twice is one entry
+    lib.hp_abi_version()                       # no flush in front of these two
+    lib.hp_last_error()
+    assert calls == []
+    h = C.c_void_p()
+    lib.hp_ctx_create(10 ** 6, C.byref(h))     # any other entry point (this one fails: no such device) flushes first
+    assert calls == ["flush"]
+    lib.hp_ctx_create(10 ** 6, C.byref(h))     # ... once: nothing is pending any more
+    assert calls == ["flush"]
+    _lib.register_pending(p)
+    _lib.unregister_pending(p)
+    lib.hp_ctx_create(10 ** 6, C.byref(h))
+    assert calls == ["flush"]
