@@ -58,3 +58,22 @@ t0 = time.perf_counter()
 for _ in range(400): ag._update_network()
 r.sync()
 print(f"loop of argument-less _update_network() calls (deferred, issued 40 at a time): {1e6 * (time.perf_counter() - t0) / 400:.2f} us/update")
+
+# the reference's six lines of learn() (ddpg_agent.py:143-150) exactly as they stand, against train_cycle on the same episodes
+from rl_arm_under_sparse_reward_amd.synthetic import make_episodes
+eps = make_episodes(2, seed=5)
+def six_lines():
+    ag.buffer.store_episode(eps)
+    ag._update_normalizer(eps)
+    for _ in range(ag.args.n_batches):
+        ag._update_network()
+    ag._soft_update_target_network(ag.actor_target_network, ag.actor_network)
+    ag._soft_update_target_network(ag.critic_target_network, ag.critic_network)
+for name, fn in (("the reference's six lines, unchanged", six_lines), ("train_cycle", lambda: ag.train_cycle(eps))):
+    for _ in range(3): fn()
+    r.sync()
+    t0 = time.perf_counter()
+    for _ in range(50): fn()
+    r.sync()
+    dt = time.perf_counter() - t0
+    print(f"{name}: {1e6 * dt / 50:.0f} us per cycle = {1e6 * dt / (50 * ag.args.n_batches):.2f} us per update")
