@@ -341,6 +341,12 @@ int hp_agent_set_peer(hp_agent *ag, hp_peer *peer);
 int hp_agent_train_cycle(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng,
                          const double *obs, const double *ag_host, const double *g, const double *actions,
                          int64_t n_new, double future_p, double sq_threshold, int32_t n_batches);
+/* The same cycle (ddpg_agent.py:143-150) on episodes that lie in a host block registered with the device (hp_host_register;
+ * layout and ticket as hp_buffer_store_pinned): what a multi-process rollout feeder (ddpg_agent.py:101-144 spread over worker
+ * processes) calls per wave -- the store is an asynchronous DMA out of the shared ring, no CPU copy. */
+int hp_agent_train_cycle_pinned(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng,
+                                const double *block, int64_t n_new, double future_p, double sq_threshold,
+                                int32_t n_batches, uint64_t *ticket);
 
 /* timing hook for bench.py: average device time (ms) of the kernels tagged `which` over the
  * last recorded region; see DESIGN.md "Measurement". */

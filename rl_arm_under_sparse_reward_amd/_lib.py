@@ -133,6 +133,8 @@ PROTOTYPES = {
     "hp_agent_set_grad_reduce": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_train_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f64p, f64p, f64p,
                                        f64p, C.c_int64, C.c_double, C.c_double, C.c_int32]),
+    "hp_agent_train_cycle_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_uint64)]),
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
     "hp_agent_debug_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "hp_agent_engine": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

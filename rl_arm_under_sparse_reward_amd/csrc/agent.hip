@@ -674,22 +674,48 @@ int hp_agent_set_comm(hp_agent *a, hp_comm *comm) {
     return HP_OK;
 }
 
+// everything of a cycle behind the staging of its episodes: one cached graph
+static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, int64_t n_new, double future_p,
+                              double sq_threshold, int32_t n_batches, bool open);
+
+static int train_cycle_checks(hp_agent *a, hp_buffer *b, int64_t n_new, int32_t n_batches, const char *who) {
+    HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "%s: n_new and n_batches must be positive", who);
+    HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
+    HP_REQUIRE(!a->prof, HP_ERR_STATE, "%s: profiling mode uses the eager path (hp_agent_profile(0) first)", who);
+    return peer_check_alive(a->peer, who);
+}
+
 int hp_agent_train_cycle(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, const double *obs,
                          const double *ag_host, const double *g, const double *actions, int64_t n_new,
                          double future_p, double sq_threshold, int32_t n_batches) {
     HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_train_cycle"));
     HP_SERIALISE(a);
     HP_REQUIRE(obs && ag_host && g && actions, HP_ERR_INVALID, "hp_agent_train_cycle: null episode array");
-    HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "hp_agent_train_cycle: n_new and n_batches must be positive");
-    HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
-    HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_train_cycle: profiling mode uses the eager path (hp_agent_profile(0) first)");
-    HP_TRY(peer_check_alive(a->peer, "hp_agent_train_cycle"));
-    hipStream_t s = a->ctx->stream;
+    HP_TRY(train_cycle_checks(a, b, n_new, n_batches, "hp_agent_train_cycle"));
     // 1. episodes -> pinned -> device staging (eager: the source pointers change per call); slots and scatter: part of the
     // opening launch of the graph, or eager launches as well when that launch is switched off / would not fit the CUs
     const bool open = a->cycle_open && cycle_open_fits(a, n_new);
     if (open) HP_TRY(buffer_stage_for_cycle(b, obs, ag_host, g, actions, n_new));
     else HP_TRY(buffer_stage_and_store(b, rng, obs, ag_host, g, actions, n_new));
+    return train_cycle_staged(a, b, on, gn, rng, n_new, future_p, sq_threshold, n_batches, open);
+}
+
+// The same cycle on episodes that lie in a host block registered with the device (hp_host_register: the feeder's shared-memory
+// ring, layout of hp_buffer_store_pinned): the staging is an asynchronous DMA out of that block; `ticket` as there.
+int hp_agent_train_cycle_pinned(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, const double *block,
+                                int64_t n_new, double future_p, double sq_threshold, int32_t n_batches, uint64_t *ticket) {
+    HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_train_cycle_pinned"));
+    HP_SERIALISE(a);
+    HP_REQUIRE(block, HP_ERR_INVALID, "hp_agent_train_cycle_pinned: null block");
+    HP_TRY(train_cycle_checks(a, b, n_new, n_batches, "hp_agent_train_cycle_pinned"));
+    const bool open = a->cycle_open && cycle_open_fits(a, n_new);
+    HP_TRY(buffer_stage_pinned(b, rng, block, n_new, ticket, !open));
+    return train_cycle_staged(a, b, on, gn, rng, n_new, future_p, sq_threshold, n_batches, open);
+}
+
+static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, int64_t n_new, double future_p,
+                              double sq_threshold, int32_t n_batches, bool open) {
+    hipStream_t s = a->ctx->stream;
     // 2. everything else is one graph; rebuild when a baked-in argument changes
     const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
                       a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&

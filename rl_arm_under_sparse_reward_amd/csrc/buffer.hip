@@ -156,6 +156,41 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
     return HP_OK;
 }
 
+// Episodes in a host block registered with the device (hp_host_register: the feeder's shared-memory ring), laid out
+// obs | ag | g | actions back to back: asynchronous DMA into the staging, a ticket behind it, and -- store_now -- slots + scatter
+// (hp_buffer_store_pinned); without store_now those follow in the cycle's opening launch (hp_agent_train_cycle_pinned).
+int buffer_stage_pinned(hp_buffer *b, hp_rng *rng, const double *block, int64_t n_new, uint64_t *ticket, bool store_now) {
+    hipStream_t s = b->ctx->stream;
+    const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
+                 n3 = n_new * b->ep_act() * 8;
+    HP_TRY(b->st_slots.ensure(n_new * 8));
+    HP_TRY(b->st_obs.ensure(n0 + n1 + n2 + n3));
+    char *dst = b->st_obs.as<char>();
+    b->st_ag = reinterpret_cast<double *>(dst + n0);
+    b->st_g = reinterpret_cast<double *>(dst + n0 + n1);
+    b->st_act = reinterpret_cast<double *>(dst + n0 + n1 + n2);
+    HP_CHECK_HIP(hipMemcpyAsync(dst, block, n0 + n1 + n2 + n3, hipMemcpyHostToDevice, s));
+    // ticket: an event behind the copy, from a small ring (a ticket older than the ring is done by construction: its
+    // event is re-recorded only after this call synchronised on it)
+    const uint64_t t = ++b->pin_tickets;
+    hipEvent_t &ev = b->pin_events[t % hp_buffer::PIN_RING];
+    if (!ev) HP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else HP_CHECK_HIP(hipEventSynchronize(ev));
+    HP_CHECK_HIP(hipEventRecord(ev, s));
+    if (ticket) *ticket = t;
+    b->staged_n = n_new;
+    if (store_now) {
+        HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
+        hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)(n_new * STORE_PARTS)), dim3(256), 0, s, b->st_slots.as<long long>(),
+                           (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g, b->st_act, b->d_obs, b->d_ag, b->d_g,
+                           b->d_act, (long long)b->ep_obs(), (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
+    b->n_transitions_stored += (int64_t)b->T * n_new;
+    return HP_OK;
+}
+
 int buffer_stage_for_cycle(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
                            int64_t n_new) {
     HP_TRY(b->st_slots.ensure(n_new * 8));
@@ -230,33 +265,7 @@ int hp_buffer_store_pinned(hp_buffer *b, hp_rng *rng, const double *block, int64
     HP_SERIALISE(b);
     HP_REQUIRE(n_new > 0, HP_ERR_INVALID, "hp_buffer_store_pinned: n_new must be positive");
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
-    hipStream_t s = b->ctx->stream;
-    const size_t n0 = n_new * b->ep_obs() * 8, n1 = n_new * b->ep_ag() * 8, n2 = n_new * b->ep_g() * 8,
-                 n3 = n_new * b->ep_act() * 8;
-    HP_TRY(b->st_slots.ensure(n_new * 8));
-    HP_TRY(b->st_obs.ensure(n0 + n1 + n2 + n3));
-    char *dst = b->st_obs.as<char>();
-    b->st_ag = reinterpret_cast<double *>(dst + n0);
-    b->st_g = reinterpret_cast<double *>(dst + n0 + n1);
-    b->st_act = reinterpret_cast<double *>(dst + n0 + n1 + n2);
-    HP_CHECK_HIP(hipMemcpyAsync(dst, block, n0 + n1 + n2 + n3, hipMemcpyHostToDevice, s));
-    // ticket: an event behind the copy, from a small ring (a ticket older than the ring is done by construction: its
-    // event is re-recorded only after this call synchronised on it)
-    const uint64_t t = ++b->pin_tickets;
-    hipEvent_t &ev = b->pin_events[t % hp_buffer::PIN_RING];
-    if (!ev) HP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    else HP_CHECK_HIP(hipEventSynchronize(ev));
-    HP_CHECK_HIP(hipEventRecord(ev, s));
-    if (ticket) *ticket = t;
-    b->staged_n = n_new;
-    HP_TRY(rng_launch_slots(rng, b, n_new, b->st_slots.as<int64_t>()));
-    hipLaunchKernelGGL(k_store_scatter, dim3((unsigned)(n_new * STORE_PARTS)), dim3(256), 0, s, b->st_slots.as<long long>(),
-                       (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g, b->st_act, b->d_obs, b->d_ag, b->d_g,
-                       b->d_act, (long long)b->ep_obs(), (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
-    HP_CHECK_HIP(hipGetLastError());
-    b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
-    b->n_transitions_stored += (int64_t)b->T * n_new;
-    return HP_OK;
+    return buffer_stage_pinned(b, rng, block, n_new, ticket, true);
 }
 
 int hp_buffer_store_done(hp_buffer *b, uint64_t ticket, int32_t wait, int32_t *done) {

@@ -233,6 +233,8 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
 // the staging half alone (+ the host mirror of the counters): slots and scatter follow in k_cycle_open (cycle_open.hip)
 int buffer_stage_for_cycle(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
                            int64_t n_new);
+// the same out of a device-registered host block (feeder ring); store_now: slots + scatter follow at once
+int buffer_stage_pinned(hp_buffer *b, hp_rng *rng, const double *block, int64_t n_new, uint64_t *ticket, bool store_now);
 
 // norm.hip
 int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const PlanRec *d_plan, int64_t rows,

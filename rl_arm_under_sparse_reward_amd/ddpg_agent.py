@@ -354,6 +354,11 @@ class ddpg_agent:
         registered shared-memory slot (no CPU copy), the normalizer samples the staged episodes, the updates replay their
         cached graph.  Asynchronous; ranks of a data-parallel group call it in step like train_cycle."""
         n_batches = int(n_batches or self.args.n_batches)
+        if not self.comm.active or self._native_comm is not None or self._peer is not None:
+            # the whole cycle as one cached graph behind the DMA (hp_agent_train_cycle_pinned): same launches as train_cycle
+            with self._stage_lock:
+                feeder.train_cycle_wave(slot, n_batches)
+            return
         with self._stage_lock:       # store + normalizer update as one unit: another thread's store_wave (e.g. a rollout
             feeder.store_wave(slot)  # thread) must not replace the staged episodes in between
             self._update_normalizer()

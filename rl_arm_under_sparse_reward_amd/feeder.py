@@ -191,6 +191,17 @@ class EpisodeFeeder:
         self._tickets[slot] = ticket.value
         return ticket.value
 
+    def train_cycle_wave(self, slot, n_batches):
+        """ddpg_agent.py:143-150 on the slot's episodes as ONE cached graph behind the asynchronous DMA out of the shared ring
+        (hp_agent_train_cycle_pinned): store, normalizer update, n_batches updates, soft update."""
+        ag = self.agent
+        ticket = C.c_uint64()
+        self._lib.check(ag.lib.hp_agent_train_cycle_pinned(
+            *ag._handles(), C.c_void_p(self._ring_addr + slot * self.lay.slot_elems * 8), self.n_envs,
+            float(ag.her_module.future_p), float(ag.her_module.sq_threshold), int(n_batches), C.byref(ticket)))
+        self._tickets[slot] = ticket.value
+        return ticket.value
+
     def close(self):
         if not self._procs:
             return
