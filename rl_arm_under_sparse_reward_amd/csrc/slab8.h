@@ -110,7 +110,10 @@ struct PolicyArgs {
 #ifndef S8_RING1
 #define S8_RING1 12   // ring depth of the 4-row build (-DS8_RING1=14|16 for experiments)
 #endif
-#define S8_RING (S8_NRG >= 4 ? 10 : (S8_NRG == 1 ? S8_RING1 : 12))   // 16-row slabs need the LDS for their activation buffers
+#ifndef S8_RING2
+#define S8_RING2 12   // ring depth of the 8-row build
+#endif
+#define S8_RING (S8_NRG >= 4 ? 10 : (S8_NRG == 1 ? S8_RING1 : S8_RING2))   // 16-row slabs need the LDS for their activation buffers
 #undef S8_RPW
 #define S8_RPW ((S8_ROWS + S8_WAVES - 1) / S8_WAVES)   // rows per wavefront in the one-wavefront-per-row stages
 namespace S8_NS {
@@ -185,6 +188,9 @@ __device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, cons
 // Block T of the 32 this wave consumes.  The weight operand is software-pipelined through registers: the LDS read of
 // block T+1 is issued BEFORE the 8 MFMAs of block T, so its latency hides under this wave's own matrix work instead
 // of being exposed once per block (with two waves per SIMD the other wave covered only part of it).
+// (Store-aware waits -- allowing the write-through copies a wave issued at the end of the previous stage to stay outstanding
+// while the blocks that were in flight before them are consumed -- were built and measured SLOWER: 55.7 vs 54.1 us/update at batch
+// 1024, 46.2 vs 45.3 at 512 k8, 40.6 vs 40.3 at 256.  The stricter waits stay.)
 template <int T, bool HAS_NEXT>
 __device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring, int rbase, const float *wlayer,
                                              const float *nxt, int cg, int b0, const float (&a)[8][S8_NRG],
@@ -269,10 +275,11 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                              int ld_out, const s8_mask_t *mask_in = nullptr,
                                              s8_mask_t *mask_out = nullptr, unsigned long long *tl2 = nullptr,
-                                             int k2 = 0, float *gout = nullptr) {
+                                             int k2 = 0, float *gout = nullptr, const float *pre_e = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
-    if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
+    if (pre_e) e[0] = *pre_e;   // bias loaded at the trunk's start (s8_trunk)
+    else if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
     S8_TSTAMP(tl2, k2);
     f32x4 c[S8_NRG];
@@ -467,16 +474,25 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
                                          unsigned long long *tl, int tbase, s8_mask_t *m1 = nullptr,
                                          s8_mask_t *m2 = nullptr, s8_mask_t *m3 = nullptr) {
     S8_TSTAMP(tl, tbase);
+    // the biases of the two 256 x 256 layers come in now: a global load issued at a layer's start is younger than the ring's
+    // transfers in flight and, loads retiring in order, would make every counted wait of that layer one block stricter
+    // (-0.3 us/update at batch 256, -0.6 at 1024)
+    float eb2 = 0.f, eb3 = 0.f;
+    {
+        const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col_ = 64 * (w_ & 3) + (threadIdx.x & 63);
+        if ((w_ >> 2) == 0) { eb2 = canon[l.b2 + col_]; eb3 = canon[l.b3 + col_]; }
+    }
+    const float *pe2 = &eb2, *pe3 = &eb3;
     s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1,
                    g1 ? g1 + row0 * H : nullptr);
     s8_sync();
     S8_TSTAMP(tl, tbase + 1);
     s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2,
-                 tl, 24, g2 ? g2 + row0 * H : nullptr);
+                 tl, 24, g2 ? g2 + row0 * H : nullptr, pe2);
     s8_sync();
     S8_TSTAMP(tl, tbase + 2);
     s8_big_layer(bufB, S8_LD, ring, rbase, wf + l.w3, nxt, SE_BIAS_RELU, canon + l.b3, 0, pbuf, bufA, S8_LD, nullptr, m3, nullptr,
-                 0, g3 ? g3 + row0 * H : nullptr);
+                 0, g3 ? g3 + row0 * H : nullptr, pe3);
     s8_sync();
     S8_TSTAMP(tl, tbase + 3);
 }
@@ -676,7 +692,20 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const SlabNetPtrs &tn = A.target;
         const PlanRec rec = s8_plan_rec(A.gs, row0);
         float4 wbaT[6], wbcT[6], wbcA[6], whT[4], wqT[4], wqA[4];
+        s8_ring_prologue(ring, rbase, tn.wf + la.w2);   // first: the transfers fly while the inputs and first-layer weights come in
         s8_small_prefetch(tn.wf + la.w1, la.K1, wbaT);
+        __builtin_amdgcn_sched_barrier(0);
+        if (A.gs.plan) {
+            s8_gather(xin, A.gs, rec, 0, row0, A.ldx, A.act_off, ad, A.max_action, nullptr);
+            s8_gather(xin2, A.gs, rec, 1, row0, A.ldx, A.act_off, ad, A.max_action, const_cast<float *>(A.XA), rows[2]);
+        } else {
+            s8_load(xin, S8_LDX, A.ldx, A.XT + row0 * A.ldx, A.ldx);
+            s8_load(xin2, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
+            if (tid < S8_ROWS) rows[2][tid] = Bk.R[row0 + tid];
+        }
+        // everything the FIRST layer does not need goes out behind the input loads (loads return in order: the inputs would wait
+        // for all of it): -0.4 us/update at batch 256, -0.2 at 1024 with the critic side alone
+        __builtin_amdgcn_sched_barrier(0);
         s8_small_prefetch(tn.wf + ca + lc.w1, lc.K1, wbcT);
         s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbcA);
 #pragma unroll
@@ -688,15 +717,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const float bqT = tn.canon[ca + lc.b4], bqA = on.canon[ca + lc.b4];
         const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
         __builtin_amdgcn_sched_barrier(0);
-        if (A.gs.plan) {
-            s8_gather(xin, A.gs, rec, 0, row0, A.ldx, A.act_off, ad, A.max_action, nullptr);
-            s8_gather(xin2, A.gs, rec, 1, row0, A.ldx, A.act_off, ad, A.max_action, const_cast<float *>(A.XA), rows[2]);
-        } else {
-            s8_load(xin, S8_LDX, A.ldx, A.XT + row0 * A.ldx, A.ldx);
-            s8_load(xin2, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
-            if (tid < S8_ROWS) rows[2][tid] = Bk.R[row0 + tid];
-        }
-        s8_ring_prologue(ring, rbase, tn.wf + la.w2);
         s8_sync();
         s8_trunk(xin, la, wbaT, tn.wf, tn.canon, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
                  tn.wf + ca + lc.w2, tl, 1);
@@ -786,10 +806,15 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 22);
     } else {
     // ---------------------------------------------------------------------- actor side
+    s8_ring_prologue(ring, rbase, on.wf + la.w2);   // (as on the critic side: -0.4 us/update at batch 1024, neutral at 256)
     const PlanRec rec = s8_plan_rec(A.gs, row0);
     float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
     float w1n[4];
     s8_small_prefetch(on.wf + la.w1, la.K1, wba);
+    __builtin_amdgcn_sched_barrier(0);   // (as on the critic side: what the first layer does not need follows the input loads)
+    if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
+    else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
+    __builtin_amdgcn_sched_barrier(0);
     s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbc);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -805,9 +830,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     s8_small_prefetch(on.wd + la.w4, 16, wb4);
     __builtin_amdgcn_sched_barrier(0);
-    if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
-    else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
-    s8_ring_prologue(ring, rbase, on.wf + la.w2);
     s8_sync();
     s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
              tl, 1, msk[2], msk[3], msk[4]);
