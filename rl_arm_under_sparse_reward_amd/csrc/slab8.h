@@ -320,11 +320,13 @@ __device__ __forceinline__ void s8_small_prefetch(const float *__restrict__ wlay
 __device__ __forceinline__ void s8_small_layer(const float *lin, int ld_in, int Kred, const float4 (&b)[6], int epi,
                                                const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                                int ld_out, const s8_mask_t *mask_in = nullptr,
-                                               s8_mask_t *mask_out = nullptr, float *gout = nullptr) {
+                                               s8_mask_t *mask_out = nullptr, float *gout = nullptr,
+                                               const float *pre_e = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = wave >> 2;
     const int nb4 = Kred >> 2, half = nb4 >> 1, b0 = kh * half;
     float e[8];
-    if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
+    if (pre_e) e[0] = *pre_e;   // bias loaded at kernel entry (k_fb_slab8)
+    else if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     f32x4 c[S8_NRG];
 #pragma unroll
     for (int g = 0; g < S8_NRG; ++g) c[g] = f32x4{0, 0, 0, 0};
@@ -472,19 +474,22 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
                                          float *bufA, float *bufB, float *pbuf, float *g1, float *g2, float *g3,
                                          size_t row0, RingSlot *ring, int &rbase, const float *nxt,
                                          unsigned long long *tl, int tbase, s8_mask_t *m1 = nullptr,
-                                         s8_mask_t *m2 = nullptr, s8_mask_t *m3 = nullptr) {
+                                         s8_mask_t *m2 = nullptr, s8_mask_t *m3 = nullptr, const float *pre3 = nullptr) {
     S8_TSTAMP(tl, tbase);
     // the biases of the two 256 x 256 layers come in now: a global load issued at a layer's start is younger than the ring's
     // transfers in flight and, loads retiring in order, would make every counted wait of that layer one block stricter
     // (-0.3 us/update at batch 256, -0.6 at 1024)
     float eb2 = 0.f, eb3 = 0.f;
-    {
+    if (pre3) {   // k_fb_slab8 loaded all three at kernel entry: nothing comes in from global memory at a trunk's start
+        eb2 = pre3[1];
+        eb3 = pre3[2];
+    } else {
         const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col_ = 64 * (w_ & 3) + (threadIdx.x & 63);
         if ((w_ >> 2) == 0) { eb2 = canon[l.b2 + col_]; eb3 = canon[l.b3 + col_]; }
     }
     const float *pe2 = &eb2, *pe3 = &eb3;
     s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1,
-                   g1 ? g1 + row0 * H : nullptr);
+                   g1 ? g1 + row0 * H : nullptr, pre3);
     s8_sync();
     S8_TSTAMP(tl, tbase + 1);
     s8_big_layer(bufA, S8_LD, ring, rbase, wf + l.w2, wf + l.w3, SE_BIAS_RELU, canon + l.b2, 0, pbuf, bufB, S8_LD, nullptr, m2,
@@ -694,6 +699,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         float4 wbaT[6], wbcT[6], wbcA[6], whT[4], wqT[4], wqA[4];
         s8_ring_prologue(ring, rbase, tn.wf + la.w2);   // first: the transfers fly while the inputs and first-layer weights come in
         s8_small_prefetch(tn.wf + la.w1, la.K1, wbaT);
+#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
+        // biases of all three trunks (epilogue lanes: the reduction-half-0 waves, column 64 (wave % 4) + lane): the first layer's
+        // with its weights, the rest behind the inputs -- a trunk's start then waits for nothing from global memory
+        float ebT[3] = {0.f, 0.f, 0.f}, ebC[3] = {0.f, 0.f, 0.f}, ebA[3] = {0.f, 0.f, 0.f};
+        const int ecol_ = 64 * (wave & 3) + lane;
+        const bool ekh0_ = wave < 4;
+        if (ekh0_) ebT[0] = tn.canon[la.b1 + ecol_];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (A.gs.plan) {
             s8_gather(xin, A.gs, rec, 0, row0, A.ldx, A.act_off, ad, A.max_action, nullptr);
@@ -716,10 +729,20 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const float bhT = tn.canon[la.b4 + (lane < ad ? lane : 0)];
         const float bqT = tn.canon[ca + lc.b4], bqA = on.canon[ca + lc.b4];
         const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
+#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
+        if (ekh0_) {
+            ebT[1] = tn.canon[la.b2 + ecol_]; ebT[2] = tn.canon[la.b3 + ecol_];
+            ebC[0] = tn.canon[ca + lc.b1 + ecol_]; ebC[1] = tn.canon[ca + lc.b2 + ecol_]; ebC[2] = tn.canon[ca + lc.b3 + ecol_];
+            ebA[0] = on.canon[ca + lc.b1 + ecol_]; ebA[1] = on.canon[ca + lc.b2 + ecol_]; ebA[2] = on.canon[ca + lc.b3 + ecol_];
+        }
+        const float *pT = ebT, *pC = ebC, *pA = ebA;
+#else
+        const float *pT = nullptr, *pC = nullptr, *pA = nullptr;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         s8_sync();
         s8_trunk(xin, la, wbaT, tn.wf, tn.canon, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
-                 tn.wf + ca + lc.w2, tl, 1);
+                 tn.wf + ca + lc.w2, tl, 1, nullptr, nullptr, nullptr, pT);
         {   // target actor head -> action block of the target critic's input (models.py:24)
 #pragma unroll
             for (int i = 0; i < S8_RPW; ++i) {
@@ -736,7 +759,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         s8_sync();
         S8_TSTAMP(tl, 7);
         s8_trunk(xin, lc, wbcT, tn.wf + ca, tn.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
-                 on.wf + ca + lc.w2, tl, 8);
+                 on.wf + ca + lc.w2, tl, 8, nullptr, nullptr, nullptr, pC);
         {
 #pragma unroll
             for (int i = 0; i < S8_RPW; ++i) {
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 13);
         // critic(x, a): forward with global copies (weight gradients) and masks (dX chain below)
         s8_trunk(xin2, lc, wbcA, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, A.CAh1, A.CAh2, A.CAh3, row0, ring, rbase,
-                 on.wd + ca + lc.w3, tl, 14, msk[0], msk[1], nullptr);
+                 on.wd + ca + lc.w3, tl, 14, msk[0], msk[1], nullptr, pA);
         {
 #pragma unroll
             for (int i = 0; i < S8_RPW; ++i) {
@@ -811,6 +834,12 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
     float w1n[4];
     s8_small_prefetch(on.wf + la.w1, la.K1, wba);
+#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
+    float ebP[3] = {0.f, 0.f, 0.f}, ebQ[3] = {0.f, 0.f, 0.f};   // biases of the actor trunk and of the critic trunk behind it
+    const int ecol_ = 64 * (wave & 3) + lane;
+    const bool ekh0_ = wave < 4;
+    if (ekh0_) ebP[0] = on.canon[la.b1 + ecol_];
+#endif
     __builtin_amdgcn_sched_barrier(0);   // (as on the critic side: what the first layer does not need follows the input loads)
     if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
     else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
@@ -829,10 +858,19 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int j = 0; j < 4; ++j) w1n[j] = w1[j < ad ? j : ad - 1];
     }
     s8_small_prefetch(on.wd + la.w4, 16, wb4);
+#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
+    if (ekh0_) {
+        ebP[1] = on.canon[la.b2 + ecol_]; ebP[2] = on.canon[la.b3 + ecol_];
+        ebQ[0] = on.canon[ca + lc.b1 + ecol_]; ebQ[1] = on.canon[ca + lc.b2 + ecol_]; ebQ[2] = on.canon[ca + lc.b3 + ecol_];
+    }
+    const float *pP = ebP, *pQ = ebQ;
+#else
+    const float *pP = nullptr, *pQ = nullptr;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     s8_sync();
     s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
-             tl, 1, msk[2], msk[3], msk[4]);
+             tl, 1, msk[2], msk[3], msk[4], pP);
     S8_TSTAMP(tl, 5);
     float u_mine[S8_RPW], th_mine[S8_RPW];
 #pragma unroll
@@ -852,7 +890,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     s8_sync();
     S8_TSTAMP(tl, 7);
     s8_trunk(xin, lc, wbc, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
-             on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr);
+             on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr, pQ);
     {
 #pragma unroll
         for (int i = 0; i < S8_RPW; ++i) {
