@@ -179,11 +179,17 @@ __device__ __forceinline__ void s8_ring_issue(RingSlot *ring, int rbase, const f
 }
 
 // first S8_RING blocks of this wave's half of a 256-reduction layer (start of a chain)
+template <int T0 = 0, int T1 = S8_RING>
 __device__ __forceinline__ void s8_ring_prologue(RingSlot *ring, int rbase, const float *wlayer) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
 #pragma unroll
-    for (int t = 0; t < S8_RING; ++t) s8_ring_issue(ring, rbase, wlayer, cg, b0, t);
+    for (int t = T0; t < T1; ++t) s8_ring_issue(ring, rbase, wlayer, cg, b0, t);
 }
+// blocks of the chain's first ring issued in front of the input loads (the rest behind them).  us/update with 0 / 4 / 8 / 12 in
+// front: 40.09 / 39.70 / 39.56 / 39.79 at batch 256 and 46.12 / 45.00 / 44.69 / 45.30 at 512 k8 (4 rows), 54.63 / 54.87 / 54.76 /
+// 54.29 at 1024 (8 rows)
+#undef S8_PRO_FIRST
+#define S8_PRO_FIRST (S8_NRG == 1 ? 8 : S8_RING)
 
 // Block T of the 32 this wave consumes.  The weight operand is software-pipelined through registers: the LDS read of
 // block T+1 is issued BEFORE the 8 MFMAs of block T, so its latency hides under this wave's own matrix work instead
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const SlabNetPtrs &tn = A.target;
         const PlanRec rec = s8_plan_rec(A.gs, row0);
         float4 wbaT[6], wbcT[6], wbcA[6], whT[4], wqT[4], wqA[4];
-        s8_ring_prologue(ring, rbase, tn.wf + la.w2);   // first: the transfers fly while the inputs and first-layer weights come in
+        s8_ring_prologue<0, S8_PRO_FIRST>(ring, rbase, tn.wf + la.w2);   // first: the transfers fly while the inputs and first-layer weights come in
         s8_small_prefetch(tn.wf + la.w1, la.K1, wbaT);
 #if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
         // biases of all three trunks (epilogue lanes: the reduction-half-0 waves, column 64 (wave % 4) + lane): the first layer's
@@ -716,6 +722,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             s8_load(xin2, S8_LDX, A.ldx, A.XA + row0 * A.ldx, A.ldx);
             if (tid < S8_ROWS) rows[2][tid] = Bk.R[row0 + tid];
         }
+        s8_ring_prologue<S8_PRO_FIRST, S8_RING>(ring, rbase, tn.wf + la.w2);
         // everything the FIRST layer does not need goes out behind the input loads (loads return in order: the inputs would wait
         // for all of it): -0.4 us/update at batch 256, -0.2 at 1024 with the critic side alone
         __builtin_amdgcn_sched_barrier(0);
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 22);
     } else {
     // ---------------------------------------------------------------------- actor side
-    s8_ring_prologue(ring, rbase, on.wf + la.w2);   // (as on the critic side: -0.4 us/update at batch 1024, neutral at 256)
+    s8_ring_prologue<0, S8_PRO_FIRST>(ring, rbase, on.wf + la.w2);   // (as on the critic side: -0.4 us/update at batch 1024, neutral at 256)
     const PlanRec rec = s8_plan_rec(A.gs, row0);
     float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
     float w1n[4];
@@ -843,6 +850,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __builtin_amdgcn_sched_barrier(0);   // (as on the critic side: what the first layer does not need follows the input loads)
     if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
     else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
+    s8_ring_prologue<S8_PRO_FIRST, S8_RING>(ring, rbase, on.wf + la.w2);
     __builtin_amdgcn_sched_barrier(0);
     s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbc);
 #pragma unroll
