@@ -491,10 +491,15 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             P.ahead.R = xs ? a->R : a->R2;
             P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
         }
-        // L2 warmers: one spare workgroup per XCD while the launch still fits the CUs.  Measured (us/update, with vs
-        // without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs 54.2 at 512, 56.6 vs 57.1 at 768
-        P.n_pref = (a->fb_prefetch >= 0 ? a->fb_prefetch == 1
-                                        : n_chain + P.n_plan + P.n_ahead + 8 <= a->ctx->cu_count) ? 8 : 0;
+        // L2 warmers: spare workgroups (the same number on every XCD) while the launch still fits the CUs.  Measured (us/update, with
+        // 8 vs without): 39.9 vs 42.4 at batch 128, 42.1 vs 44.4 at 256, 46.4 vs 46.6 at 384, 52.8 vs 54.2 at 512, 56.6 vs 57.1 at 768.
+        // Two per XCD instead of one (round 3, after the entry reordering): 39.65 vs 39.82 at batch 256, 41.3 vs 43.0 at 384; 24 / 32: no
+        // further gain (40.0 / 40.0 vs 39.95 with 16).
+        {
+            const int fit = a->ctx->cu_count - (n_chain + P.n_plan + P.n_ahead);
+            const int want = fit >= 16 ? 16 : (fit >= 8 ? 8 : 0);
+            P.n_pref = a->fb_prefetch >= 0 ? (a->fb_prefetch == 1 ? (want ? want : 8) : 0) : want;
+        }
         const unsigned grid = n_chain + P.n_plan + P.n_ahead + P.n_pref;
         if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
