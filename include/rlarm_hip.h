@@ -35,7 +35,11 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 1
+/* Version of the STABLE surface declared in this header.  2 (round 4): the diagnostic / test-hook entry points moved to
+ * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
+ * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  hp_abi_version() returns the library's value; a host
+ * must refuse a library whose version differs from the header it was built against. */
+#define HP_ABI_VERSION 2
 
 typedef enum {
     HP_OK = 0,
@@ -65,14 +69,6 @@ int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
 int hp_ctx_pci_bus_id(hp_ctx *ctx, char *buf, size_t len);      /* "0000:05:00.0"; len >= 16 */
-/* diagnostic: average microseconds per dependent trivial kernel on the context's stream, measured
- * as an n-node captured hipGraph (graph != 0) or n eager launches (the launch floor in DESIGN.md) */
-int hp_ctx_launch_floor(hp_ctx *ctx, int n, int graph, double *us_per_kernel);
-/* diagnostic: microseconds a hipEvent pair reads with nothing between the two records (the bracketing overhead
- * inside every per-launch event measurement of hp_agent_profile; bench.py subtracts it) */
-int hp_ctx_event_pair_us(hp_ctx *ctx, int reps, double *us);
-/* diagnostic: shader clock in MHz observed by a probe kernel enqueued now (DVFS state under this load) */
-int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz);
 void hp_ctx_destroy(hp_ctx *ctx);
 
 /* ---- random stream ------------------------------------------------------------------
@@ -138,10 +134,6 @@ typedef struct {
 } hp_sample_out;
 int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *host_out);
-/* diagnostic: average device microseconds of the sampler's two kernels (index draw; gather + relabel + reward into the
- * reference's dict layout), `reps` back-to-back launches each, no host copies.  Consumes 1 + reps index draws. */
-int hp_buffer_sample_device_us(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
-                               int32_t reps, double *draw_us, double *gather_us);
 
 /* ---- GoalEnv reward / success as batched device ops --------------------------------------------
  * compute_reward (bmirobot_env_push_F.py:84-90 -> goal_distance :20-23; byte-identical in
@@ -220,9 +212,6 @@ int hp_agent_get_params(hp_agent *ag, int32_t net, float *flat_host, int64_t n);
  * written) */
 int hp_agent_get_grads(hp_agent *ag, int32_t net, float *flat_host, int64_t n);  /* net = actor|critic */
 int hp_agent_get_adam(hp_agent *ag, int32_t net, float *m_host, float *v_host, int64_t n, int64_t *step);
-/* test hook: load torch.optim.Adam state (exp_avg, exp_avg_sq in the flat order of utils.py:18-27; either may be NULL) and the
- * number of optimizer steps already taken (shared by both optimizers, ddpg_agent.py:272,277 step together) */
-int hp_agent_set_adam(hp_agent *ag, int32_t net, const float *m_host, const float *v_host, int64_t n, int64_t step);
 
 /* One ddpg_agent._update_network (:250-277) on a caller-provided, already normalised minibatch
  * (host float32: x [B,obs+goal], x_next [B,obs+goal], actions [B,act], r [B]).
@@ -350,18 +339,16 @@ int hp_agent_train_cycle_pinned(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, h
 
 /* timing hook for bench.py: average device time (ms) of the kernels tagged `which` over the
  * last recorded region; see DESIGN.md "Measurement". */
-/* diagnostic: microseconds per launch of ONE stage of the update, repeated n times in a captured
- * hipGraph (kind: 6 optimizer kernel, 8 polyak, 10 forward + backward of the active engine, 11 its chain kernel only,
- * 12 its weight-gradient launch + optimizer only) -- the per-stage numbers quoted in DESIGN.md / bench.py */
-int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_launch);
-/* diagnostic: stage-boundary time stamps (100 MHz ticks) of the slab kernels; only a build with
- * -DSLAB_TIMELINE writes them (tools/ubench/), a production build returns zeros */
-int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);
 /* Which kernels hp_agent_sample_and_update / hp_agent_train_cycle run for this agent (chosen at creation from the batch
  * size and the RLARM_* switches): *engine = 0 layer-per-launch, 8 thin row slabs (slab8.h, *slab_rows = 4 / 8 / 16),
  * 32 the 32-row engine (slab32.h); *dw_split = 0 for 32 x 32 weight-gradient tiles
  * (gemm_lds.h), else the number of batch-row slices per 64 x 64 tile (dw64.h).  Any pointer may be null. */
 int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *dw_split);
+/* Sticky health word of the learner, free for the host (pinned memory, no synchronisation): 0 = healthy.  Bit 0: a bounded
+ * in-launch hand-off gave up (bits 4-7: which -- 1 critic chains -> weight-gradient tiles, 2 actor chains -> critic optimizer
+ * step, 3 cycle-opening launch); the launches since skipped work, every later hp_agent_train_cycle* /
+ * hp_agent_sample_and_update / hp_agent_get_losses fails with HP_ERR_STATE, the agent must be recreated. */
+int hp_agent_status(hp_agent *ag, uint32_t *fault);
 int hp_agent_profile(hp_agent *ag, int32_t enable);
 int hp_agent_profile_read(hp_agent *ag, double *ms_out, int32_t n);
 

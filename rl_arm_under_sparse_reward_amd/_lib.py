@@ -40,7 +40,13 @@ class AgentCfg(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
 
 
-# name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h
+ABI_VERSION = 2     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
+
+# entry points declared in include/rlarm_hip_debug.h: diagnostics and test hooks, outside the stable surface
+DEBUG_SYMBOLS = {"hp_ctx_launch_floor", "hp_ctx_event_pair_us", "hp_ctx_clock_mhz", "hp_ctx_calibrate", "hp_buffer_sample_device_us",
+                 "hp_agent_set_adam", "hp_agent_debug_chain", "hp_agent_debug_timeline"}
+
+# name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h and include/rlarm_hip_debug.h
 PROTOTYPES = {
     "hp_abi_version": (C.c_int, []),
     "hp_last_error": (C.c_char_p, []),
@@ -52,6 +58,7 @@ PROTOTYPES = {
     "hp_ctx_launch_floor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p]),
     "hp_ctx_event_pair_us": (C.c_int, [C.c_void_p, C.c_int, f64p]),
     "hp_ctx_clock_mhz": (C.c_int, [C.c_void_p, f64p]),
+    "hp_ctx_calibrate": (C.c_int, [C.c_void_p, f64p]),
     "hp_ctx_destroy": (None, [C.c_void_p]),
     "hp_rng_create": (C.c_int, [C.c_void_p, c_void_pp]),
     "hp_rng_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -138,6 +145,7 @@ PROTOTYPES = {
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
     "hp_agent_debug_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "hp_agent_engine": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hp_agent_status": (C.c_int, [C.c_void_p, u32p]),
     "hp_agent_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_profile_read": (C.c_int, [C.c_void_p, f64p, C.c_int32]),
     "hp_agent_destroy": (None, [C.c_void_p]),
@@ -224,8 +232,9 @@ def load(path: str | None = None):
             fn.argtypes = args
         if missing:    # header/library mismatch (tests/test_abi.py asserts this list is empty)
             raise HpError("librlarm_hip.so does not export: " + ", ".join(missing) + " -- rebuild it")
-        if lib.hp_abi_version() != 1:
-            raise HpError("librlarm_hip.so ABI version mismatch")
+        if lib.hp_abi_version() != ABI_VERSION:
+            raise HpError(f"librlarm_hip.so has ABI version {lib.hp_abi_version()}, this package binds version {ABI_VERSION} "
+                          "(include/rlarm_hip.h: HP_ABI_VERSION) -- rebuild it")
         _lib = _Library(lib)
         return _lib
 

@@ -91,6 +91,43 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
     st->bc2_sqrt = (float)sqrt(bc2);
 }
 
+// hand-off counters of the split launch (slab8_split.h): 6 counters x 8 XCD copies, SPLIT_CTR_STRIDE words apart, then the
+// learner's sticky fault word
+#define SPLIT_CTR_STRIDE 64          // 256 bytes: another memory channel
+#define SPLIT_COUNTERS 6
+#define SPLIT_FAULT (SPLIT_COUNTERS * 8 * SPLIT_CTR_STRIDE)
+#define SPLIT_SYNC_WORDS (SPLIT_FAULT + 4)
+
+// sticky fault word of in-launch hand-offs: bit 0 = a poll gave up, bits 4-7 = which (1 critic chains published, 2 actor
+// chains past the critic, 3 cycle-opening launch), mirrored into pinned host memory so that the next host call fails loudly
+__device__ __forceinline__ void handoff_fault(unsigned *fault, unsigned *fault_host, unsigned which) {
+    const unsigned word = 1u | (which << 4);
+    __hip_atomic_fetch_or(fault, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fault_host) __hip_atomic_fetch_or(fault_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// bounded wait until *ctr >= need (agent scope); the verdict reaches every thread of the workgroup (contains barriers: call
+// from uniform control flow).  flag: one int of LDS nobody else touches between the two barriers.
+__device__ __forceinline__ bool handoff_wait(const unsigned *ctr, unsigned need, unsigned long long ticks, unsigned *fault,
+                                             unsigned *fault_host, unsigned which, int *flag) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(12);   // ~0.3 us between polls: many workgroups poll one word
+            if (wall_clock64() - t0 > ticks) {
+                handoff_fault(fault, fault_host, which);
+                ok = 0;
+                break;
+            }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
 #define LOSS_LOG 4096
 
 #include "slab_common.h"
@@ -110,6 +147,7 @@ struct hp_agent {
     float *XA2 = nullptr, *XP2 = nullptr, *XT2 = nullptr, *R2 = nullptr;   // second input set (gather-ahead ping-pong)
     Pass AT, CT, CA, AP, CP;
     float *QT = nullptr, *QA = nullptr, *QP = nullptr, *dQA = nullptr, *dQP = nullptr;
+    float *QT2 = nullptr;                // split launch (slab8_split.h): Q' of the next update's minibatch (ping-pong with QT)
     float *dA3 = nullptr, *dA2 = nullptr, *dA1 = nullptr;  // critic-loss path
     float *dP3 = nullptr, *dP2 = nullptr, *dP1 = nullptr, *dXP = nullptr;  // actor-loss path through the critic
     float *dZ = nullptr, *dK3 = nullptr, *dK2 = nullptr, *dK1 = nullptr;   // actor
@@ -182,6 +220,13 @@ struct hp_agent {
     int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
     float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)
     unsigned long long *gl_ticket = nullptr;
+    // split launch (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the
+    // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
+    // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
+    int split_mode = -1, split_place = 1;
+    unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
+    unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
+    unsigned *fault_host_dev = nullptr;
     bool cycle_open = true;              // RLARM_CYCLE_OPEN=0: slots / scatter / plans / normalizer as separate launches
     bool g_open = false;
     void *g_slots = nullptr;
@@ -341,7 +386,13 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     // last update of a training cycle: the optimizer launch also applies the soft update of both target networks
     // (ddpg_agent.py:149-150) to the parameters it has just stepped -- no separate polyak launch
     bool polyak_after = false;
+    // split launch (slab8_split.h): this update's Q' was computed one launch ahead (set qset of QT / QT2); t_plan = plan of the
+    // NEXT update, whose Q' the target chains of this launch compute into the other set (nullptr: last update of the sequence)
+    bool split = false;
+    int qset = 0;
+    const PlanRec *t_plan = nullptr;
 };
+#define SPLIT_MIN_UPDATES 4   // shorter sequences keep the two-launch form (the target prologue would cost more than it saves)
 
 // workgroups of the chain kernel that carry chains (the spare ones -- index plan, look-ahead gather, L2 warmers -- follow)
 static inline int chain_wgs(const hp_agent *a) { return 2 * (a->Mp / a->s8_rows); }
@@ -358,6 +409,12 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
 int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fuse_adam = false, bool *fused = nullptr);
 // only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
+// split launch: does this agent's shape fit it (4-row slabs, three kinds of chains + spare workgroups on the CUs)?
+bool split_fits(const hp_agent *a);
+// ... and its prologue: the target chains of a sequence's FIRST update (plan = that update's index plan) into Q' set 0
+int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc);
+// a bounded in-launch hand-off gave up earlier (k_cycle_open, k_fb_split8): HP_ERR_STATE + message; free for the host
+int agent_check_fault(const hp_agent *a, const char *who);
 int enqueue_adam(hp_agent *a, bool polyak_after = false);   // polyak_after: see GatherCtx (slab engines; returns whether via *folded)
 int enqueue_polyak(hp_agent *a);
 // cycle_open.hip: slots + scatter + normalizer update + first minibatch plans of a cycle as one launch

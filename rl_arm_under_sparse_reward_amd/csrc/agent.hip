@@ -8,6 +8,20 @@
 
 static void drop_graph(hp_agent *a);
 
+// A bounded in-launch hand-off gave up in an earlier launch (k_cycle_open's flags, k_fb_split8's counters): work was skipped, so
+// buffer / normalizer / parameters are no longer what the reference would hold.  The word is sticky and mirrored into pinned
+// host memory by the kernel that gave up: reading it costs the host nothing, and every entry point that enqueues more work on
+// this learner checks it first (as peer_check_alive does for the rank exchange).
+int agent_check_fault(const hp_agent *a, const char *who) {
+    const unsigned w = a->fault_host ? *(volatile const unsigned *)a->fault_host : 0u;
+    if (w == 0u) return HP_OK;
+    const unsigned which = (w >> 4) & 15u;
+    hp_set_error("%s: an in-launch hand-off gave up earlier (%s%s%s; word 0x%x): the launches since skipped work and the "
+                 "learner's state is not valid -- recreate the agent", who, (which & 1u) ? "critic chains -> weight-gradient tiles " : "",
+                 (which & 2u) ? "actor chains -> critic optimizer step " : "", which == 3u ? "/ cycle-opening launch" : "", w);
+    return HP_ERR_STATE;
+}
+
 static int ensure_plan(hp_agent *a, int n_batches) {
     if (n_batches > a->plan_batches) {
         // the cached cycle graph has the plan's address baked into its draw / gather / ride-along kernels: growing the
@@ -66,6 +80,10 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const bool dw_ride = want_offload && !side_gather;
     const bool ahead = ride && ((a->slab8 && (a->gather_ahead || side_gather || dw_ride)) || s32_side || s32_ride);
     const int lead = ahead ? 2 : 1;
+    // split form (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the chain
+    // launch.  Needs the chain kernel's own look-ahead (plans two updates ahead, gather workgroups) and the fused optimizer.
+    const bool split = ride && ahead && !dw_ride && !side_gather && a->slab8 && a->gather_ahead && split_fits(a) &&
+                       (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
     {
         ProfScope ps(a, PROF_PLAN);
         const int first = ride ? (n_updates < lead ? n_updates : lead) : n_updates;
@@ -94,8 +112,15 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_join, hipEventDisableTiming));
     }
     bool join_pending = false;
+    if (split) {   // Q' of the first update's minibatch (every later one is computed one launch ahead)
+        GatherCtx g0{b, on, gn, a->plan.as<PlanRec>(), sq};
+        HP_TRY(enqueue_split_prologue(a, &g0));
+    }
     for (int u = 0; u < n_updates; ++u) {
         GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
+        gc.split = split;
+        gc.qset = u & 1;
+        gc.t_plan = (split && u + 1 < n_updates) ? a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B : nullptr;
         hipStream_t ms = a->ctx->stream;
         if (join_pending) {   // the plan drawn beside the previous update is what this launch gathers from
             HP_CHECK_HIP(hipStreamWaitEvent(ms, a->plan_join, 0));
@@ -262,7 +287,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->XA, Mp * ldx); A(&a->XP, Mp * ldx); A(&a->XT, Mp * ldx); A(&a->R, Mp); A(&a->TP, 2 * Mp * 16);
     A(&a->XA2, Mp * ldx); A(&a->XP2, Mp * ldx); A(&a->XT2, Mp * ldx); A(&a->R2, Mp);
     for (Pass *ps : {&a->AT, &a->CT, &a->CA, &a->AP, &a->CP}) { A(&ps->h1, Mp * H); A(&ps->h2, Mp * H); A(&ps->h3, Mp * H); }
-    A(&a->QT, Mp * 16); A(&a->QA, Mp * 16); A(&a->QP, Mp * 16); A(&a->dQA, Mp * 16); A(&a->dQP, Mp * 16);
+    A(&a->QT, Mp * 16); A(&a->QT2, Mp * 16); A(&a->QA, Mp * 16); A(&a->QP, Mp * 16); A(&a->dQA, Mp * 16); A(&a->dQP, Mp * 16);
     A(&a->dA3, Mp * H); A(&a->dA2, Mp * H); A(&a->dA1, Mp * H);
     A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
     A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
@@ -306,6 +331,8 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->upd_graph_ok = tri("RLARM_UPDATE_GRAPH") != 0;
         a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
         a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
+        a->split_mode = tri("RLARM_SPLIT");
+        if (const char *sp = getenv("RLARM_SPLIT_PLACE")) a->split_place = atoi(sp);
         a->gl_uni = tri("RLARM_GEMM_UNI");
         a->adam_wt = tri("RLARM_ADAM_WT");
         if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
@@ -322,6 +349,18 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->open_sync, 4);
+    if (st == HP_OK) st = dev_alloc(a, &a->k1_sync, SPLIT_SYNC_WORDS);
+    if (st == HP_OK) {   // sticky fault word of the in-launch hand-offs, mirrored where the host can read it without a sync
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            hp_set_error("hp_agent_create: pinned fault word: %s", hipGetErrorString(hipGetLastError()));
+            st = HP_ERR_HIP;
+        } else {
+            memset(hp, 0, 64);
+            a->fault_host = static_cast<unsigned *>(hp);
+            a->fault_host_dev = static_cast<unsigned *>(dp);
+        }
+    }
     if (st == HP_OK && a->slab) {   // split narrow weight-gradient tiles (gemm_lds.h): 4 slices from 768 batch rows (us/update with
         // 1 / 2 / 4 / 8 slices: 58.6 / 57.1 / 55.6 / 60.0 at batch 1024; 47.7 / 48.2 / 48.2 / 52.4 at 512 k8; 40.6 / 41.9 / 42.7 / - at 256;
         // 1 vs 4 slices: 54.2 / 53.1 at 768, 55.6 / 54.1 at 896, 82.1 / 78.9 at 1152, 83.6 / 79.2 at 1280)
@@ -482,6 +521,7 @@ int hp_agent_sample_and_update(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *
     HP_SERIALISE(a);
     HP_REQUIRE(n_updates > 0, HP_ERR_INVALID, "hp_agent_sample_and_update: n_updates must be positive");
     HP_TRY(peer_check_alive(a->peer, "hp_agent_sample_and_update"));
+    HP_TRY(agent_check_fault(a, "hp_agent_sample_and_update"));
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     HP_TRY(ensure_plan(a, n_updates));
     hipStream_t s = a->ctx->stream;
@@ -575,6 +615,7 @@ int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
     HP_CHECK_HIP(hipMemcpyAsync(&h, a->d_state, sizeof(h), hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipMemcpyAsync(log.data(), a->loss_log, log.size() * 4, hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_TRY(agent_check_fault(a, "hp_agent_get_losses"));
     HP_REQUIRE(h.open_timeouts == 0u, HP_ERR_STATE, "hp_agent_get_losses: %u hand-off polls of the cycle-opening launch gave up "
                "(k_cycle_open): the cycles since are not valid", h.open_timeouts);
     HP_REQUIRE(h.n_logged >= n_last, HP_ERR_STATE, "hp_agent_get_losses: only %lld updates logged", h.n_logged);
@@ -583,6 +624,12 @@ int hp_agent_get_losses(hp_agent *a, float *out_host, int32_t n_last) {
         out_host[2 * i] = log[(k % LOSS_LOG) * 2];
         out_host[2 * i + 1] = log[(k % LOSS_LOG) * 2 + 1];
     }
+    return HP_OK;
+}
+
+int hp_agent_status(hp_agent *a, uint32_t *fault) {
+    HP_REQUIRE(a && fault, HP_ERR_INVALID, "hp_agent_status: null argument");
+    *fault = a->fault_host ? *(volatile const unsigned *)a->fault_host : 0u;
     return HP_OK;
 }
 
@@ -682,6 +729,7 @@ static int train_cycle_checks(hp_agent *a, hp_buffer *b, int64_t n_new, int32_t 
     HP_REQUIRE(n_new > 0 && n_batches > 0, HP_ERR_INVALID, "%s: n_new and n_batches must be positive", who);
     HP_REQUIRE(!(b->current_size == 0 && n_new > b->size), HP_ERR_INVALID, "high <= 0");
     HP_REQUIRE(!a->prof, HP_ERR_STATE, "%s: profiling mode uses the eager path (hp_agent_profile(0) first)", who);
+    HP_TRY(agent_check_fault(a, who));
     return peer_check_alive(a->peer, who);
 }
 
@@ -838,6 +886,7 @@ void hp_agent_destroy(hp_agent *a) {
     a->pin.release();
     if (a->ev0) (void)hipEventDestroy(a->ev0);
     if (a->ev1) (void)hipEventDestroy(a->ev1);
+    if (a->fault_host) (void)hipHostFree(a->fault_host);
     delete a;
 }
 

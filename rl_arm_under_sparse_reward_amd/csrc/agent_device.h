@@ -36,11 +36,65 @@ struct AdamFuse {
     float *tgt, *fragFT;
     float polyak, one_minus;
     int wt;                           // write-through stores for the stepped state (adam_apply4)
+    // tiles that run INSIDE the chain launch (k_fb_split8, slab8_split.h): the step may only be stored once `gate_need` chains
+    // of that launch have counted themselves past the parameters it overwrites (*gate, agent scope); a poll that gives up
+    // after gate_ticks (100 MHz) skips the step, sets the sticky fault word and its pinned host mirror
+    const unsigned *gate;             // first gate counter, copy of XCD 0; XCD x polls the copy x * SPLIT_CTR_STRIDE words on
+    unsigned gate_need;
+    unsigned gate_sel;                // 4 bits per problem of the group: which gate counter (0, 1, 2) its step waits for
+    unsigned *fault, *fault_host;
+    unsigned long long gate_ticks;
+    unsigned *reset_sync;             // the launch BEHIND k_fb_split8: its workgroup 0 clears that launch's counters
+    int tl_mark;                      // time-line builds: record this launch's gate stamps
 };
 
+// Everything the optimizer epilogue reads of its argument block, loaded NOW and held in scalar registers.  Inside k_fb_split8 the
+// block sits at the end of a 2.5 KB kernel-argument segment and the compiler loads each field where it is first used: behind the
+// gate that meant four dependent scalar-cache misses (~0.5 us each) between "gate passed" and the first store -- the epilogue
+// took 2.4 us instead of the stand-alone launch's 1.3 (round 4 time line).  Called at tile entry, where the latency hides under
+// the operand transfers.
+template <class T> __device__ __forceinline__ T sgpr_pin(T v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ void sgpr_pin_layout(NetLayout &l) {
+    l.K1 = sgpr_pin(l.K1); l.w1 = sgpr_pin(l.w1); l.b1 = sgpr_pin(l.b1); l.w2 = sgpr_pin(l.w2); l.b2 = sgpr_pin(l.b2);
+    l.w3 = sgpr_pin(l.w3); l.b3 = sgpr_pin(l.b3); l.w4 = sgpr_pin(l.w4); l.b4 = sgpr_pin(l.b4); l.total = sgpr_pin(l.total);
+}
+__device__ __forceinline__ AdamFuse adam_pinned(const AdamFuse &F) {
+    AdamFuse L = F;
+    L.p = sgpr_pin(L.p); L.p_out = sgpr_pin(L.p_out); L.m = sgpr_pin(L.m); L.v = sgpr_pin(L.v);
+    L.fragF = sgpr_pin(L.fragF); L.fragD = sgpr_pin(L.fragD); L.grads_base = sgpr_pin(L.grads_base); L.scal = sgpr_pin(L.scal);
+    sgpr_pin_layout(L.am.la); sgpr_pin_layout(L.am.lc);
+    L.am.H = sgpr_pin(L.am.H); L.am.mode = sgpr_pin(L.am.mode);
+    L.n_actor = sgpr_pin(L.n_actor);
+    L.w = sgpr_pin(L.w); L.b2 = sgpr_pin(L.b2); L.omb2 = sgpr_pin(L.omb2); L.eps = sgpr_pin(L.eps);
+    L.keep_grads = sgpr_pin(L.keep_grads);
+    L.tgt = sgpr_pin(L.tgt); L.fragFT = sgpr_pin(L.fragFT); L.polyak = sgpr_pin(L.polyak); L.one_minus = sgpr_pin(L.one_minus);
+    L.wt = sgpr_pin(L.wt);
+    L.gate = sgpr_pin(L.gate); L.gate_need = sgpr_pin(L.gate_need); L.gate_sel = sgpr_pin(L.gate_sel);
+    L.fault = sgpr_pin(L.fault); L.fault_host = sgpr_pin(L.fault_host); L.gate_ticks = sgpr_pin(L.gate_ticks);
+    return L;
+}
+
+__device__ __forceinline__ bool adam_gate_wait(const AdamFuse &F, int prob, int *flag) {
+    if (!F.gate) return true;
+    const unsigned which = (F.gate_sel >> (4 * prob)) & 15u;
+    return handoff_wait(F.gate + (which * 8 + (blockIdx.x & 7)) * SPLIT_CTR_STRIDE, F.gate_need, F.gate_ticks, F.fault, F.fault_host, 2u,
+                        flag);
+}
+
+
+// AGENT: the step scalars were written (write-through) by a workgroup of the SAME launch: agent-scope loads
+template <bool AGENT>
+__device__ __forceinline__ float adam_scal(const AdamFuse &F, int i) {
+    if constexpr (AGENT) return __hip_atomic_load(F.scal + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return F.scal[i];
+}
+template <bool AGENT = false>
 __device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
-    const float neg_step_size = F.scal[idx < F.n_actor ? 0 : 1];
-    const float bc2_sqrt = F.scal[2];
+    const float neg_step_size = adam_scal<AGENT>(F, idx < F.n_actor ? 0 : 1);
+    const float bc2_sqrt = adam_scal<AGENT>(F, 2);
     float mi = F.m[idx], vi = F.v[idx];
     mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
@@ -80,9 +134,10 @@ struct AdamState4 {   // optimizer state of 4 consecutive elements + the step sc
     float4 p, m, v;
     float neg_step_size, bc2_sqrt;
 };
+template <bool AGENT = false>
 __device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, int idx0) {
-    S.neg_step_size = F.scal[idx0 < F.n_actor ? 0 : 1];
-    S.bc2_sqrt = F.scal[2];
+    S.neg_step_size = adam_scal<AGENT>(F, idx0 < F.n_actor ? 0 : 1);
+    S.bc2_sqrt = adam_scal<AGENT>(F, 2);
     S.p = *reinterpret_cast<const float4 *>(F.p + idx0);
     S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
     S.v = *reinterpret_cast<const float4 *>(F.v + idx0);

@@ -411,14 +411,125 @@ static int dw64_args(hp_agent *a, const Launch &L, Dw64Args &X) {
     return HP_OK;
 }
 
-// slab engines: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): chain kernel + weight-gradient launch
-// only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
-int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
+// ---- split launch (slab8_split.h) ------------------------------------------------------------------------------------------
+static int split_warmers(const hp_agent *a) {   // L2 warmers per XCD that still fit beside three kinds of chains + the spare workgroups
+    const int per_xcd = a->ctx->cu_count / 8;
+    const int nslab = a->Mp / 4;
+    const int chains = 3 * ((nslab + 7) / 8) + 1;   // worst XCD: its share of every kind of chain + a plan / gather workgroup
+    return per_xcd - chains >= 2 ? 2 : (per_xcd - chains >= 1 ? 1 : 0);
+}
+bool split_fits(const hp_agent *a) {
+    if (!a->slab8 || a->s8_rows != 4 || a->dw64 || !a->fuse_adam_ok || a->comm || a->peer) return false;
+    if (a->Mp < GL_RING_MIN_K || a->dw_ksplit > 1) return false;   // the in-launch tiles take the ring path, unsplit
+    if (a->ctx->cu_count % 8 != 0) return false;
+    const int per_xcd = a->ctx->cu_count / 8, nslab = a->Mp / 4;
+    return 3 * ((nslab + 7) / 8) + 1 <= per_xcd;
+}
+
+// Who runs where.  Workgroup b of the launch lands on XCD b % 8, and within an XCD in index order: chains first, then the spare
+// workgroups, the weight-gradient tiles last (they wait for chains).  place 0: every kind of chain spread evenly over the XCDs.
+// place 1: actor-side chains on XCDs 0-3 with the warmers and spare workgroups, target chains on XCDs 4-7, critic chains on
+// both halves -- an XCD then streams 4 of the 6 fragment sets (as Launch::xcd_split does for k_fb_slab8).
+static unsigned build_split_roles(const hp_agent *a, s8r4::FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
+                                  int n_tiles) {
+    using namespace s8r4;
+    const int nslab = a->Mp / 4, per_xcd = a->ctx->cu_count / 8;
+    int n[8][SR_N];
+    memset(n, 0, sizeof(n));
+    auto spread = [&](int role, int count, int x0, int nx) {   // evenly over XCDs x0 .. x0 + nx - 1, remainder to the first ones
+        for (int i = 0; i < nx; ++i) n[x0 + i][role] += count / nx + (i < count % nx ? 1 : 0);
+    };
+    const bool half = a->split_place == 1 && nslab % 8 == 0 && chains_ac && 3 * (nslab / 8) + 2 <= per_xcd;
+    if (half) {
+        if (chains_ac) { spread(SR_A, nslab, 0, 4); spread(SR_C, nslab, 0, 8); }
+        if (chains_t) spread(SR_T, nslab, 4, 4);
+    } else {
+        if (chains_ac) { spread(SR_A, nslab, 0, 8); spread(SR_C, nslab, 0, 8); }
+        if (chains_t) spread(SR_T, nslab, 0, 8);
+    }
+    for (int i = 0; i < n_plan; ++i) n[i % (half ? 4 : 8)][SR_PLAN] += 1;
+    for (int i = 0; i < n_ahead; ++i) n[(n_plan + i) % (half ? 4 : 8)][SR_AHEAD] += 1;
+    int warm = a->fb_prefetch == 0 ? 0 : split_warmers(a);
+    Q.warm_side = 0u;
+    for (int x = 0; x < 8; ++x) {
+        int used = 0;
+        for (int r = 0; r < SR_WARM; ++r) used += n[x][r];
+        const int w = (per_xcd - used) < warm ? (per_xcd - used > 0 ? per_xcd - used : 0) : warm;
+        n[x][SR_WARM] = (!chains_ac && !chains_t) ? 0 : w;
+        // what this XCD's chains stream: 1 = the actor side's sets, 0 = the critic side's (targets + critic), 2 = all
+        const unsigned side = half ? (x < 4 ? 1u : 0u) : (chains_ac ? 2u : 0u);
+        Q.warm_side |= side << (4 * x);
+    }
+    // tiles: dealt to the XCDs in proportion to the CUs their short chains (C, T) and idle CUs leave them; the kernel numbers
+    // them slot-major across the XCDs (slab8_split.h)
+    if (n_tiles > 0) {
+        int room[8], total = 0;
+        for (int x = 0; x < 8; ++x) {
+            room[x] = per_xcd - n[x][SR_A] - n[x][SR_PLAN] - n[x][SR_AHEAD] - n[x][SR_WARM];
+            if (room[x] < 0) room[x] = 0;
+            total += room[x];
+        }
+        int given = 0;
+        for (int x = 0; x < 8; ++x) {
+            n[x][SR_TILE] = total ? n_tiles * room[x] / total : 0;
+            given += n[x][SR_TILE];
+        }
+        for (int x = 0; given < n_tiles; x = (x + 1) % 8) { n[x][SR_TILE] += 1; ++given; }
+    }
+    unsigned rows = 0;
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long packed = 0ull;
+        unsigned tot = 0;
+        for (int r = 0; r < SR_N; ++r) {
+            packed |= (unsigned long long)(n[x][r] & 0xff) << (8 * r);
+            tot += (unsigned)n[x][r];
+        }
+        Q.nrole[x] = packed;
+        rows = tot > rows ? tot : rows;
+    }
+    return 8u * rows;   // grid: workgroup b = 8 * slot + XCD; slots past an XCD's list exit at once
+}
+
+// the weight-gradient problems of one network (critic: inside the split launch; actor: the launch behind it)
+static Launch build_dw_half(const hp_agent *a, bool critic, const float *sX, float *grads) {
     const int H = a->H, Mp = a->Mp, ldx = a->ldx;
     const NetLayout &la = a->la, &lc = a->lc;
-    hipStream_t s = a->ctx->stream;
-    const int nslab = Mp / (a->slab8 ? a->s8_rows : S32_ROWS);
+    if (!grads) grads = a->grads;
+    float *Ga = grads, *Gc = grads + la.total;
+    Launch L;
+    if (critic) {
+        // in the order the critic chains publish the operands (slab8_split.h: stages 0, 0, 1, 2)
+        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
+        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
+        add_dw(L, a->dA1, H, H, sX, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+    } else {
+        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
+        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+        add_dw(L, a->dK1, H, H, sX, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        // two 256 x 256 problems: four XCDs each (gemm_tile: placed2)
+        if (a->gemm_xcd && L.g.p[0].tiles_n == 8 && L.g.p[0].M == 256 && L.g.p[1].tile0 == 64 && L.g.p[1].tiles_n == 8 && L.g.p[1].M == 256)
+            L.g.xcd = 2;
+    }
+    L.g.uni = a->gl_uni >= 0 ? a->gl_uni : (Mp > 256 && Mp <= 640 ? 1 : 0);
+    return L;
+}
+
+// slab engines: forwards + losses + backwards of one update (inputs in XA/XP/XT/R): chain kernel + weight-gradient launch
+// only = 1 / 2: just the chain kernel / just the weight-gradient launch (timing diagnostics, hp_agent_debug_chain)
+// argument blocks of the chain kernels for one update (gc as in enqueue_forward_backward_slab)
+struct FbBuilt {
     FbSlabArgs P;
+    int nslab, xs;
+    float *sXA, *sXP, *sXT, *sR;
+    bool ride_dw, ride;
+};
+static void build_fb_args(hp_agent *a, const GatherCtx *gc, FbBuilt &O) {
+    const int H = a->H, Mp = a->Mp, ldx = a->ldx;
+    const NetLayout &la = a->la, &lc = a->lc;
+    const int nslab = Mp / (a->slab8 ? a->s8_rows : S32_ROWS);
+    FbSlabArgs &P = O.P;
     const int xs = gc ? gc->xset : 0;
     float *sXA = xs ? a->XA2 : a->XA, *sXP = xs ? a->XP2 : a->XP, *sXT = xs ? a->XT2 : a->XT, *sR = xs ? a->R2 : a->R;
     const SlabNetPtrs online = SlabNetPtrs{a->fragF, a->fragD, a->params};
@@ -472,6 +583,20 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         A.T = ride ? gc->b->T : 0;
         A.plan_batch = a->B;
     }
+    O.nslab = nslab; O.xs = xs; O.sXA = sXA; O.sXP = sXP; O.sXT = sXT; O.sR = sR; O.ride_dw = ride_dw; O.ride = ride;
+}
+
+static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only);
+int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
+    const int ldx = a->ldx;
+    hipStream_t s = a->ctx->stream;
+    FbBuilt built;
+    build_fb_args(a, gc, built);
+    FbSlabArgs &P = built.P;
+    const int nslab = built.nslab, xs = built.xs;
+    float *sXA = built.sXA, *sXP = built.sXP;
+    const bool ride_dw = built.ride_dw, ride = built.ride;
+    if (gc && gc->split) return enqueue_split_update(a, gc, built, fuse_adam, only);
     if (only == 2) {
     } else if (a->slab8) {
         // one launch: each workgroup carries its rows through forward AND backward (k_fb_slab8)
@@ -582,12 +707,118 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
     return HP_OK;
 }
 
+// ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step), then the actor's tiles
+static void split_common(hp_agent *a, s8r4::FbSplitArgs &Q) {
+    Q.sync = a->k1_sync;
+    Q.fault_host = a->fault_host_dev;
+    Q.wait_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock: three orders of magnitude beyond a launch
+}
+
+static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only) {
+    HP_REQUIRE(only == 0 && fuse_adam && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine / call");
+    hipStream_t s = a->ctx->stream;
+    FbSlabArgs &P = built.P;
+    const int xs = built.xs, nslab = built.nslab;
+    static s8r4::FbSplitArgs Qz;   // zero template (the struct has padding the kernel never reads)
+    s8r4::FbSplitArgs Q = Qz;
+    P.n_plan = built.ride ? 1 : 0;
+    P.n_ahead = 0;
+    P.xcd_split = 0;
+    P.n_pref = 0;
+    P.ahead = P.f.gs;
+    P.aXT = P.aXA = P.aXP = nullptr;
+    if (gc->ahead_plan) {   // next update's inputs into the other set (the target side gathers its own rows)
+        P.n_ahead = S8_AHEAD_WGS;
+        P.ahead.plan = gc->ahead_plan;
+        P.ahead.plan_any = gc->ahead_plan;
+        P.ahead.R = xs ? a->R : a->R2;
+        P.aXT = xs ? a->XT : a->XT2; P.aXA = xs ? a->XA : a->XA2; P.aXP = xs ? a->XP : a->XP2;
+    }
+    Q.tgs = P.f.gs;
+    if (gc->t_plan) {
+        Q.tgs.plan = gc->t_plan;
+        Q.tgs.plan_any = gc->t_plan;
+    }
+    Q.tgs.R = nullptr;
+    Q.qt_in = gc->qset ? a->QT2 : a->QT;
+    Q.qt_out = gc->qset ? a->QT : a->QT2;
+    split_common(a, Q);
+    Launch Lc = build_dw_half(a, true, built.sXA, nullptr);
+    Q.tiles = Lc.g;
+    Q.need_c = (unsigned)nslab;
+    Q.tile_stage = 0u | (0u << 4) | (1u << 8) | (2u << 12);
+    Q.tl_mark = gc->t_plan != nullptr ? 1 : 0;
+    AdamFuse F = adam_fuse(a);
+    F.keep_grads = a->keep_grads_dbg ? 1 : 0;
+    if (gc->polyak_after) fold_polyak(a, F);
+    F.gate = a->k1_sync + 3 * 8 * SPLIT_CTR_STRIDE;
+    F.gate_need = (unsigned)nslab;
+    F.gate_sel = 1u | (0u << 4) | (2u << 8) | (0u << 12);   // W3: past the first dX layer, W4: past the forward, W2: past the second dX layer, W1: forward
+    F.fault = a->k1_sync + SPLIT_FAULT;
+    F.fault_host = a->fault_host_dev;
+    F.gate_ticks = Q.wait_ticks;
+    F.tl_mark = gc->t_plan != nullptr ? 1 : 0;
+    Q.adam = F;
+    Q.s = P;
+    const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, Lc.tiles);
+    {
+        ProfScope ps(a, PROF_GEMM_FWD);
+        hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
+        ProfScope ps(a, PROF_DW);
+        Launch La = build_dw_half(a, false, built.sXP, nullptr);
+        AdamFuse Fa = adam_fuse(a);
+        Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
+        if (gc->polyak_after) fold_polyak(a, Fa);
+        Fa.reset_sync = a->k1_sync;   // workgroup 0 clears the hand-off counters for the next launch
+        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g, Fa);
+        HP_CHECK_HIP(hipGetLastError());
+    }
+    return HP_OK;
+}
+
+// target chains of the sequence's first update (its plan: gc->plan) -> Q' set 0; also clears the hand-off counters
+int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
+    HP_REQUIRE(gc && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine");
+    FbBuilt built;
+    GatherCtx g0 = *gc;
+    g0.pregathered = false;
+    g0.next_plan = nullptr;
+    g0.rng = nullptr;
+    build_fb_args(a, &g0, built);
+    FbSlabArgs &P = built.P;
+    static s8r4::FbSplitArgs Qz;
+    s8r4::FbSplitArgs Q = Qz;
+    P.n_plan = P.n_ahead = P.xcd_split = P.n_pref = 0;
+    P.ahead = P.f.gs;
+    P.aXT = P.aXA = P.aXP = nullptr;
+    Q.tgs = P.f.gs;
+    Q.tgs.plan = gc->plan;
+    Q.tgs.plan_any = gc->plan;
+    Q.tgs.R = nullptr;
+    Q.qt_in = a->QT2;
+    Q.qt_out = a->QT;
+    split_common(a, Q);
+    Q.need_c = 0u;
+    Q.reset_sync = 1;
+    Q.adam = adam_fuse(a);
+    Q.s = P;
+    const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
+    ProfScope ps(a, PROF_GEMM_FWD);
+    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
 static AdamFuse adam_fuse(hp_agent *a) {
     AdamFuse F;
     F.p = a->params; F.p_out = a->params; F.m = a->adam_m; F.v = a->adam_v; F.fragF = a->fragF; F.fragD = a->fragD;
     F.grads_base = a->grads; F.st = a->d_state; F.scal = &a->d_state->neg_step_actor; F.am = arena_map(a); F.n_actor = a->la.total;
     F.keep_grads = 1;
     F.tgt = nullptr; F.fragFT = nullptr; F.polyak = 0.f; F.one_minus = 0.f;
+    F.gate = nullptr; F.gate_need = 0u; F.gate_sel = 0u; F.fault = nullptr; F.fault_host = nullptr; F.gate_ticks = 0ull; F.reset_sync = nullptr; F.tl_mark = 0;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : S32_ROWS); F.B = a->B;
@@ -961,6 +1192,20 @@ int hp_agent_debug_timeline(hp_agent *a, uint64_t *out192) {
 int hp_debug_gemm_wg_timeline(uint64_t *out4096) {
     HP_CHECK_HIP(hipDeviceSynchronize());
     HP_CHECK_HIP(hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_gemm_tl_wg), 512 * 8 * 8));
+    return HP_OK;
+}
+// every workgroup of the last k_fb_split8 launch: out[5 * b + 0..3] = {start, hand-off point, gate reached (tiles), end}, [4] = role
+int hp_debug_split_timeline(uint64_t *out5120) {
+    HP_CHECK_HIP(hipDeviceSynchronize());
+    static unsigned long long tl[1024][4], gate[1024][2];
+    static int role[1024];
+    HP_CHECK_HIP(hipMemcpyFromSymbol(tl, HIP_SYMBOL(s8r4::g_split_tl), sizeof(tl)));
+    HP_CHECK_HIP(hipMemcpyFromSymbol(gate, HIP_SYMBOL(g_split_tl_gate), sizeof(gate)));
+    HP_CHECK_HIP(hipMemcpyFromSymbol(role, HIP_SYMBOL(s8r4::g_split_role), sizeof(role)));
+    for (int b = 0; b < 1024; ++b) {
+        out5120[5 * b + 0] = tl[b][0]; out5120[5 * b + 1] = tl[b][1]; out5120[5 * b + 2] = gate[b][0]; out5120[5 * b + 3] = tl[b][3];
+        out5120[5 * b + 4] = (uint64_t)role[b] | (gate[b][1] << 8);   // role | gate passed << 8 (the stamps are < 2^56)
+    }
     return HP_OK;
 }
 int hp_debug_gemm_blk_timeline(uint64_t *out512) {   // [wave][block]{landed, issued} of one workgroup's product loop

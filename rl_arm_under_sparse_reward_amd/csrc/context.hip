@@ -19,6 +19,41 @@ __global__ void k_floor_probe(int *p) {
     if (threadIdx.x == 0) p[0] += 1;
 }
 
+// calibration probes (hp_ctx_calibrate): the two per-CU rates the update's chain kernel lives on
+// (a) one workgroup streams a 256 KiB block (one 256 x 256 layer's weights) through LDS-DMA, `passes` times: 8 waves x 32 blocks
+//     of 1 KiB, eight in flight per wave.  out[0] = wall-clock ticks (100 MHz)
+__global__ __launch_bounds__(512) void k_cal_stream(const float *src, int passes, unsigned long long *out, float *sink) {
+    __shared__ __attribute__((aligned(16))) float ring[8][8][256];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const float4 *base = reinterpret_cast<const float4 *>(src) + (size_t)wave * 32 * 64 + lane;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    for (int p = 0; p < passes; ++p) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) __builtin_amdgcn_global_load_lds(base + (8 * g + b) * 64, &ring[wave][b][0], 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = wall_clock64() - t0;
+    if (ring[wave][lane & 7][lane] == 1.2345e-30f) sink[0] = 1.f;
+}
+// (b) one wave, a dependent chain of v_mfma_f32_4x4x1_16b_f32: out[1] = shader cycles for n of them
+typedef float cal_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_cal_mfma(int n8, unsigned long long *out, float *sink) {
+    cal_f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const float a = (float)(threadIdx.x & 3), b = 1.0f;
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < n8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+    }
+    if (c[0] == 1.2345e-30f) sink[0] = c[1];
+    if (threadIdx.x == 0) out[1] = __builtin_readcyclecounter() - c0;
+}
+
 void hp_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -187,6 +222,33 @@ int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz) {
     (void)hipFree(d);
     *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return HP_OK;
+}
+
+// diagnostic: ~200 us of probes that characterise the box (rlarm_hip_debug.h)
+int hp_ctx_calibrate(hp_ctx *ctx, double *out4) {
+    HP_REQUIRE(ctx && out4, HP_ERR_INVALID, "hp_ctx_calibrate: bad argument");
+    hipStream_t s = ctx->stream;
+    HP_TRY(hp_ctx_launch_floor(ctx, 200, 1, &out4[0]));
+    float *src = nullptr, *sink = nullptr;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    const int passes = 16, n8 = 512;
+    HP_CHECK_HIP(hipMalloc((void **)&src, 256 * 1024));
+    HP_CHECK_HIP(hipMalloc((void **)&sink, 16));
+    HP_CHECK_HIP(hipMalloc((void **)&d, 16));
+    HP_CHECK_HIP(hipMemsetAsync(src, 0, 256 * 1024, s));
+    for (int rep = 0; rep < 2; ++rep) {   // the second run finds the block in L2 and the code in the instruction cache
+        hipLaunchKernelGGL(k_cal_stream, dim3(1), dim3(512), 0, s, src, passes, d, sink);
+        hipLaunchKernelGGL(k_cal_mfma, dim3(1), dim3(64), 0, s, n8, d, sink);
+    }
+    HP_CHECK_HIP(hipGetLastError());
+    HP_CHECK_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    (void)hipFree(src);
+    (void)hipFree(sink);
+    (void)hipFree(d);
+    out4[1] = h[0] ? (double)passes * 256.0 * 1024.0 / ((double)h[0] * 10.0) : 0.0;   // bytes per ns = GB/s (a tick is 10 ns)
+    out4[2] = (double)h[1] / (8.0 * n8);
+    return hp_ctx_clock_mhz(ctx, &out4[3]);
 }
 
 void hp_ctx_destroy(hp_ctx *ctx) {

@@ -52,6 +52,7 @@ struct OpenArgs {
     // hand-off
     unsigned *sync;               // [0] slots ready, [1] normalizer plan ready, [2] workgroups that have left
     AgentDevState *dev;
+    unsigned *fault, *fault_host; // the agent's sticky fault word and its pinned host mirror (agent.h: handoff_fault)
 };
 
 __device__ __forceinline__ void open_publish(unsigned *flag) {
@@ -60,14 +61,22 @@ __device__ __forceinline__ void open_publish(unsigned *flag) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void open_wait(unsigned *flag, AgentDevState *dev) {
+// false (to every thread of the workgroup): the poll gave up -- the caller must NOT consume what it waited for (slots or plan
+// that are not ready would corrupt the replay buffer / the normalizer silently); the fault word makes the next host call fail
+__device__ __forceinline__ bool open_wait(unsigned *flag, const OpenArgs &A) {
+    __shared__ int s_open_ok;
     if (threadIdx.x == 0) {
         int spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(2);
-        if (spins >= (1 << 22)) atomicAdd(&dev->open_timeouts, 1u);
+        if (spins >= (1 << 22)) {
+            atomicAdd(&A.dev->open_timeouts, 1u);
+            handoff_fault(A.fault, A.fault_host, 3u);
+        }
+        s_open_ok = spins < (1 << 22) ? 1 : 0;
     }
     __syncthreads();
+    return s_open_ok != 0;
 }
 
 __device__ __forceinline__ void open_leave(unsigned *sync) {   // thread 0 of every workgroup, as its last act
@@ -102,14 +111,14 @@ __global__ __launch_bounds__(OPEN_THREADS) void k_cycle_open(const OpenArgs A) {
             open_leave(A.sync);
         }
     } else if (role == 1) {
-        open_wait(A.sync + 1, A.dev);
-        norm_update_from_plan_body<true>(A.onz, A.gnz, A.norm_plan, (long long)A.T, A.s_obs, A.s_ag, A.s_g, A.T, A.obs_dim,
-                                         A.goal_dim, A.clip_obs, A.recompute, A.o_eps_sq, A.o_std_f32, A.g_eps_sq, A.g_std_f32,
-                                         A.chunk_rows, open_lds);
+        if (open_wait(A.sync + 1, A))
+            norm_update_from_plan_body<true>(A.onz, A.gnz, A.norm_plan, (long long)A.T, A.s_obs, A.s_ag, A.s_g, A.T, A.obs_dim,
+                                             A.goal_dim, A.clip_obs, A.recompute, A.o_eps_sq, A.o_std_f32, A.g_eps_sq, A.g_std_f32,
+                                             A.chunk_rows, open_lds);
         if (threadIdx.x == 0) open_leave(A.sync);
     } else {
-        open_wait(A.sync + 0, A.dev);
         const int w = role - 2;
+        if (open_wait(A.sync + 0, A))
         store_scatter_share([&](long long j) { return __hip_atomic_load(A.slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
                             w / OPEN_PARTS, w % OPEN_PARTS, OPEN_PARTS, A.inc, A.s_obs, A.s_ag, A.s_g, A.s_act, A.obs, A.ag, A.g,
                             A.act, A.ep_obs, A.ep_ag, A.ep_g, A.ep_act);
@@ -163,6 +172,8 @@ int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rn
     A.chunk_rows = norm_plan_chunk(b->obs_dim, b->goal_dim, b->T, &norm_bytes);
     A.sync = a->open_sync;
     A.dev = a->d_state;
+    A.fault = a->k1_sync + SPLIT_FAULT;
+    A.fault_host = a->fault_host_dev;
     const size_t mt_bytes = 4 * MT_N * sizeof(uint32_t) + MT_IBUF * sizeof(int);
     const size_t lds = norm_bytes > mt_bytes ? norm_bytes : mt_bytes;
     hipLaunchKernelGGL(k_cycle_open, dim3((unsigned)(2 + OPEN_PARTS * b->staged_n)), dim3(OPEN_THREADS), lds, a->ctx->stream, A);

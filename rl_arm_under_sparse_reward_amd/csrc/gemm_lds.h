@@ -34,6 +34,7 @@
 #define GL_OPERAND_FLOATS (GL_KC * GL_KMAJ_LD)  // 9216 floats = larger of the two images (rowK: 32*260 = 8320)
 
 #ifdef SLAB_TIMELINE   // debug build: first and last workgroup stamp the 100 MHz wall clock at stage boundaries
+__device__ unsigned long long g_split_tl_gate[1024][2];   // in-launch tiles of k_fb_split8: {products done: about to wait at the gate, gate passed}
 __device__ unsigned long long g_gemm_tl[32];
 __device__ unsigned long long g_gemm_tl_blk[8][32][2];   // workgroup GL_BLK_WG's product loop: [wave][block]{operands landed, MFMAs issued}
 #ifndef GL_BLK_WG
@@ -97,9 +98,15 @@ __device__ __forceinline__ float4 gl_frag(const float *lds, bool rowk, int frag,
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 // one LDS-DMA wave instruction (64 lanes x 16 B -> 1 KB at dst)
+// SC1: agent-scope load -- the operands were written (write-through) by workgroups of the SAME launch on other XCDs
+// (k_fb_split8's in-launch weight-gradient tiles), so they must not be served from this XCD's L2
+template <bool SC1 = false>
 __device__ __forceinline__ void gl_dma(float *dst, const float *src) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+    if constexpr (SC1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(src) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -134,15 +141,25 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 #define GL_LDS_FLOATS (2 * GL_OPERAND_FLOATS)
 // UNI: the wave index lives in a scalar register, so the ring loop below gets scalar branches instead of exec-mask ones
 // (GemmGroup::uni, set for reductions of at most 640 rows: see the note at `wave` below).
-template <bool ADAM, bool UNI = false>
-__device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F, int bx, float *lds, float (*bsum)[32],
+// SC1 (k_fb_split8 only): the tile runs inside the launch that produces its operands -- agent-scope operand loads, and the
+// optimizer epilogue waits at AdamFuse::gate (the chains of that launch that still read the parameters it is about to step).
+template <bool ADAM, bool UNI = false, bool SC1 = false>
+__device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F_arg, int bx, float *lds, float (*bsum)[32],
                                           bool finalize_loss) {
+    AdamFuse F_pinned;
+    const AdamFuse *F = F_arg;
+    if constexpr (ADAM && SC1) {   // (agent_device.h: adam_pinned)
+        F_pinned = adam_pinned(*F_arg);
+        F = &F_pinned;
+    }
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_PROBS; ++i)
         if (i < grp.n && bx >= grp.p[i].tile0) pi = i;
-    const bool placed = grp.xcd && bx < 256;   // Launch::place_on_xcds
+    const bool placed = grp.xcd == 1 && bx < 256;   // Launch::place_on_xcds: four 256 x 256 problems, one pair of XCDs each
+    const bool placed2 = grp.xcd == 2 && bx < 128;  // ... two of them (actor-only launch behind k_fb_split8): four XCDs each
     if (placed) pi = (bx & 7) >> 1;
+    if (placed2) pi = (bx & 7) >> 2;
     const GemmProb &p = grp.p[pi];
     int t = bx - p.tile0, slice = 0;
     if (p.ks > 1) {   // slice-major: the slices of a tile are a whole problem apart in the launch order
@@ -156,6 +173,11 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         tm = (bx & 1) * 4 + (slot >> 3);
         tn = slot & 7;
     }
+    if (placed2) {  // XCD x = bx & 7: problem x / 4, row-panel quarter x % 4, all 8 column panels
+        const int slot = bx >> 3;
+        tm = (bx & 3) * 2 + (slot >> 3);
+        tn = slot & 7;
+    }
     const int m0 = tm * 32, n0 = tn * 32;
     // How the wave index is held decides how the two waves of a SIMD fall into step in the ring loop below, and the better form
     // depends on the length of the reduction (us/update, same box, three alternating runs each; bit-identical results):
@@ -164,6 +186,8 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     const int tid = threadIdx.x, wave = UNI ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
     if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
+    if (ADAM && finalize_loss && tid >= 64 && tid < 64 + SPLIT_COUNTERS * 8 && F->reset_sync)   // (the launch in front of this one has ended: nobody counts now)
+        __hip_atomic_store(F->reset_sync + (tid - 64) * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
     float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
@@ -186,7 +210,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     AdamState4 ast;
     const bool adam_vec = ADAM && etile && (en + 3 < p.n_store);
     if (ADAM) {
-        if (adam_vec) adam_fetch4(ast, *F, (int)(p.C - F->grads_base) + em * p.ldc + en);
+        if (adam_vec) adam_fetch4<SC1>(ast, *F, (int)(p.C - F->grads_base) + em * p.ldc + en);
     }
     f32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
     float as0 = 0.f, as1 = 0.f;
@@ -218,14 +242,14 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         const long long stepA = 64LL * p.a_sk, stepB = 64LL * p.b_sk;
         const int nblk = k_len > 8 * wave ? (k_len - 8 * wave + 63) >> 6 : 0;   // K is a multiple of 8
         for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) {
-            gl_dma(ring + (i2 & 3) * 512, srcA + i2 * stepA);
-            gl_dma(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
+            gl_dma<SC1>(ring + (i2 & 3) * 512, srcA + i2 * stepA);
+            gl_dma<SC1>(ring + (i2 & 3) * 512 + 256, srcB + i2 * stepB);
         }
         for (int i2 = 0; i2 < nblk; ++i2) {
             const int ahead = i2 + 3;
             if (ahead < nblk) {   // into the slot of block i2 - 1, whose operands the MFMAs of the previous turn have consumed
-                gl_dma(ring + (ahead & 3) * 512, srcA + ahead * stepA);
-                gl_dma(ring + (ahead & 3) * 512 + 256, srcB + ahead * stepB);
+                gl_dma<SC1>(ring + (ahead & 3) * 512, srcA + ahead * stepA);
+                gl_dma<SC1>(ring + (ahead & 3) * 512 + 256, srcB + ahead * stepB);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 const int rem = nblk - 1 - i2;
@@ -339,9 +363,19 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
             }
         }
     }
+    if constexpr (ADAM && SC1) {
+        // the chains of this launch that still read the parameters stepped below (AdamFuse::gate) must be past them
+#ifdef SLAB_TIMELINE
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && F->tl_mark) g_split_tl_gate[blockIdx.x][0] = wall_clock64();
+#endif
+        if (!adam_gate_wait(*F, pi, reinterpret_cast<int *>(&bsum[0][0]))) return;
+#ifdef SLAB_TIMELINE
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && F->tl_mark) g_split_tl_gate[blockIdx.x][1] = wall_clock64();
+#endif
+    }
     if (want_bias_grad && tid < vm) {
-        p.bias_grad[m0 + tid] = sb;
-        if (ADAM) adam_apply(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, sb);
+        if (!SC1 || !ADAM || F->keep_grads) p.bias_grad[m0 + tid] = sb;
+        if (ADAM) adam_apply<SC1>(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, sb);
     }
     if (!etile) return;
     switch (p.epi) {
@@ -387,7 +421,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (en + j < p.n_store) adam_apply(*F, base + j, v[j]);
+                if (en + j < p.n_store) adam_apply<SC1>(*F, base + j, v[j]);
         }
     }
     GL_STAMP(5);

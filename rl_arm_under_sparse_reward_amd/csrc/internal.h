@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rlarm_hip.h"
+#include "rlarm_hip_debug.h"
 
 // ------------------------------------------------------------------ error plumbing
 void hp_set_error(const char *fmt, ...);

@@ -602,12 +602,10 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
 // L2 warmer `widx` (of P.n_pref: a multiple of 8, the same number on every XCD) of this workgroup's XCD: touches the weight
 // fragments the XCD's chains will stream, in the order they use them, one dword per 128-byte line, so that the chains find them
 // in their L2 instead of behind the fabric
-__device__ __forceinline__ void s8_l2_warm(const FbSlabArgs &P, int widx, float *sink) {
+// side: 0 = the sets of the critic-side chains, 1 = of the actor-side chains, 2 = all; per / mine: warmers on this XCD, my index
+__device__ __forceinline__ void s8_l2_warm_at(const FbSlabArgs &P, int side, int per, int mine, float *sink) {
     const FwdSlabArgs &A = P.f;
     const int tid = threadIdx.x;
-    // L2 warmer of this workgroup's XCD: touches the weight fragments the XCD's chains will stream, in the order
-    // they use them, one dword per 128-byte line, so that the chains find them in their L2 instead of behind the fabric
-    const int side = P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2;
     const int na = A.la.total, nall = na + A.lc.total;
     const float *r0 = side == 1 ? A.online.wf : A.target.wf;
     const int n0 = nall;
@@ -617,7 +615,6 @@ __device__ __forceinline__ void s8_l2_warm(const FbSlabArgs &P, int widx, float 
     const int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
     const float *rs[3] = {r0, r1, r2};
     const int ns[3] = {n0, n1, n2};
-    const int per = P.n_pref >> 3, mine = widx >> 3;   // warmers per XCD, my index
     float acc = 0.f;
     if (tid < 256) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
         const int grp = tid >> 6, i = tid & 63;
@@ -646,6 +643,11 @@ __device__ __forceinline__ void s8_l2_warm(const FbSlabArgs &P, int widx, float 
         for (; off < ns[r]; off += step) acc += rs[r][off];
     }
     if (acc == 1.2345678e-33f) sink[0] = acc;   // keeps the loads; never true in practice, harmless if it is
+}
+__device__ __forceinline__ void s8_l2_warm(const FbSlabArgs &P, int widx, float *sink) {
+    // L2 warmer of this workgroup's XCD (workgroups are dealt round-robin to the XCDs): touches the weight fragments the XCD's
+    // chains will stream, in the order they use them, one dword per 128-byte line
+    s8_l2_warm_at(P, P.xcd_split ? (int)((blockIdx.x & 7) >> 2) : 2, P.n_pref >> 3, widx >> 3, sink);
 }
 
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_slab8(const FbSlabArgs P) {
@@ -836,157 +838,13 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 22);
     } else {
     // ---------------------------------------------------------------------- actor side
-    s8_ring_prologue<0, S8_PRO_FIRST>(ring, rbase, on.wf + la.w2);   // (as on the critic side: -0.4 us/update at batch 1024, neutral at 256)
-    const PlanRec rec = s8_plan_rec(A.gs, row0);
-    float4 wba[6], wbc[6], wh[4], wq[4], wb4[6];
-    float w1n[4];
-    s8_small_prefetch(on.wf + la.w1, la.K1, wba);
-#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
-    float ebP[3] = {0.f, 0.f, 0.f}, ebQ[3] = {0.f, 0.f, 0.f};   // biases of the actor trunk and of the critic trunk behind it
-    const int ecol_ = 64 * (wave & 3) + lane;
-    const bool ekh0_ = wave < 4;
-    if (ekh0_) ebP[0] = on.canon[la.b1 + ecol_];
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // (as on the critic side: what the first layer does not need follows the input loads)
-    if (A.gs.plan) s8_gather(xin, A.gs, rec, 2, row0, A.ldx, A.act_off, ad, A.max_action, A.XP);
-    else s8_load(xin, S8_LDX, A.ldx, A.XP + row0 * A.ldx, A.ldx);
-    s8_ring_prologue<S8_PRO_FIRST, S8_RING>(ring, rbase, on.wf + la.w2);
-    __builtin_amdgcn_sched_barrier(0);
-    s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        wh[j] = *reinterpret_cast<const float4 *>(on.canon + la.w4 + (j < ad ? j : ad - 1) * H + 4 * lane);
-    wq[0] = *reinterpret_cast<const float4 *>(on.canon + ca + lc.w4 + 4 * lane);
-    const float bh = on.canon[la.b4 + (lane < ad ? lane : 0)];
-    const float bq = on.canon[ca + lc.b4];
-    const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
-    {
-        const float *w1 = on.canon + ca + lc.w1 + (size_t)(tid & 255) * lc.K1 + A.act_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1n[j] = w1[j < ad ? j : ad - 1];
-    }
-    s8_small_prefetch(on.wd + la.w4, 16, wb4);
-#if S8_NRG == 1   // 4-row slabs: -0.4 us/update at batch 256, -0.2 at 512 k8 (8 rows: +0.2 at 1024, not taken there)
-    if (ekh0_) {
-        ebP[1] = on.canon[la.b2 + ecol_]; ebP[2] = on.canon[la.b3 + ecol_];
-        ebQ[0] = on.canon[ca + lc.b1 + ecol_]; ebQ[1] = on.canon[ca + lc.b2 + ecol_]; ebQ[2] = on.canon[ca + lc.b3 + ecol_];
-    }
-    const float *pP = ebP, *pQ = ebQ;
-#else
-    const float *pP = nullptr, *pQ = nullptr;
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    s8_sync();
-    s8_trunk(xin, la, wba, on.wf, on.canon, H, bufA, bufB, pbuf, A.APh1, A.APh2, A.APh3, row0, ring, rbase, on.wf + ca + lc.w2,
-             tl, 1, msk[2], msk[3], msk[4], pP);
-    S8_TSTAMP(tl, 5);
-    float u_mine[S8_RPW], th_mine[S8_RPW];
-#pragma unroll
-    for (int i = 0; i < S8_RPW; ++i) {   // actor head: tanh -> action block of the critic input (models.py:24, :38); lane j owns output j
-        const int rr = wave + S8_WAVES * i;
-        u_mine[i] = th_mine[i] = 0.f;
-        const float z = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, wh);
-        if (lane < ad && rr < S8_ROWS) {
-            th_mine[i] = tanhf(z + bh);
-            u_mine[i] = (A.max_action * th_mine[i]) / A.max_action;
-            xin[rr * S8_LDX + A.act_off + lane] = u_mine[i];
-            A.XP[(row0 + rr) * A.ldx + A.act_off + lane] = u_mine[i];
-            A.TP[(row0 + rr) * 16 + lane] = th_mine[i];
-        }
-    }
-    S8_TSTAMP(tl, 6);
-    s8_sync();
-    S8_TSTAMP(tl, 7);
-    s8_trunk(xin, lc, wbc, on.wf + ca, on.canon + ca, H, bufA, bufB, pbuf, nullptr, nullptr, nullptr, row0, ring, rbase,
-             on.wd + ca + lc.w3, tl, 8, msk[0], msk[1], nullptr, pQ);
-    {
-#pragma unroll
-        for (int i = 0; i < S8_RPW; ++i) {
-            const int rr = wave + S8_WAVES * i;
-            const float q = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, 1, wq);
-            if (lane == 0 && rr < S8_ROWS) {
-                rows[1][rr] = q + bq;
-                A.QP[(row0 + rr) * 16] = q + bq;
-            }
-        }
-    }
-    if (tid < 256) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1t[j * 256 + tid] = w1n[j];
-    }
-    s8_sync();
-    S8_TSTAMP(tl, 13);
-    // ---- actor loss (ddpg_agent.py:265-267)
-    float keep_q = 0.f, keep_u = 0.f;
-    if (tid < S8_ROWS) {
-        const size_t m = row0 + tid;
-        const bool live = (int)m < Bk.B;
-        dq[tid] = live ? -invB : 0.f;
-        float sq = live ? rows[1][tid] : 0.f, su = 0.f;
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < ad) {
-                    const float u = xin[tid * S8_LDX + A.act_off + j];
-                    su += u * u;
-                }
-        }
-        for (int o = S8_ROWS / 2; o > 0; o >>= 1) {
-            sq += __shfl_down(sq, o, S8_ROWS);
-            su += __shfl_down(su, o, S8_ROWS);
-        }
-        keep_q = sq;
-        keep_u = su;
-    }
-    s8_sync();
-    s8_head_bwd_inplace(dq, w4c, bufA);   // bufA holds h3 of critic(x, pi(x))
-    s8_sync();
-    S8_TSTAMP(tl, 14);
-    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + ca + lc.w3, on.wd + ca + lc.w2, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[1]);
-    s8_sync();
-    S8_TSTAMP(tl, 15);
-    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + ca + lc.w2, on.wd + la.w3, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[0]);
-    s8_sync();
-    S8_TSTAMP(tl, 16);
-    {   // d L / d(action block of the critic input), then through the L2 penalty and tanh; lane j owns action j
-        float4 w1g[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1g[j] = *reinterpret_cast<const float4 *>(w1t + j * 256 + 4 * lane);
-#pragma unroll
-        for (int i = 0; i < S8_RPW; ++i) {
-            const int rr = wave + S8_WAVES * i;
-            const float sj = s8_rowdots(bufA, S8_LD, rr < S8_ROWS ? rr : 0, ad, w1g);
-            if (lane < 16 && rr < S8_ROWS) {
-                const size_t m = row0 + rr;
-                float v = 0.f;
-                if (lane < ad && (int)m < Bk.B) {
-                    const float gu = Bk.action_l2 * (2.f * u_mine[i] / (float)(Bk.B * ad)) + sj;
-                    const float gt = (gu / A.max_action) * A.max_action;
-                    v = gt * (1.f - th_mine[i] * th_mine[i]);
-                }
-                dz[rr * 20 + lane] = v;
-                wt_store(Bk.dZ + m * 16 + lane, v);
-            }
-        }
-    }
-    s8_sync();
-    S8_TSTAMP(tl, 17);
-    s8_small_layer(dz, 20, 16, wb4, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[4], nullptr, Bk.dK3 + row0 * H);
-    s8_sync();
-    S8_TSTAMP(tl, 18);
-    s8_big_layer(bufB, S8_LD, ring, rbase, on.wd + la.w3, on.wd + la.w2, SE_MASK, nullptr, 0, pbuf, bufA, S8_LD, msk[3], nullptr,
-                 nullptr, 0, Bk.dK2 + row0 * H);
-    s8_sync();
-    S8_TSTAMP(tl, 19);
-    s8_big_layer(bufA, S8_LD, ring, rbase, on.wd + la.w2, nullptr, SE_MASK, nullptr, 0, pbuf, bufB, S8_LD, msk[2], nullptr,
-                 nullptr, 0, Bk.dK1 + row0 * H);
-    s8_sync();
-    S8_TSTAMP(tl, 20);
-    if (tid == 0) {
-        wt_store(Bk.part + nslab + slab, keep_q);
-        wt_store(Bk.part + 2 * nslab + slab, keep_u);
-    }
-    S8_TSTAMP(tl, 21);
+#define S8_AFTER_CRITIC_FWD do { } while (0)
+#define S8_AFTER_CRITIC_DX1 do { } while (0)
+#define S8_AFTER_CRITIC_DX do { } while (0)
+#include "slab8_actor_side.inc"
+#undef S8_AFTER_CRITIC_FWD
+#undef S8_AFTER_CRITIC_DX1
+#undef S8_AFTER_CRITIC_DX
     }
     }
 }
@@ -1044,6 +902,10 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             P.actions[(row0 + rr) * ad + lane] = P.max_action * tanhf(z + bh);
     }
 }
+#endif
+
+#if S8_NRG == 1
+#include "slab8_split.h"
 #endif
 
 }  // namespace S8_NS

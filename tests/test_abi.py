@@ -10,13 +10,19 @@ import pytest
 from conftest import REPO
 
 HEADER = os.path.join(REPO, "include", "rlarm_hip.h")
+DEBUG_HEADER = os.path.join(REPO, "include", "rlarm_hip_debug.h")
 PKG = os.path.join(REPO, "rl_arm_under_sparse_reward_amd")
 
 
-def header_symbols():
-    txt = open(HEADER).read()
+def _symbols(path):
+    txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(hp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def header_symbols():
+    """stable surface + diagnostics: everything the library must export"""
+    return sorted(set(_symbols(HEADER)) | set(_symbols(DEBUG_HEADER)))
 
 
 def test_library_exports_every_header_symbol():
@@ -34,6 +40,20 @@ def test_library_exports_every_header_symbol():
 def test_ctypes_table_matches_header():
     from rl_arm_under_sparse_reward_amd import _lib
     assert sorted(_lib.PROTOTYPES) == header_symbols()
+
+
+def test_stable_and_diagnostic_surfaces_are_separate():
+    """HP_ABI_VERSION names the stable header only: diagnostics and test hooks live in rlarm_hip_debug.h, and the version the
+    Python binding checks is the header's."""
+    from rl_arm_under_sparse_reward_amd import _lib
+    stable, debug = set(_symbols(HEADER)), set(_symbols(DEBUG_HEADER))
+    assert not (stable & debug), stable & debug
+    assert debug == _lib.DEBUG_SYMBOLS
+    assert not [s for s in stable if "debug" in s or s in ("hp_agent_set_adam", "hp_ctx_launch_floor")]
+    version = int(re.search(r"#define\s+HP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert version == _lib.ABI_VERSION == 2
+    if os.path.exists(os.path.join(PKG, "librlarm_hip.so")):
+        assert ctypes.CDLL(os.path.join(PKG, "librlarm_hip.so")).hp_abi_version() == version
 
 
 def test_no_device_fails_loudly_not_silently():

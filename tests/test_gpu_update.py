@@ -478,7 +478,12 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           # loop-control form of the weight-gradient tiles; optimizer stores plain / write-through
                                           ("RLARM_CYCLE_OPEN=0", 256), ("RLARM_CYCLE_OPEN=0", 1024), ("RLARM_GEMM_UNI=1", 256),
                                           ("RLARM_GEMM_UNI=0", 512), ("RLARM_GEMM_UNI=1", 1024), ("RLARM_ADAM_WT=0", 256),
-                                          ("RLARM_ADAM_WT=1", 1024), ("RLARM_ADAM_WT=1", 3072)])
+                                          ("RLARM_ADAM_WT=1", 1024), ("RLARM_ADAM_WT=1", 3072),
+                                          # round 4: the split launch (target chains one update ahead, critic tiles + optimizer
+                                          # inside the chain launch; default where it fits) against the two-launch form, its other
+                                          # placement, and forced on for the single-update tail of a sequence
+                                          ("RLARM_SPLIT=0", 256), ("RLARM_SPLIT=0", 128), ("RLARM_SPLIT=0", 288), ("RLARM_SPLIT=0", 64),
+                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1", 256)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
@@ -492,6 +497,36 @@ def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     got = _run_cycles(agent, graph=True)
     for a, b in zip(want, got):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+@pytest.mark.parametrize("batch,n_updates", [(256, 40), (256, 7), (320, 5), (100, 40)])
+def test_split_launch_is_bit_identical(batch, n_updates, monkeypatch):
+    """slab8_split.h against k_fb_slab8 + k_gemm_lds_adam over whole cycles (40 updates each, polyak folded into the last
+    optimizer epilogues) and over `_update_network(n)` sequences of odd / short length: same device functions, same operands,
+    same summation order -> the same bits in parameters, targets, optimizer state, losses and random stream."""
+    def run():
+        torch.manual_seed(0)
+        agent, rng = make_agent(batch=batch, n_eps=32, seed=21)
+        agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
+        for c in range(4):
+            agent.train_cycle(make_episodes(2, seed=300 + c, mode="walk"), n_updates)
+        agent._update_network(n_updates)
+        agent._update_network(n_updates + 1)
+        st = rng.get_state()
+        ma, va, sa = agent.get_adam_state(NET_ACTOR)
+        mc, vc, sc = agent.get_adam_state(NET_CRITIC)
+        return (agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent._get_flat(NET_ACTOR_TARGET),
+                agent._get_flat(NET_CRITIC_TARGET), ma, va, mc, vc, np.asarray([sa, sc]),
+                agent.last_losses(6 * n_updates + 1), np.asarray(st[1]), np.asarray([st[2]]))
+    monkeypatch.setenv("RLARM_SPLIT", "0")
+    want = run()
+    monkeypatch.delenv("RLARM_SPLIT")
+    got = run()
+    monkeypatch.setenv("RLARM_SPLIT", "1")
+    forced = run()
+    for other in (got, forced):
+        for a, b in zip(want, other):
+            assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
 
 @pytest.mark.parametrize("batch", [256, 1024, 2048, 3072])
