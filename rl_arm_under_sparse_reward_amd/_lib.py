@@ -159,9 +159,16 @@ _lock = threading.Lock()
 # is a graph of its own that draws its index plan in a launch in front and gathers its minibatch inside the chain kernel: 51 us
 # per update at batch 256.  The mirror therefore only COUNTS argument-less `_update_network()` calls and issues them together --
 # one hp_agent_sample_and_update(n): 40.5 us per update -- as soon as anything else touches the library: every entry point goes
-# through the proxy below, which first issues what is pending.  Nothing can observe the difference except a clock: parameters,
-# losses, the random stream and the buffer are only reachable through library calls, and n updates in one call are bit for bit
-# n calls of one update (tests/test_gpu_update.py).  RLARM_DEFER_UPDATES=0 switches it off.
+# through the proxy below, which first issues what is pending.  n updates in one call are bit for bit n calls of one update
+# (tests/test_gpu_update.py).  RLARM_DEFER_UPDATES=0 switches it off.
+#
+# What a caller CAN observe, and must know (tests/test_gpu_update.py::test_deferred_updates_*):
+#   * a zero-copy view of library memory held across calls (`DevicePointer`, e.g. the gradient / parameter arena handed to
+#     torch) shows the state as of the LAST LIBRARY CALL, not as of the last `_update_network()`: touch the library (any entry
+#     point, or `flush_pending()`) before reading such a view;
+#   * an error of a deferred update (an empty buffer: "high <= 0", a dead rank exchange, a hand-off fault) is raised by the call
+#     that triggers the flush, possibly from another thread -- the exception then names the deferred call it belongs to
+#     ("deferred _update_network() x n"); the updates that could not be issued stay pending and are NOT dropped.
 pending_lock = threading.RLock()
 _pending = []            # objects with a `_flush_updates()` method and work outstanding
 _NO_FLUSH = {"hp_last_error", "hp_abi_version"}
@@ -179,13 +186,19 @@ def unregister_pending(obj):
 
 
 def flush_pending():
-    """Issue every deferred update now (called by the library proxy in front of any other entry point)."""
+    """Issue every deferred update now (called by the library proxy in front of any other entry point).  If one object's
+    flush raises, the objects behind it stay registered (their updates are still owed) and the exception carries on."""
     if not _pending:
         return
     with pending_lock:
         todo, _pending[:] = list(_pending), []
-        for o in todo:
-            o._flush_updates()
+        for i, o in enumerate(todo):
+            try:
+                o._flush_updates()
+            except BaseException:
+                for rest in todo[i + 1:]:
+                    register_pending(rest)
+                raise
 
 
 class _Library:

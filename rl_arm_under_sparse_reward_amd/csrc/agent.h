@@ -91,11 +91,14 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
     st->bc2_sqrt = (float)sqrt(bc2);
 }
 
-// hand-off counters of the split launch (slab8_split.h): 6 counters x 8 XCD copies, SPLIT_CTR_STRIDE words apart, then the
-// learner's sticky fault word
+// hand-off counters of the split launch (slab8_split.h): two sets (the launch of update u counts in set u % 2 and clears the
+// other one for its successor) of SPLIT_COUNTERS counters x 8 XCD copies, SPLIT_CTR_STRIDE words apart, then the learner's
+// sticky fault word
 #define SPLIT_CTR_STRIDE 64          // 256 bytes: another memory channel
-#define SPLIT_COUNTERS 6
-#define SPLIT_FAULT (SPLIT_COUNTERS * 8 * SPLIT_CTR_STRIDE)
+#define SPLIT_COUNTERS 8             // 0-2 stages of the critic chains, 3-5 gates of the actor-side chains, 6 actor-side chains done
+#define SPLIT_CTR_NONE 15u           // "no counter" in the 4-bit per-problem tables
+#define SPLIT_SET_WORDS (SPLIT_COUNTERS * 8 * SPLIT_CTR_STRIDE)
+#define SPLIT_FAULT (2 * SPLIT_SET_WORDS)
 #define SPLIT_SYNC_WORDS (SPLIT_FAULT + 4)
 
 // sticky fault word of in-launch hand-offs: bit 0 = a poll gave up, bits 4-7 = which (1 critic chains published, 2 actor
@@ -113,8 +116,14 @@ __device__ __forceinline__ bool handoff_wait(const unsigned *ctr, unsigned need,
     if (threadIdx.x == 0) {
         int ok = 1;
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(12);   // ~0.3 us between polls: many workgroups poll one word
+        // Adaptive poll: while NOBODY has counted yet the producers are microseconds away -- look every ~1.7 us; once the first
+        // count is in, the rest follow within a microsecond or two -- look every ~0.15 us.  (Hundreds of workgroups polling
+        // every 0.3 us slowed the chains they were waiting for by 2 us: each poll is a round trip to the memory side.)
+        for (;;) {
+            const unsigned seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= need) break;
+            if (seen == 0u) __builtin_amdgcn_s_sleep(64);
+            else __builtin_amdgcn_s_sleep(6);
             if (wall_clock64() - t0 > ticks) {
                 handoff_fault(fault, fault_host, which);
                 ok = 0;
@@ -224,6 +233,7 @@ struct hp_agent {
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
     // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
     int split_mode = -1, split_place = 1;
+    int split_one = -1;                  // RLARM_SPLIT_ONE=1: the actor's tiles inside the split launch too (ONE launch per update): built, parity-green, 45.7 vs 39.2 us -- opt-in
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
     unsigned *fault_host_dev = nullptr;
@@ -390,6 +400,8 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     // NEXT update, whose Q' the target chains of this launch compute into the other set (nullptr: last update of the sequence)
     bool split = false;
     int qset = 0;
+    // data-parallel ranks, tile-wise exchange: index of this update in its sequence (the exchange epoch), -1: not this form
+    int peer_u = -1;
     const PlanRec *t_plan = nullptr;
 };
 #define SPLIT_MIN_UPDATES 4   // shorter sequences keep the two-launch form (the target prologue would cost more than it saves)
@@ -423,6 +435,10 @@ int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rn
                       double future_p, bool recompute);
 // utils.sync_grads (utils.py:43-48) + both Adam steps of update u as the peer exchange's optimizer kernel(s) (peer.hip)
 int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after = false);
+// data-parallel ranks: do the weight-gradient tiles exchange by themselves (one launch: gradients + rank exchange + optimizer)?
+static inline bool peer_tiles_ok(const hp_agent *a) {
+    return a->peer && a->peer->tiles && a->peer->phases == 1 && !a->peer->gate && a->slab && !a->dw64 && a->fuse_adam_ok;
+}
 // can the optimizer launches of this agent apply the soft target update themselves?  (slab engines: yes)
 static inline bool polyak_foldable(const hp_agent *a) { return a->slab; }
 // ---- defined in agent_layers.hip

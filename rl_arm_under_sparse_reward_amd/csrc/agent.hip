@@ -164,10 +164,13 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         gc.ride_in_dw = dw_ride;
         const bool last_fold = fold && u == n_updates - 1;
         gc.polyak_after = last_fold;
-        const bool via_peer = with_adam && a->peer != nullptr;
+        const bool peer_tiles = with_adam && peer_tiles_ok(a);
+        const bool via_peer = with_adam && a->peer != nullptr && !peer_tiles;
         if (via_peer) gc.grads_out = peer_grad_buffer(a->peer, u + 1);   // epoch base is even: parity of epoch base + u + 1
+        if (peer_tiles) gc.peer_u = u;   // the weight-gradient tiles exchange and step by themselves (gemm_lds.h PEER)
         bool fused = false;
-        HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm && !a->peer, &fused));
+        HP_TRY(enqueue_forward_backward(a, &gc, with_adam && !a->comm && (!a->peer || peer_tiles), &fused));
+        HP_REQUIRE(!peer_tiles || fused, HP_ERR_STATE, "tile-wise exchange: the engine did not take the fused optimizer path");
         if (via_peer) {
             // utils.sync_grads (utils.py:43-48) + both Adam steps in ONE kernel: every rank reads the peers' gradient
             // vectors over xGMI, sums them in rank order and steps (peer.hip)
@@ -332,6 +335,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
         a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
         a->split_mode = tri("RLARM_SPLIT");
+        a->split_one = tri("RLARM_SPLIT_ONE");
         if (const char *sp = getenv("RLARM_SPLIT_PLACE")) a->split_place = atoi(sp);
         a->gl_uni = tri("RLARM_GEMM_UNI");
         a->adam_wt = tri("RLARM_ADAM_WT");

@@ -39,12 +39,11 @@ struct AdamFuse {
     // tiles that run INSIDE the chain launch (k_fb_split8, slab8_split.h): the step may only be stored once `gate_need` chains
     // of that launch have counted themselves past the parameters it overwrites (*gate, agent scope); a poll that gives up
     // after gate_ticks (100 MHz) skips the step, sets the sticky fault word and its pinned host mirror
-    const unsigned *gate;             // first gate counter, copy of XCD 0; XCD x polls the copy x * SPLIT_CTR_STRIDE words on
+    const unsigned *gate;             // counter 0, copy of XCD 0, of this launch's set; XCD x polls the copy x * SPLIT_CTR_STRIDE words on
     unsigned gate_need;
-    unsigned gate_sel;                // 4 bits per problem of the group: which gate counter (0, 1, 2) its step waits for
+    unsigned gate_sel;                // 4 bits per problem of the group: the counter its step waits for (SPLIT_CTR_NONE: none)
     unsigned *fault, *fault_host;
     unsigned long long gate_ticks;
-    unsigned *reset_sync;             // the launch BEHIND k_fb_split8: its workgroup 0 clears that launch's counters
     int tl_mark;                      // time-line builds: record this launch's gate stamps
 };
 
@@ -80,6 +79,7 @@ __device__ __forceinline__ AdamFuse adam_pinned(const AdamFuse &F) {
 __device__ __forceinline__ bool adam_gate_wait(const AdamFuse &F, int prob, int *flag) {
     if (!F.gate) return true;
     const unsigned which = (F.gate_sel >> (4 * prob)) & 15u;
+    if (which == SPLIT_CTR_NONE) return true;
     return handoff_wait(F.gate + (which * 8 + (blockIdx.x & 7)) * SPLIT_CTR_STRIDE, F.gate_need, F.gate_ticks, F.fault, F.fault_host, 2u,
                         flag);
 }

@@ -109,12 +109,13 @@ struct RideArgs {
     float max_action;
 };
 
-template <bool ADAM, bool UNI = false>
-__device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, int tiles) {
+template <bool ADAM, bool UNI = false, bool PEER = false>
+__device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, int tiles,
+                                               const PeerTile *PT = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
     __shared__ float bsum[GL_WAVES][32];
     if ((int)blockIdx.x < tiles) {
-        gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
+        gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, PT);
         return;
     }
     const int extra = (int)blockIdx.x - tiles;
@@ -144,6 +145,20 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride_u(const GemmGroup 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(const GemmGroup grp, const AdamFuse F, const RideArgs R,
                                                                      int tiles) {
     gemm_ride_body<true, true>(grp, &F, R, tiles);
+}
+
+// data-parallel ranks, tile-wise one-shot exchange (gemm_lds.h PEER): weight gradients + rank exchange + optimizer step in ONE
+// launch, the riders behind the tiles as above.  Replaces k_gemm_lds -> k_peer_adam (its kernel boundary, its second pass over
+// the gradients: +6 us per update at world size 1), and lets early tiles exchange while later ones still multiply.
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer(const GemmGroup grp, const AdamFuse F, const RideArgs R, int tiles,
+                                                                   const PeerDev D, int u, int mean) {
+    const PeerTile PT{&D, u, mean};
+    gemm_ride_body<true, false, true>(grp, &F, R, tiles, &PT);
+}
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer_u(const GemmGroup grp, const AdamFuse F, const RideArgs R, int tiles,
+                                                                     const PeerDev D, int u, int mean) {
+    const PeerTile PT{&D, u, mean};
+    gemm_ride_body<true, true, true>(grp, &F, R, tiles, &PT);
 }
 
 // Large minibatches: 64 x 64 tiles with the batch rows split over workgroups (dw64.h), same riders behind the tiles
@@ -679,6 +694,17 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 hipLaunchKernelGGL(k_dw64, dim3(grid), dim3(DW_THREADS), 0, s, L.g, R, X);
             }
             HP_CHECK_HIP(hipGetLastError());
+        } else if (fuse_adam && gc && gc->peer_u >= 0) {
+            // data-parallel ranks: the tiles exchange by themselves (gemm_lds.h PEER); riders, if any, behind them
+            ProfScope ps(a, PROF_DW);
+            HP_REQUIRE(a->peer && L.tiles <= HP_PEER_TILES, HP_ERR_STATE, "tile-wise exchange: %d tiles exceed the flag rows", L.tiles);
+            const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
+            AdamFuse F = adam_fuse(a);
+            F.keep_grads = a->keep_grads_dbg ? 1 : 0;
+            if (gc->polyak_after) fold_polyak(a, F);
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_peer_u : k_gemm_lds_adam_peer, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R,
+                               L.tiles, a->peer->dev, gc->peer_u, a->grad_mean ? 1 : 0);
+            HP_CHECK_HIP(hipGetLastError());
         } else if (riders) {
             ProfScope ps(a, PROF_DW);
             const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
@@ -707,12 +733,16 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
     return HP_OK;
 }
 
-// ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step), then the actor's tiles
-static void split_common(hp_agent *a, s8r4::FbSplitArgs &Q) {
-    Q.sync = a->k1_sync;
+// ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step [+ the actor's]), then -- in
+// the two-launch form -- the actor's tiles
+static void split_common(hp_agent *a, s8r4::FbSplitArgs &Q, int set) {
+    Q.sync = a->k1_sync + (set & 1) * SPLIT_SET_WORDS;
+    Q.sync_other = a->k1_sync + ((set + 1) & 1) * SPLIT_SET_WORDS;
+    Q.fault = a->k1_sync + SPLIT_FAULT;
     Q.fault_host = a->fault_host_dev;
     Q.wait_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock: three orders of magnitude beyond a launch
 }
+static bool split_one_launch(const hp_agent *a) { return a->split_one == 1; }
 
 static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only) {
     HP_REQUIRE(only == 0 && fuse_adam && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine / call");
@@ -742,44 +772,63 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     Q.tgs.R = nullptr;
     Q.qt_in = gc->qset ? a->QT2 : a->QT;
     Q.qt_out = gc->qset ? a->QT : a->QT2;
-    split_common(a, Q);
-    Launch Lc = build_dw_half(a, true, built.sXA, nullptr);
-    Q.tiles = Lc.g;
-    Q.need_c = (unsigned)nslab;
+    split_common(a, Q, gc->qset);
+    const bool one = split_one_launch(a);
+    // tile problems in the order their operands are published: the critic's W3, W4 (stage 0), W2 (stage 1), W1 (stage 2), then
+    // the actor's (counter 6: every actor-side chain has ended).  Gates of the optimizer steps: W3c after the actor-side chains'
+    // first critic dX layer (counter 4), W4c / W1c after their critic forward (3), W2c after the second dX layer (5); the
+    // actor's parameters are read by the actor-side chains only, which have ended when its tiles start.
+    Launch L = build_dw_half(a, true, built.sXA, nullptr);
     Q.tile_stage = 0u | (0u << 4) | (1u << 8) | (2u << 12);
+    unsigned gate_sel = 4u | (3u << 4) | (5u << 8) | (3u << 12);
+    Q.loss_prob = -1;
+    if (one) {
+        const Launch La = build_dw_half(a, false, built.sXP, nullptr);
+        for (int i = 0; i < La.g.n; ++i) {
+            GemmProb p = La.g.p[i];
+            p.tile0 += L.tiles;
+            L.g.p[L.g.n + i] = p;
+            Q.tile_stage |= 6u << (4 * (L.g.n + i));
+            gate_sel |= SPLIT_CTR_NONE << (4 * (L.g.n + i));
+        }
+        Q.loss_prob = L.g.n;
+        L.g.n += La.g.n;
+        L.tiles += La.tiles;
+    }
+    Q.tiles = L.g;
+    Q.need_c = (unsigned)nslab;
     Q.tl_mark = gc->t_plan != nullptr ? 1 : 0;
     AdamFuse F = adam_fuse(a);
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;
     if (gc->polyak_after) fold_polyak(a, F);
-    F.gate = a->k1_sync + 3 * 8 * SPLIT_CTR_STRIDE;
+    F.gate = Q.sync;
     F.gate_need = (unsigned)nslab;
-    F.gate_sel = 1u | (0u << 4) | (2u << 8) | (0u << 12);   // W3: past the first dX layer, W4: past the forward, W2: past the second dX layer, W1: forward
-    F.fault = a->k1_sync + SPLIT_FAULT;
+    F.gate_sel = gate_sel;
+    F.fault = Q.fault;
     F.fault_host = a->fault_host_dev;
     F.gate_ticks = Q.wait_ticks;
-    F.tl_mark = gc->t_plan != nullptr ? 1 : 0;
+    F.tl_mark = Q.tl_mark;
     Q.adam = F;
     Q.s = P;
-    const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, Lc.tiles);
+    const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
         hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
-    {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
+    if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
         ProfScope ps(a, PROF_DW);
         Launch La = build_dw_half(a, false, built.sXP, nullptr);
         AdamFuse Fa = adam_fuse(a);
         Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
         if (gc->polyak_after) fold_polyak(a, Fa);
-        Fa.reset_sync = a->k1_sync;   // workgroup 0 clears the hand-off counters for the next launch
         hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;
 }
 
-// target chains of the sequence's first update (its plan: gc->plan) -> Q' set 0; also clears the hand-off counters
+// target chains of the sequence's first update (its plan: gc->plan) -> Q' set 0; also clears the first update's counter set
 int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     HP_REQUIRE(gc && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine");
     FbBuilt built;
@@ -800,9 +849,10 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.tgs.R = nullptr;
     Q.qt_in = a->QT2;
     Q.qt_out = a->QT;
-    split_common(a, Q);
+    split_common(a, Q, 1);        // sync_other = set 0, the first update's
     Q.need_c = 0u;
     Q.reset_sync = 1;
+    Q.loss_prob = -1;
     Q.adam = adam_fuse(a);
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
@@ -818,7 +868,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.grads_base = a->grads; F.st = a->d_state; F.scal = &a->d_state->neg_step_actor; F.am = arena_map(a); F.n_actor = a->la.total;
     F.keep_grads = 1;
     F.tgt = nullptr; F.fragFT = nullptr; F.polyak = 0.f; F.one_minus = 0.f;
-    F.gate = nullptr; F.gate_need = 0u; F.gate_sel = 0u; F.fault = nullptr; F.fault_host = nullptr; F.gate_ticks = 0ull; F.reset_sync = nullptr; F.tl_mark = 0;
+    F.gate = nullptr; F.gate_need = 0u; F.gate_sel = 0u; F.fault = nullptr; F.fault_host = nullptr; F.gate_ticks = 0ull; F.tl_mark = 0;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : S32_ROWS); F.B = a->B;

@@ -143,9 +143,16 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 // (GemmGroup::uni, set for reductions of at most 640 rows: see the note at `wave` below).
 // SC1 (k_fb_split8 only): the tile runs inside the launch that produces its operands -- agent-scope operand loads, and the
 // optimizer epilogue waits at AdamFuse::gate (the chains of that launch that still read the parameters it is about to step).
-template <bool ADAM, bool UNI = false, bool SC1 = false>
+// PEER (data-parallel ranks, one-shot form inside this launch): the tile's gradient sums go out through the rank's exchange
+// vector, the workgroup signals its slot of the per-tile flags on every peer, waits for the peers' same tile, adds the
+// ranks' tiles in rank order (utils.sync_grads: SUM, utils.py:43-48) and steps -- no separate exchange + optimizer launch.
+struct PeerTile {
+    const PeerDev *D;
+    int u, mean;
+};
+template <bool ADAM, bool UNI = false, bool SC1 = false, bool PEER = false>
 __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F_arg, int bx, float *lds, float (*bsum)[32],
-                                          bool finalize_loss) {
+                                          bool finalize_loss, const PeerTile *PT = nullptr) {
     AdamFuse F_pinned;
     const AdamFuse *F = F_arg;
     if constexpr (ADAM && SC1) {   // (agent_device.h: adam_pinned)
@@ -186,8 +193,6 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     const int tid = threadIdx.x, wave = UNI ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
     if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
-    if (ADAM && finalize_loss && tid >= 64 && tid < 64 + SPLIT_COUNTERS * 8 && F->reset_sync)   // (the launch in front of this one has ended: nobody counts now)
-        __hip_atomic_store(F->reset_sync + (tid - 64) * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
     float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
@@ -361,6 +366,59 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
                 const float b = __hip_atomic_load(src + 1024 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sb = sl ? sb + b : b;
             }
+        }
+    }
+    if constexpr (ADAM && PEER) {
+        const PeerDev &D = *PT->D;
+        const unsigned long long epoch = D.epoch[0] + (unsigned long long)PT->u + 1ull;
+        const int par = (int)(epoch & 1ull);
+        float *G = D.grad[D.rank][par];                                     // arena layout, like F->grads_base
+        const int gbase = (int)(p.C - F->grads_base) + em * p.ldc + en;    // this thread's 4 elements
+        const int bbase = want_bias_grad ? (int)(p.bias_grad - F->grads_base) + m0 + tid : 0;
+        const bool vec = etile && (en + 3 < p.n_store);
+        // 1. my sums -> my exchange vector (system scope: what the peers' loads must find), drained before the flag
+        if (vec) peer_store4(G + gbase, make_float4(v[0], v[1], v[2], v[3]));
+        else if (etile) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (en + j < p.n_store) peer_store1(G + gbase + j, v[j]);
+        }
+        if (want_bias_grad && tid < vm) peer_store1(G + bbase, sb);
+        if (D.world > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // 2. my slot of this tile's flag row on every peer; wait for theirs (bounded; a dead exchange steps nothing)
+            peer_signal_row(D, D.flags_t, bx, epoch);
+            if (!peer_wait(D, D.flags_t[D.rank] + (size_t)bx * HP_PEER_MAX, epoch, 1u)) return;
+            // 3. rank-ordered sum (the same float32 expression on every rank: the replicas stay bit-identical)
+            const size_t gbytes = (size_t)F->am.la.total * 4 + (size_t)F->am.lc.total * 4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
+            for (int q = 0; q < D.world; ++q) {
+                float w[4] = {v[0], v[1], v[2], v[3]}, wb = sb;
+                if (q != D.rank) {
+                    if (vec) {
+                        const float4 t4 = peer_load4(D.grad[q][par], gbytes, (unsigned)gbase * 4u, false);
+                        w[0] = t4.x; w[1] = t4.y; w[2] = t4.z; w[3] = t4.w;
+                    } else if (etile) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (en + j < p.n_store) w[j] = __hip_atomic_load(D.grad[q][par] + gbase + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (want_bias_grad && tid < vm) wb = __hip_atomic_load(D.grad[q][par] + bbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = q ? acc[j] + w[j] : w[j];
+                accb = q ? accb + wb : wb;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[j];
+            sb = accb;
+        }
+        if (PT->mean) {   // SUM / world, float32 true division (what k_peer_adam does)
+            const float wn = (float)D.world;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] /= wn;
+            sb /= wn;
         }
     }
     if constexpr (ADAM && SC1) {

@@ -4,6 +4,7 @@
 
 #define HP_PEER_MAX 16        // ranks of one node
 #define HP_PEER_SMALL 1024    // floats of a mailbox (the normalizer exchanges 55 and 7)
+#define HP_PEER_TILES 512     // weight-gradient tiles of one launch that can exchange by themselves (flags_t)
 
 struct PeerDev {              // by-value kernel argument: where every rank's exchange memory is mapped in THIS process
     int rank, world;
@@ -13,6 +14,7 @@ struct PeerDev {              // by-value kernel argument: where every rank's ex
     float *grad[HP_PEER_MAX][2];                // rank q's gradient vectors (ping-pong)
     unsigned long long *flags_r[HP_PEER_MAX];   // two-phase exchange: rank q's "reduced slice ready" flags
     float *red[HP_PEER_MAX][2];                 // two-phase exchange: rank q's buffer of reduced sums (it fills ITS slice)
+    unsigned long long *flags_t[HP_PEER_MAX];   // tile-wise exchange: rank q's [HP_PEER_TILES][HP_PEER_MAX] epochs (slot [t][w] written by rank w)
     unsigned long long *epoch;                  // local: [0] gradient channel base, [1] mailbox channel
     unsigned int *error;                        // local, sticky: a wait timed out (every later exchange kernel returns at once)
     unsigned int *error_host;                   // the same word in pinned host memory: the host reads it without a sync
@@ -31,6 +33,7 @@ struct hp_peer {
     bool connected = false;
     int phases = 1;            // 1: every rank reads all peers' whole vectors; 2: reduce-scatter + all-gather (peer.hip)
     bool gate = false;         // every wait of the gradient exchange in a one-wavefront kernel of its own (hp_peer_set_gate)
+    bool tiles = true;         // one-shot form inside the weight-gradient launch: every tile exchanges by itself (RLARM_PEER_TILES=0: off)
     PeerDev dev;
 };
 
@@ -54,6 +57,13 @@ __device__ __forceinline__ void peer_signal(const PeerDev &D, unsigned long long
     if (q < D.world && q != D.rank) __hip_atomic_store(flags[q] + D.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ... the same for one slot row of a per-tile flag array: my slot of row `row` on every peer
+__device__ __forceinline__ void peer_signal_row(const PeerDev &D, unsigned long long *const *flags, int row, unsigned long long epoch) {
+    const int q = threadIdx.x;
+    if (q < D.world && q != D.rank)
+        __hip_atomic_store(flags[q] + (size_t)row * HP_PEER_MAX + D.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // every peer has signalled `epoch`?  lane q of the first wave polls the local slot of peer q.  Returns the same answer to
 // every thread of the workgroup (it contains a barrier: call it from uniform control flow).  false = the exchange is dead:
 // a wait timed out now or in an earlier kernel (sticky) -- the caller must NOT consume the peers' buffers or step the
@@ -61,6 +71,7 @@ __device__ __forceinline__ void peer_signal(const PeerDev &D, unsigned long long
 // once instead of stalling for another timeout.
 __device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *mine, unsigned long long epoch, unsigned channel = 1u) {
     __shared__ int s_peer_ok;
+    __syncthreads();   // a second call in one kernel must not overwrite the verdict a slow wave of the first call has yet to read
     if (threadIdx.x < 64) {
         const int q = threadIdx.x & 63;
         const bool poll = q < D.world && q != D.rank;
@@ -91,6 +102,14 @@ __device__ __forceinline__ bool peer_wait(const PeerDev &D, unsigned long long *
     __syncthreads();
     return s_peer_ok != 0;
 }
+
+// write-through to system scope: what a peer GPU's system-scope load must find (own exchange memory)
+__device__ __forceinline__ void peer_store4(float *p, const float4 v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void peer_store1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // float4s [lo, lo + per) of the vector are rank r's slice in the two-phase exchange
 __device__ __forceinline__ int peer_slice_len(const PeerDev &D, int n4) { return (n4 + D.world - 1) / D.world; }

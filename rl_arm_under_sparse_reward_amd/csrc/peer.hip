@@ -188,7 +188,7 @@ int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PeerLayout {
-    size_t flags_g, flags_s, flags_r, small, grad, red, total;
+    size_t flags_g, flags_s, flags_r, small, grad, red, flags_t, total;
     explicit PeerLayout(size_t n_grad) {
         size_t o = 0;
         flags_g = o; o += HP_PEER_MAX * 8;
@@ -199,6 +199,7 @@ struct PeerLayout {
         o = align_up(o, 256);
         grad = o; o += 2 * align_up(n_grad * 4, 256);
         red = o; o += 2 * align_up(n_grad * 4, 256);
+        flags_t = o; o += (size_t)HP_PEER_TILES * HP_PEER_MAX * 8;
         total = align_up(o, 4096);
     }
 };
@@ -211,6 +212,7 @@ static void peer_fill_dev(hp_peer *p) {
         p->dev.flags_g[q] = reinterpret_cast<unsigned long long *>(b + L.flags_g);
         p->dev.flags_s[q] = reinterpret_cast<unsigned long long *>(b + L.flags_s);
         p->dev.flags_r[q] = reinterpret_cast<unsigned long long *>(b + L.flags_r);
+        p->dev.flags_t[q] = reinterpret_cast<unsigned long long *>(b + L.flags_t);
         for (int k = 0; k < 2; ++k) {
             p->dev.small[q][k] = reinterpret_cast<float *>(b + L.small) + (size_t)k * HP_PEER_SMALL;
             p->dev.grad[q][k] = reinterpret_cast<float *>(b + L.grad + k * gstride);
@@ -238,6 +240,7 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     p->phases = world >= 4 ? 2 : 1;
     if (const char *ph = getenv("RLARM_PEER_PHASES")) p->phases = atoi(ph) == 2 ? 2 : (atoi(ph) == 1 ? 1 : p->phases);
     if (const char *g = getenv("RLARM_PEER_GATE")) p->gate = g[0] != '0';
+    if (const char *t = getenv("RLARM_PEER_TILES")) p->tiles = t[0] != '0';
     const PeerLayout L(p->n_grad);
     p->bytes = L.total;
     // fine-grained: coherent with the peers' system-scope accesses; plain device memory if the runtime refuses

@@ -23,7 +23,11 @@
 // Workgroups are dispatched in index order and a waiting workgroup only ever waits for workgroups with a SMALLER index (chains
 // come first on every XCD), so the waits cannot starve what they wait for, also when ranks share a device.  Every poll is
 // bounded (FbSplitArgs::wait_ticks): a give-up skips the work, sets the sticky fault word and its pinned host mirror, and the
-// next host call fails (agent.hip: agent_check_fault).  The launch that follows holds the ACTOR's tiles only (one per CU).
+// next host call fails (agent.hip: agent_check_fault).
+// The ACTOR's tiles: either the launch behind this one (144 tiles, one per CU), or -- the default -- further tile workgroups of
+// THIS launch that start when every actor-side chain has published (counter 6): one launch per update, the kernel boundary
+// between chains and tiles (the chain launch's drain, a gap, the tile launch's ramp and cold start: ~3 us) is replaced by one
+// hand-off (~1 us).  The first actor tile also finishes the loss log.
 // Same device functions, same operands, same summation order as k_fb_slab8 + k_gemm_lds_adam: bit-identical results
 // (tests/test_gpu_update.py::test_split_launch_is_bit_identical).
 
@@ -56,15 +60,18 @@ struct FbSplitArgs {
     GatherSrc tgs;                   // T chains: replay buffer, normalizers and the plan of the NEXT update
     const float *qt_in;              // C chains: Q' of this update's minibatch, [Mp][16] column 0
     float *qt_out;                   // T chains: Q' of the next update's minibatch
-    unsigned *sync;                  // counters (split_ctr): 3 stages of the C chains + the A chains' gate, one copy per XCD; sync[SPLIT_FAULT] = sticky fault word
-    unsigned *fault_host;            // pinned mirror of sync[2]
+    unsigned *sync;                  // this launch's counter set (split_ctr), sync_other: the set it clears for the next launch
+    unsigned *sync_other;
+    unsigned *fault;                 // the learner's sticky fault word ...
+    unsigned *fault_host;            // ... and its pinned host mirror
     unsigned long long wait_ticks;   // bound of every poll (100 MHz)
     unsigned need_c;                 // C chains of this launch (0: no tiles)
-    unsigned tile_stage;             // 4 bits per problem of `tiles`: the stage of the C chains its operands come from
+    unsigned tile_stage;             // 4 bits per problem of `tiles`: the counter that says its operands are published
+    int loss_prob;                   // the first tile of this problem finishes the loss log (-1: the launch behind this one does)
     int reset_sync;                  // prologue launch of a sequence (target chains only): clear the counters
     int tl_mark;                     // time-line builds: this launch records its per-workgroup stamps (the last one WITH target chains)
-    GemmGroup tiles;                 // the critic's weight-gradient problems (row-major tile order, XCD-major tile indices)
-    AdamFuse adam;                   // their optimizer epilogue (gate = sync + 1)
+    GemmGroup tiles;                 // weight-gradient problems: the critic's four, then (one-launch form) the actor's four
+    AdamFuse adam;                   // their optimizer epilogue
 };
 static_assert(sizeof(FbSplitArgs) <= 4096, "kernel arguments of k_fb_split8 exceed the 4 KB kernarg segment");
 
@@ -175,16 +182,19 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 if (xx < x && nt > in_xcd) tile += 1;
             }
         }
-        int pi = 0;
+        int pi = 0, first_tile = 0;
 #pragma unroll
         for (int i = 1; i < MAX_PROBS; ++i)
-            if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) pi = i;
+            if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) {
+                pi = i;
+                first_tile = Q.tiles.p[i].tile0;
+            }
         const int stage = (int)((Q.tile_stage >> (4 * pi)) & 15u);
-        if (!handoff_wait(split_ctr(Q.sync, stage, (int)(blockIdx.x & 7)), Q.need_c, Q.wait_ticks, Q.sync + SPLIT_FAULT, Q.fault_host,
+        if (!handoff_wait(split_ctr(Q.sync, stage, (int)(blockIdx.x & 7)), Q.need_c, Q.wait_ticks, Q.fault, Q.fault_host,
                           1u, reinterpret_cast<int *>(dq)))
             return;
         SPLIT_STAMP(1);
-        gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, false);
+        gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, pi == Q.loss_prob && tile == first_tile);
         SPLIT_STAMP(3);
     } else if (role == SR_T) {
         // ------------------------------------------------------------------ target side, one update ahead
@@ -193,8 +203,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 0);
         const SlabNetPtrs &tn = A.target;
         const GatherSrc &G = Q.tgs;
-        if (Q.reset_sync && slab == 0 && tid < SPLIT_COUNTERS * 8)   // nothing of THIS launch counts (no C / A chains, no tiles)
-            __hip_atomic_store(Q.sync + tid * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Q.reset_sync && slab == 0 && tid < SPLIT_COUNTERS * 8)   // prologue: the first update's set (nothing of THIS launch counts)
+            __hip_atomic_store(Q.sync_other + tid * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const PlanRec rec = s8_plan_rec(G, row0);
         float4 wbaT[6], wbcT[6], whT[4], wqT[4];
         s8_ring_prologue<0, S8_PRO_FIRST>(ring, rbase, tn.wf + la.w2);
@@ -343,6 +353,8 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     } else {
         // ---------------------------------------------------------------------- actor side
         S8_TSTAMP(tl, 0);
+        if (slab == 0 && tid < SPLIT_COUNTERS * 8)   // the NEXT launch's counter set (nobody of this launch touches it)
+            __hip_atomic_store(Q.sync_other + tid * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #define S8_AFTER_CRITIC_FWD do { split_bump(Q.sync, 3); } while (0)
 #define S8_AFTER_CRITIC_DX1 do { split_bump(Q.sync, 4); } while (0)
 #define S8_AFTER_CRITIC_DX do { split_bump(Q.sync, 5); SPLIT_STAMP(1); } while (0)
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #undef S8_AFTER_CRITIC_FWD
 #undef S8_AFTER_CRITIC_DX1
 #undef S8_AFTER_CRITIC_DX
+        if (Q.loss_prob >= 0) split_publish(Q.sync, 6);   // one-launch form: dZ, dK3..dK1, the actor's activations and loss partials are out
         SPLIT_STAMP(3);
     }
 }

@@ -138,6 +138,7 @@ class ddpg_agent:
     def close_comm(self):
         """Detach and destroy the library-side RCCL communicator (call on every rank before
         torch.distributed.destroy_process_group / interpreter exit)."""
+        self._flush_updates()         # deferred updates still exchange gradients: issue them while the transport exists
         if self._native_comm is not None or self._peer is not None or self.comm.peer is not None or self.comm.native is not None:
             self.ctx.synchronize()
             _lib.check(self.lib.hp_agent_set_comm(self.h, None))
@@ -259,11 +260,27 @@ class ddpg_agent:
         self._issue_updates(int(n_updates))
 
     def _flush_updates(self):
+        """Issue the counted `_update_network()` calls.  In chunks whose lengths are powers of two (at most n_batches): a loop
+        that is flushed at irregular points would otherwise ask for a new sequence length -- a freshly captured graph -- every
+        time and thrash the library's 8-entry graph cache.  An error names the deferred call it belongs to, and what could not
+        be issued stays pending (the caller may fix the cause -- e.g. store an episode -- and carry on)."""
         with _lib.pending_lock:
             n, self._pending_updates = self._pending_updates, 0
             _lib.unregister_pending(self)
-            if n:
-                self._issue_updates(n)
+            cap = max(1, int(self.args.n_batches))
+            while n:
+                chunk = n if n == cap else 1 << (min(n, cap).bit_length() - 1)
+                try:
+                    self._issue_updates(chunk)
+                except Exception as e:
+                    self._pending_updates += n                 # nothing of this chunk was enqueued: still owed
+                    _lib.register_pending(self)
+                    note = f"deferred _update_network() x {n} (issued by a later library call, _lib.py 'deferred updates')"
+                    if hasattr(e, "add_note"):
+                        e.add_note(note)
+                        raise
+                    raise type(e)(f"{e} [{note}]") from e
+                n -= chunk
 
     def _issue_updates(self, n_updates):
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)
@@ -540,6 +557,11 @@ class ddpg_agent:
 
     def __del__(self):
         try:
+            self._flush_updates()     # counted `_update_network()` calls are owed even if nobody looks at the result
+        except Exception:
+            pass
+        try:
+            _lib.unregister_pending(self)
             self.lib.hp_agent_destroy(self.h)
         except Exception:
             pass

@@ -239,13 +239,15 @@ def test_every_update_meets_the_north_star_bar_single_rank(batch, k, monkeypatch
           f"grad / max|g| {worst[1]:.2e} (error vs float64 = {worst[4]:.2f} x torch float32's), optimizer vs torch.optim.Adam {worst[2]:.2f} x (1 ulp + 5e-10), well-conditioned param {worst[3]:.2e}, ReLU ties {worst[5]}")
 
 
-@pytest.mark.parametrize("batch,k,n_eps", [(256, 4, 64), (256, 4, 5000), (64, 4, 64)], ids=["b256", "b256_full_shard", "b64"])
-def test_every_update_meets_the_bar_through_the_split_launch(batch, k, n_eps, monkeypatch):
+@pytest.mark.parametrize("batch,k,n_eps,one", [(256, 4, 64, 1), (256, 4, 5000, 1), (64, 4, 64, 1), (256, 4, 64, 0)],
+                         ids=["b256", "b256_full_shard", "b64", "b256_two_launches"])
+def test_every_update_meets_the_bar_through_the_split_launch(batch, k, n_eps, one, monkeypatch):
     """Round 4: the same bars through slab8_split.h (RLARM_SPLIT=1 forces it for single updates too): target chains in a
     prologue launch, critic chains + the critic's weight-gradient tiles and optimizer step inside the chain launch behind the
     two in-launch counters, the actor's tiles behind it -- on the 64-episode buffer and on the full 5000-episode shard."""
     monkeypatch.setenv("RLARM_KEEP_GRADS", "1")
     monkeypatch.setenv("RLARM_SPLIT", "1")
+    monkeypatch.setenv("RLARM_SPLIT_ONE", str(one))   # 1 (default): the actor's tiles inside the split launch as well
     worst, agent = _run(batch, k, n_eps=n_eps, n_steps=N_STEPS if n_eps <= 64 else 20)
     print(f"teacher-forced (split launch) batch {batch} k {k} episodes {n_eps}: worst: loss rel {worst[0]:.2e}, grad / max|g| {worst[1]:.2e} "
           f"(vs float64 = {worst[4]:.2f} x torch float32's), optimizer {worst[2]:.2f} x (1 ulp + 5e-10), param {worst[3]:.2e}, ReLU ties {worst[5]}")
@@ -260,15 +262,19 @@ def test_every_update_meets_the_bar_on_the_full_shard(batch, k, monkeypatch):
           f"grad / max|g| {worst[1]:.2e}, optimizer {worst[2]:.2f} x (1 ulp + 5e-10), param {worst[3]:.2e}, ReLU ties {worst[5]}")
 
 
-@pytest.mark.parametrize("transport", ["peer", "peer+2phase", "native", "torch"])
+@pytest.mark.parametrize("transport", ["peer", "peer+notiles", "peer+2phase", "native", "torch"])
 def test_every_update_meets_the_bar_through_the_data_parallel_optimizer(transport, monkeypatch):
     """1-rank group, forced exchange: backward -> exchange -> separate optimizer kernel (k_peer_adam; k_peer_reduce_slice +
-    k_peer_adam2; RCCL + k_adam_frag4; torch.distributed + hp_agent_apply), the kernels every rank of a multi-GPU job runs."""
+    k_peer_adam2; RCCL + k_adam_frag4; torch.distributed + hp_agent_apply), the kernels every rank of a multi-GPU job runs --
+    and, round 4, "peer" = weight gradients + tile-wise exchange + optimizer step in ONE launch (k_gemm_lds_adam_peer)."""
     import torch.distributed as dist
     from rl_arm_under_sparse_reward_amd.utils import Communicator
     if transport.endswith("+2phase"):
         transport = transport[:-7]
         monkeypatch.setenv("RLARM_PEER_PHASES", "2")
+    if transport.endswith("+notiles"):               # "peer" alone: the tile-wise exchange inside the weight-gradient launch (round 4)
+        transport = transport[:-8]
+        monkeypatch.setenv("RLARM_PEER_TILES", "0")
     monkeypatch.setenv("RLARM_COMM", transport)
     monkeypatch.setenv("RLARM_KEEP_GRADS", "1")      # the peer optimizer kernels write the exchanged sum out for get_grads
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -39,6 +39,17 @@ def _worker(rank, world, port, out_dir, transport="torch"):
         os.environ["RLARM_PEER_PHASES"] = "1"
     if transport == "peer2":                 # reduce-scatter + all-gather over the same peer memory (default from 4 ranks)
         os.environ["RLARM_PEER_PHASES"] = "2"
+    if transport == "peertiles":
+        # Round 4: the tile-wise exchange INSIDE the weight-gradient launch (gemm_lds.h PEER), which ranks that share a device
+        # normally avoid (their waits go into gate kernels and the exchange stays a launch of its own).  Forced here with the
+        # gates off and a batch small enough that both ranks' launches are co-resident on the one device (53 chain workgroups
+        # beside the other rank's waiting tiles), so that the flag rows, the rank-ordered sums and the buffer ping-pong of the
+        # form every real multi-GPU job runs are exercised by two real processes.  Waits are bounded: a starved launch fails
+        # the test after 5 s instead of hanging the box.
+        os.environ["RLARM_COMM"] = "peer"
+        os.environ["RLARM_PEER_PHASES"] = "1"
+        os.environ["RLARM_PEER_GATE"] = "0"
+        os.environ["RLARM_PEER_TIMEOUT_S"] = "5"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -59,7 +70,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     torch.set_num_threads(2)
     comm = Communicator(0)
     assert comm.active and comm.world_size == world
-    n_eps, batch, seed = 32, 256, 125 + rank
+    n_eps, batch, seed = 32, (64 if transport == "peertiles" else 256), 125 + rank
     eps = make_episodes(n_eps, seed=40 + rank, mode="walk")
     # ---- device side
     torch.manual_seed(100 + rank)            # ranks start from DIFFERENT nets; sync_networks must fix that (C1)
@@ -156,7 +167,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("auto", 4), ("torch", 4), ("peer", 4)],
+@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("peertiles", 2), ("auto", 4), ("torch", 4), ("peer", 4)],
                 ids=lambda p: f"{p[0]}-w{p[1]}")
 def two_ranks(request, tmp_path_factory):
     """torch: collectives through torch.distributed (gloo, host-staged) from a host-driven loop.

@@ -11,6 +11,7 @@ from gpu_common import ENV_PARAMS, fresh_rng, state_equal
 from oracle import ddpg_update as oupd
 from oracle.her_replay import EpisodeStore, future_probability
 from oracle.running_norm import RunningNorm, update_normalizers
+from rl_arm_under_sparse_reward_amd import _lib
 from rl_arm_under_sparse_reward_amd.arguments import Args
 from rl_arm_under_sparse_reward_amd.ddpg_agent import (NET_ACTOR, NET_ACTOR_TARGET, NET_CRITIC, NET_CRITIC_TARGET,
                                                         ddpg_agent)
@@ -414,7 +415,10 @@ def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
                                                     ("torch", False, "mean"), ("native", True, "mean"),
                                                     ("peer", False, "sum"), ("peer", True, "sum"), ("peer", True, "mean"),
                                                     ("native+dw64", True, "sum"), ("peer+dw64", True, "sum"),
-                                                    ("peer+2phase", True, "sum"), ("peer+2phase", False, "mean")])
+                                                    ("peer+2phase", True, "sum"), ("peer+2phase", False, "mean"),
+                                                    # round 4: "peer" is now the tile-wise exchange inside the weight-gradient launch
+                                                    # (gemm_lds.h PEER); +notiles keeps k_gemm_lds -> k_peer_adam covered
+                                                    ("peer+notiles", True, "sum"), ("peer+notiles", False, "mean")])
 def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, monkeypatch):
     """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
     begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
@@ -428,6 +432,9 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
     if transport.endswith("+2phase"):   # reduce-scatter + all-gather form of the peer exchange (one rank: one slice)
         transport = transport[:-7]
         monkeypatch.setenv("RLARM_PEER_PHASES", "2")
+    if transport.endswith("+notiles"):
+        transport = transport[:-8]
+        monkeypatch.setenv("RLARM_PEER_TILES", "0")
     if transport.endswith("+dw64"):   # the split weight-gradient kernel without its optimizer epilogue (k_dw64 -> exchange -> Adam)
         transport = transport[:-5]
         monkeypatch.setenv("RLARM_DW64", "1")
@@ -483,7 +490,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           # inside the chain launch; default where it fits) against the two-launch form, its other
                                           # placement, and forced on for the single-update tail of a sequence
                                           ("RLARM_SPLIT=0", 256), ("RLARM_SPLIT=0", 128), ("RLARM_SPLIT=0", 288), ("RLARM_SPLIT=0", 64),
-                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1", 256)])
+                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT_ONE=0", 256), ("RLARM_SPLIT_ONE=0", 128)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
@@ -524,7 +531,9 @@ def test_split_launch_is_bit_identical(batch, n_updates, monkeypatch):
     got = run()
     monkeypatch.setenv("RLARM_SPLIT", "1")
     forced = run()
-    for other in (got, forced):
+    monkeypatch.setenv("RLARM_SPLIT_ONE", "0")       # the actor's tiles as a launch of their own behind the split launch
+    two = run()
+    for other in (got, forced, two):
         for a, b in zip(want, other):
             assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
@@ -709,3 +718,52 @@ def test_argumentless_update_calls_are_deferred_and_batched_with_the_same_bits(m
                      rng.get_state()[1], rng.get_state()[2]))
     for a, b in zip(*outs):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def test_deferred_updates_and_a_held_device_view():
+    """a zero-copy view of the library's parameter arena (`_lib.DevicePointer`, what utils.py hands torch)
+    held ACROSS `_update_network()` calls shows the state as of the last library call -- the counted updates are issued by the
+    next entry point (or `_lib.flush_pending()`), not by the call itself.  INTEGRATION.md section 2 states the rule; this pins it."""
+    import ctypes as C
+    torch.manual_seed(0)
+    agent, rng = make_agent(batch=256, n_eps=32, seed=21, n_batches=8)
+    agent.buffer.store_episode(make_episodes(20, seed=9, mode="walk"))
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(agent.lib.hp_agent_param_buffer(agent.h, C.byref(p), C.byref(n)))
+    view = torch.as_tensor(_lib.DevicePointer(p.value, n.value), device="cuda:0")
+    agent.ctx.synchronize()
+    before = view.clone()
+    for _ in range(3):
+        agent._update_network()                          # counted
+    assert agent._pending_updates == 3
+    torch.cuda.synchronize()
+    assert torch.equal(view, before)                     # nothing has run: the view is NOT the post-update state yet
+    _lib.flush_pending()                                 # (any library entry point does this first)
+    assert agent._pending_updates == 0
+    agent.ctx.synchronize()
+    assert not torch.equal(view, before)                 # now it is
+    want = agent._get_flat(NET_ACTOR)
+    assert np.isfinite(want).all()
+
+
+def test_a_failing_deferred_update_names_itself_and_stays_owed():
+    """the reference raises `ValueError: high <= 0` from `_update_network()` itself when the buffer is empty; deferred,
+    the error surfaces at the NEXT library call -- it must say which call it belongs to, and the updates that could not be issued
+    stay pending (they are issued once the cause is gone), as do other objects' pending updates behind it."""
+    torch.manual_seed(0)
+    agent, rng = make_agent(batch=64, n_eps=8, seed=3, n_batches=8)
+    other, _ = make_agent(batch=64, n_eps=8, seed=4, n_batches=8)
+    other.buffer.store_episode(make_episodes(4, seed=9, mode="walk"))
+    agent._update_network()                              # empty buffer: the reference would raise here
+    agent._update_network()
+    other._update_network()
+    assert agent._pending_updates == 2 and other._pending_updates == 1
+    with pytest.raises(ValueError, match=r"high <= 0.*deferred _update_network\(\) x 2"):
+        agent.o_norm.mean                                # an unrelated library call triggers the flush
+    assert agent._pending_updates == 2                   # still owed, not dropped
+    assert other._pending_updates in (0, 1)              # issued, or still registered -- never lost
+    agent._pending_updates = 0                           # give up on them explicitly (what a caller that catches the error may do)
+    _lib.unregister_pending(agent)
+    _lib.flush_pending()
+    assert other._pending_updates == 0
+    assert other.last_losses(1).shape == (1, 2)
