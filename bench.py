@@ -220,6 +220,10 @@ def profile_kernels(r: Runner, cycles=3):
     return prof
 
 
+# what hp_ctx_calibrate read on the boxes of the pool where the headline is 39-40 us/update (profiles/r04_calibration.txt)
+CALIBRATION_TYPICAL = {"launch_floor_us": 1.57, "lds_dma_GBps_per_cu": 152.6, "mfma4x4_dependent_cycles": 14.7}
+
+
 def baseline_metric_name(a):
     """BASELINE.json's metric string for its headline shape (batch 256, replay_k 4); the other shapes say what they are."""
     name = "HER-relabelled transitions sampled+updated /sec"
@@ -494,6 +498,14 @@ def main():
     from rl_arm_under_sparse_reward_amd import _lib as _l
     mhz = C.c_double()
     _l.check(r.ctx.lib.hp_ctx_clock_mhz(r.ctx.h, C.byref(mhz)))      # shader clock right after the timed region
+    cal = (C.c_double * 4)()
+    try:
+        _l.check(r.ctx.lib.hp_ctx_calibrate(r.ctx.h, cal))
+        calibration = {"launch_floor_us": round(cal[0], 3), "lds_dma_GBps_per_cu": round(cal[1], 1),
+                       "mfma4x4_dependent_cycles": round(cal[2], 2), "shader_clock_mhz": round(cal[3]),
+                       "typical": CALIBRATION_TYPICAL}
+    except Exception as e:        # noqa: BLE001 -- a diagnostic must not cost the run its line
+        calibration = {"error": str(e)}
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.batch * a.steps / dt
     out = {
@@ -527,6 +539,10 @@ def main():
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
                    "final_losses": [float(losses[0]), float(losses[1])],
                    "shader_clock_mhz_after_run": round(mhz.value)},
+        # ~200 us of probes that characterise THIS box (rlarm_hip_debug.h: hp_ctx_calibrate), taken right after the timed region:
+        # about one box in seven of the pool ran every kernel of this path ~1.4 x slower at the same shader clock -- with these
+        # three rates in the line a slow box can be told from a regression
+        "calibration": calibration,
     }
     if prof:
         # ---- roofline of the matrix kernels.  Algorithmic MACs per transition (minimal algorithm):
@@ -536,14 +552,22 @@ def main():
         # overhead inside.  rocprofv3 kernel durations of the same command (profiles/) are that minus the boundary.
         ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
         eng = r.agent.engine()
-        chain_kernel = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32"}.get(eng["engine"], "k_gemm_group")
+        split = eng.get("launches_per_update", "").startswith("split")
+        chain_kernel = {"slab8": "k_fb_split8" if split else "k_fb_slab8", "slab32": "k_fb_slab32"}.get(eng["engine"], "k_gemm_group")
         dw_kernel = "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam"
-        kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
+        # weight-gradient MACs per transition by network (SURVEY 8d's 287,488 split by the layer shapes: critic 34*256 + 2*256*256 +
+        # 256, actor 30*256 + 2*256*256 + 4*256)
+        dw_critic = round(287_488 * 140_032 / 279_808)
+        dw_actor = 287_488 - dw_critic
+        if split:   # slab8_split.h: the chain launch also holds the critic's weight gradients + Adam; the launch behind it the actor's
+            kinds = {"chain": (None, 699_648 + 395_776 + dw_critic, chain_kernel), "weight_grad": (None, dw_actor, dw_kernel)}
+        else:
+            kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
         # HBM traffic needs rocprofv3 --pmc passes around the process (tools/gpu_round3.sh), so it cannot be measured from
         # inside this run: it is read from the newest committed counter summary of this shape, which records a fingerprint of
         # the kernel sources it was taken on -- when the sources have changed since, the figure is reported as stale
         pmc, pmc_file, pmc_sha = {}, None, None
-        for cand in (f"r03_pmc_traffic_b{a.batch}.json", f"r02_pmc_traffic_b{a.batch}.json"):
+        for cand in (f"r04_pmc_traffic_b{a.batch}.json", f"r03_pmc_traffic_b{a.batch}.json", f"r02_pmc_traffic_b{a.batch}.json"):
             path = os.path.join(REPO, "profiles", cand)
             if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
                 with open(path) as fh:
@@ -559,9 +583,10 @@ def main():
             sha_now = None
         traffic_stale = (pmc_sha is None or sha_now is None or pmc_sha != sha_now) if pmc_file else None
         # committed rocprofv3 summary of this same configuration (tools/gpu_round3.sh): cross-check for the live numbers
-        prof_file = os.path.join(REPO, "profiles", f"r03_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
-        if not os.path.exists(prof_file):
-            prof_file = os.path.join(REPO, "profiles", f"r02_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+        prof_file = os.path.join(REPO, "profiles", f"r04_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+        for older in ("r03", "r02"):
+            if not os.path.exists(prof_file):
+                prof_file = os.path.join(REPO, "profiles", f"{older}_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
         prof_avg = {}
         if os.path.exists(prof_file):
             for line in open(prof_file):
@@ -573,15 +598,16 @@ def main():
                         pass
         per = {}
         for name, (kind, macs, kernel) in kinds.items():
-            us = C.c_double()
-            _l.check(r.agent.lib.hp_agent_debug_chain(r.agent.h, kind, 200, C.byref(us)))
+            us = C.c_double(float("nan"))
+            if kind is not None:
+                _l.check(r.agent.lib.hp_agent_debug_chain(r.agent.h, kind, 200, C.byref(us)))
             ev = prof.get({"chain": "forward", "weight_grad": "weight_grad"}[name], {})
             ev2 = prof.get("backward_dx", {}) if name == "chain" else {}
             # live, in situ: one HIP event pair around each eager launch of the training loop on the launch stream, minus what
             # an event pair with nothing in between reads on this stack
             live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
             if name == "chain":
-                rp = sum(v for k, v in prof_avg.items() if k in ("k_fb_slab8", "k_fb_slab32"))
+                rp = sum(v for k, v in prof_avg.items() if k == chain_kernel)
             else:   # the ride-along variant runs on all but the last updates of a cycle
                 rp = (prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam_ride_u")
                       or prof_avg.get("k_gemm_lds_adam") or prof_avg.get("k_gemm_lds_adam_u", 0.0))   # _u: scalar wave index (batch 257..640)
@@ -589,7 +615,7 @@ def main():
             tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
             per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "live_event_pair_minus_empty_us": round(live, 3),
                          "rocprofv3_avg_us_committed": round(rp, 3) if rp else None,
-                         "graph_replay_warm_us": round(us.value, 3), "flop_per_launch": 2.0 * macs * a.batch,
+                         "graph_replay_warm_us": round(us.value, 3) if us.value == us.value else None, "flop_per_launch": 2.0 * macs * a.batch,
                          "achieved_tflops": round(tf, 3), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5),
                          "traffic_hbm_bytes_per_launch": sum(v for k, v in pmc.items() if k in kernel or kernel in k) or None}
         dom = max(per, key=lambda k: per[k]["avg_launch_us"])

@@ -146,6 +146,7 @@ PROTOTYPES = {
     "hp_agent_debug_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "hp_agent_engine": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hp_agent_status": (C.c_int, [C.c_void_p, u32p]),
+    "hp_agent_update_form": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "hp_agent_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "hp_agent_profile_read": (C.c_int, [C.c_void_p, f64p, C.c_int32]),
     "hp_agent_destroy": (None, [C.c_void_p]),

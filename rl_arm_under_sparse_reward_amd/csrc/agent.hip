@@ -827,6 +827,19 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
     return HP_OK;
 }
 
+// which launch structure a sequence of n_updates sampled updates takes on this agent: 0 = chain launch + weight-gradient launch,
+// 1 = split launch (slab8_split.h: target chains one update ahead, the critic's tiles + optimizer step inside the chain launch)
+// + the actor's tile launch, 2 = split launch holding the actor's tiles as well (one launch per update)
+int hp_agent_update_form(hp_agent *a, int32_t n_updates, int32_t *form) {
+    HP_REQUIRE(a && form, HP_ERR_INVALID, "hp_agent_update_form: null argument");
+    const int chains = chain_wgs(a);
+    const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
+    const bool split = a->slab8 && a->gather_ahead && !full && a->plan_side <= 0 && split_fits(a) &&
+                       (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
+    *form = split ? (a->split_one == 1 ? 2 : 1) : 0;
+    return HP_OK;
+}
+
 int hp_agent_engine(hp_agent *a, int32_t *engine, int32_t *slab_rows, int32_t *dw_split) {
     HP_REQUIRE(a, HP_ERR_INVALID, "hp_agent_engine: null handle");
     if (engine) *engine = !a->slab ? 0 : (a->slab8 ? 8 : 32);

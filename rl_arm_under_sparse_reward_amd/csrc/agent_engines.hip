@@ -856,7 +856,7 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.adam = adam_fuse(a);
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
-    ProfScope ps(a, PROF_GEMM_FWD);
+    ProfScope ps(a, PROF_PLAN);   // (once per sequence, with the index draws: not an update's launch)
     hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;

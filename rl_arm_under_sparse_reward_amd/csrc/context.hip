@@ -227,28 +227,41 @@ int hp_ctx_clock_mhz(hp_ctx *ctx, double *mhz) {
 // diagnostic: ~200 us of probes that characterise the box (rlarm_hip_debug.h)
 int hp_ctx_calibrate(hp_ctx *ctx, double *out4) {
     HP_REQUIRE(ctx && out4, HP_ERR_INVALID, "hp_ctx_calibrate: bad argument");
-    hipStream_t s = ctx->stream;
-    HP_TRY(hp_ctx_launch_floor(ctx, 200, 1, &out4[0]));
+    CtxGuard guard(ctx);
+    // on a stream of its own: the context's may be a framework's (legacy streams cannot be captured) or busy
+    hipStream_t s = nullptr, keep = ctx->stream;
+    HP_CHECK_HIP(hipStreamSynchronize(keep));
+    HP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    ctx->stream = s;
+    int st = hp_ctx_launch_floor(ctx, 200, 1, &out4[0]);
     float *src = nullptr, *sink = nullptr;
     unsigned long long *d = nullptr, h[2] = {0, 0};
     const int passes = 16, n8 = 512;
-    HP_CHECK_HIP(hipMalloc((void **)&src, 256 * 1024));
-    HP_CHECK_HIP(hipMalloc((void **)&sink, 16));
-    HP_CHECK_HIP(hipMalloc((void **)&d, 16));
-    HP_CHECK_HIP(hipMemsetAsync(src, 0, 256 * 1024, s));
-    for (int rep = 0; rep < 2; ++rep) {   // the second run finds the block in L2 and the code in the instruction cache
-        hipLaunchKernelGGL(k_cal_stream, dim3(1), dim3(512), 0, s, src, passes, d, sink);
-        hipLaunchKernelGGL(k_cal_mfma, dim3(1), dim3(64), 0, s, n8, d, sink);
+    hipError_t e = hipSuccess;
+    if (st == HP_OK) {
+        e = hipMalloc((void **)&src, 256 * 1024);
+        if (e == hipSuccess) e = hipMalloc((void **)&sink, 16);
+        if (e == hipSuccess) e = hipMalloc((void **)&d, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(src, 0, 256 * 1024, s);
+        for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {   // the second run finds the block in L2 and the code in the instruction cache
+            hipLaunchKernelGGL(k_cal_stream, dim3(1), dim3(512), 0, s, src, passes, d, sink);
+            hipLaunchKernelGGL(k_cal_mfma, dim3(1), dim3(64), 0, s, n8, d, sink);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (st == HP_OK && e == hipSuccess) st = hp_ctx_clock_mhz(ctx, &out4[3]);
     }
-    HP_CHECK_HIP(hipGetLastError());
-    HP_CHECK_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s));
-    HP_CHECK_HIP(hipStreamSynchronize(s));
-    (void)hipFree(src);
-    (void)hipFree(sink);
-    (void)hipFree(d);
+    ctx->stream = keep;
+    if (src) (void)hipFree(src);
+    if (sink) (void)hipFree(sink);
+    if (d) (void)hipFree(d);
+    (void)hipStreamDestroy(s);
+    if (st != HP_OK) return st;
+    HP_CHECK_HIP(e);
     out4[1] = h[0] ? (double)passes * 256.0 * 1024.0 / ((double)h[0] * 10.0) : 0.0;   // bytes per ns = GB/s (a tick is 10 ns)
     out4[2] = (double)h[1] / (8.0 * n8);
-    return hp_ctx_clock_mhz(ctx, &out4[3]);
+    return HP_OK;
 }
 
 void hp_ctx_destroy(hp_ctx *ctx) {

@@ -385,10 +385,14 @@ class ddpg_agent:
     def engine(self):
         """Kernels this agent's updates run (hp_agent_engine): e.g. {'engine': 'slab8', 'slab_rows': 4, 'weight_grad':
         'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 3'} at 4096."""
-        e, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        e, r, d, f = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.hp_agent_engine(self.h, C.byref(e), C.byref(r), C.byref(d)))
+        _lib.check(self.lib.hp_agent_update_form(self.h, int(self.args.n_batches), C.byref(f)))
         return {"engine": {0: "layers", 8: "slab8", 32: "slab32"}[e.value], "slab_rows": r.value,
-                "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32"}
+                "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32",
+                "launches_per_update": {0: "chains | weight gradients + Adam",
+                                        1: "split: chains (targets one update ahead) + critic weight gradients + Adam | actor weight gradients + Adam",
+                                        2: "split, one launch: chains + all weight gradients + Adam"}[f.value]}
 
     def policy_snapshot(self):
         """Publish the current actor + normalizer statistics to feeders that call the policy while cycles run

@@ -41,7 +41,12 @@ def test_driver_invocation_prints_the_contract_line():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 256 * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-3 * d["value"]     # value = transitions / timed region
     assert 2e6 < d["value"] < 2e7                                     # a plausible MI355X figure, not a unit slip
-    assert d["config"]["engine"] == {"engine": "slab8", "slab_rows": 4, "weight_grad": "gemm_lds 32x32"}
+    eng = d["config"]["engine"]
+    assert (eng["engine"], eng["slab_rows"], eng["weight_grad"]) == ("slab8", 4, "gemm_lds 32x32")
+    assert eng["launches_per_update"].startswith("split")          # round 4: the default form at the headline shape
+    assert d["roofline"]["kernel"] == "k_fb_split8"
+    cal = d["calibration"]
+    assert 0.5 < cal["launch_floor_us"] < 10 and 20 < cal["lds_dma_GBps_per_cu"] < 400 and 4 < cal["mfma4x4_dependent_cycles"] < 40
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == pytest.approx(157.3)
     assert 0.0 < r["frac"] < 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
@@ -91,6 +96,30 @@ def test_plain_shell_launch_rehearses_4_and_8_ranks(world):
     assert t["config"]["exchange"] == "torch.distributed" and t["config"]["replicas_bit_identical"] is True
     for got, want in zip(t["config"]["final_losses"], d["config"]["final_losses"]):  # another summation order across ranks
         assert abs(got - want) <= 2e-2 * max(abs(want), 1e-2)
+
+
+@pytest.mark.parametrize("name,flags,per_rank_batch", [
+    ("config4", ("--batch", "1024"), 1024),
+    ("config5", ("--batch", "512", "--replay-k", "8", "--feeder-episodes", "8"), 512)])
+def test_baseline_configs_4_and_5_rehearsed_at_their_real_per_rank_workloads(name, flags, per_rank_batch):
+    """VERDICT r03 item 1a.  BASELINE config 4 = 8 ranks x (batch 1024, 5000-episode shard), config 5 = 8 ranks x (batch 512,
+    replay_k 8, 8 fresh episodes per cycle from the host feeder, 5000-episode shard) -- so far eight ranks had only run at batch
+    256 on 64-episode shards.  Here: the exact `bench.py --gpus 8` code path at those per-rank workloads with NOTHING forced, all
+    ranks on the one device of the test box (default transport = peer memory with gate kernels, default form at 8 ranks =
+    two-phase, cycle = hipGraph), replicas bit-identical, no fallback; then the one-shot form: the same losses bit for bit."""
+    common = ("--gpus", "8", *flags, "--steps", "40", "--warmup", "40", "--no-cpu-baseline", "--no-profile")
+    d = _run(*common, timeout=1500)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["global_batch"] == 8 * per_rank_batch
+    assert c["exchange"] == "peer-memory", c                      # no fallback to RCCL / torch.distributed
+    assert c["peer_exchange_form"].startswith("two-phase") and c["cycle_mode"] == "hipGraph"
+    assert c["replicas_bit_identical"] is True and c["devices_shared_by_ranks"] is True and c["peer_gate_kernels"] is True
+    assert abs(d["value"] - 8 * per_rank_batch * 40 / (d["ms_per_step"] * 40e-3)) <= 1e-3 * d["value"]
+    assert all(abs(x) < 1e3 for x in c["final_losses"])
+    one = _run(*common, timeout=1500, RLARM_PEER_PHASES="1")
+    assert one["config"]["exchange"] == "peer-memory" and one["config"]["peer_exchange_form"].startswith("one-shot")
+    assert one["config"]["replicas_bit_identical"] is True
+    assert one["config"]["final_losses"] == c["final_losses"]     # one-shot == two-phase: the same rank-ordered float32 sums
 
 
 def test_multi_rank_launch_survives_a_failing_exchange_on_one_rank():
