@@ -76,6 +76,14 @@ class her_sampler:
         # the kernels take the squared threshold; a negative value selects the dense reward -d (compute_reward :89-90)
         self.sq_threshold = squared_threshold(self.distance_threshold) if reward_type == "sparse" else -1.0
         self._rng = rng
+        if int(goal_dim) >= 8:
+            # The device sums the squared goal distance left to right; numpy's add.reduce (np.linalg.norm in compute_reward,
+            # bmirobot_env_push_F.py:20-23) switches to 8-way pairwise summation from 8 contiguous elements on, so bit-exact
+            # rewards are only claimed below that (the reference's goals have 3 components).  Refuse loudly rather than let the
+            # probe below reject a legitimate reward function with a misleading message, or relabel with last-bit differences.
+            raise NotImplementedError(
+                f"goal_dim={int(goal_dim)}: the device reward sums the squared distance in index order, which matches numpy's "
+                "reduction only for fewer than 8 goal components (the bmirobot tasks have 3); wider goals are not supported")
         if reward_func is not None:
             self._probe_reward_func(reward_func, int(goal_dim))
 

@@ -33,7 +33,7 @@ def csrc_sha16():
     marks the traffic figure stale when the code has changed since)."""
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rl_arm_under_sparse_reward_amd", "csrc")
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.inc"))):
         h.update(os.path.basename(path).encode())
         with open(path, "r", encoding="utf-8", errors="replace") as f:
             h.update(_code_only(f.read()).encode())
