@@ -232,7 +232,7 @@ struct hp_agent {
     // split launch (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
     // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
-    int split_mode = -1, split_place = 1;
+    int split_mode = -1, split_place = 2;
     int split_one = -1;                  // RLARM_SPLIT_ONE=1: the actor's tiles inside the split launch too (ONE launch per update): built, parity-green, 45.7 vs 39.2 us -- opt-in
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address

@@ -442,9 +442,12 @@ bool split_fits(const hp_agent *a) {
 }
 
 // Who runs where.  Workgroup b of the launch lands on XCD b % 8, and within an XCD in index order: chains first, then the spare
-// workgroups, the weight-gradient tiles last (they wait for chains).  place 0: every kind of chain spread evenly over the XCDs.
-// place 1: actor-side chains on XCDs 0-3 with the warmers and spare workgroups, target chains on XCDs 4-7, critic chains on
-// both halves -- an XCD then streams 4 of the 6 fragment sets (as Launch::xcd_split does for k_fb_slab8).
+// workgroups, the weight-gradient tiles last (they wait for chains).  RLARM_SPLIT_PLACE (us/update at batch 256, same box,
+// alternating runs): 0 = every kind of chain spread evenly over the XCDs (every L2 then streams all six fragment sets): 39.8;
+// 1 = actor-side chains on XCDs 0-3 with the warmers and spare workgroups, target chains on XCDs 4-7, critic chains on both
+// halves: 39.2; 2 (default) = the actor-side chains ALONE on XCDs 0-3 -- the launch's critical path keeps an L2 to itself, 16
+// streams per XCD like in k_fb_slab8 -- and every short chain on XCDs 4-7, whose 32 streams per XCD saturate their L2s
+// (the short chains end 1.5 us later: they have 10 us of slack): 38.3.
 static unsigned build_split_roles(const hp_agent *a, s8r4::FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
                                   int n_tiles) {
     using namespace s8r4;
@@ -454,8 +457,13 @@ static unsigned build_split_roles(const hp_agent *a, s8r4::FbSplitArgs &Q, bool 
     auto spread = [&](int role, int count, int x0, int nx) {   // evenly over XCDs x0 .. x0 + nx - 1, remainder to the first ones
         for (int i = 0; i < nx; ++i) n[x0 + i][role] += count / nx + (i < count % nx ? 1 : 0);
     };
-    const bool half = a->split_place == 1 && nslab % 8 == 0 && chains_ac && 3 * (nslab / 8) + 2 <= per_xcd;
-    if (half) {
+    const bool half = (a->split_place == 1 || a->split_place == 2) && nslab % 8 == 0 && chains_ac && 3 * (nslab / 8) + 2 <= per_xcd;
+    if (half && a->split_place == 2 && 2 * (nslab / 4) <= per_xcd) {
+        // place 2: the actor-side chains alone on XCDs 0-3 (as in k_fb_slab8), every short chain on XCDs 4-7
+        spread(SR_A, nslab, 0, 4);
+        spread(SR_C, nslab, 4, 4);
+        if (chains_t) spread(SR_T, nslab, 4, 4);
+    } else if (half) {
         if (chains_ac) { spread(SR_A, nslab, 0, 4); spread(SR_C, nslab, 0, 8); }
         if (chains_t) spread(SR_T, nslab, 4, 4);
     } else {

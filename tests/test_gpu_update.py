@@ -490,7 +490,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           # inside the chain launch; default where it fits) against the two-launch form, its other
                                           # placement, and forced on for the single-update tail of a sequence
                                           ("RLARM_SPLIT=0", 256), ("RLARM_SPLIT=0", 128), ("RLARM_SPLIT=0", 288), ("RLARM_SPLIT=0", 64),
-                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT_ONE=0", 256), ("RLARM_SPLIT_ONE=0", 128)])
+                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT_PLACE=1", 256), ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT_ONE=0", 256), ("RLARM_SPLIT_ONE=0", 128)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""

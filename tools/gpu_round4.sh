@@ -43,8 +43,8 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VA
   python tools/pmc_summary.py $d/pmc_results.db 2>&1 | grep "k_fb_\|k_gemm_lds" >> $O/pmc_sq_b256.txt
 done
 RLARM_LIB=$PWD/rl_arm_under_sparse_reward_amd/librlarm_hip_tl.so timeout 300 python tools/ubench/split_timeline.py > $O/split_timeline_b256.txt 2>&1
-tools/ubench/ab_env.sh "RLARM_SPLIT=0" "RLARM_SPLIT_PLACE=1" 3 > $O/ab_split_b256.txt 2>&1
+tools/ubench/ab_env.sh "RLARM_SPLIT=0" "RLARM_AB=default" 3 > $O/ab_split_b256.txt 2>&1
 tools/ubench/ab_env.sh "RLARM_SPLIT_ONE=0" "RLARM_SPLIT_ONE=1" 2 > $O/ab_split_one_launch_b256.txt 2>&1
-tools/ubench/ab_env.sh "RLARM_SPLIT_PLACE=0" "RLARM_SPLIT_PLACE=1" 2 > $O/ab_split_place_b256.txt 2>&1
+for pl in 0 1 2; do echo place $pl; tools/ubench/ab_env.sh "RLARM_SPLIT_PLACE=$pl" "RLARM_SPLIT_PLACE=2" 1; done > $O/ab_split_place_b256.txt 2>&1
 rm -rf $O/trace_b* $O/csv_b* $O/pmc_FETCH* $O/pmc_WRITE* $O/pmcs_* gpurun_out/pmct_*
 ls $O; cat $O/kernel_trace_b256_k4.txt | head -8; cat $O/pmc_fetch_write_b256.txt | grep "k_fb\|k_gemm"; head -c 600 $O/bench_n1_b256.json
