@@ -593,7 +593,7 @@ def main():
                 parts = line.split()
                 if len(parts) >= 6 and parts[0][0] != "#" and parts[-1].endswith("%"):
                     try:
-                        prof_avg.setdefault(parts[0].split("::")[-1].split("(")[0], float(parts[-4]))
+                        prof_avg.setdefault(parts[0].split("(")[0].split("::")[-1], float(parts[-4]))   # "s8r4::k_fb_split8(s8r4::FbSplitArgs)" -> k_fb_split8
                     except ValueError:
                         pass
         per = {}
