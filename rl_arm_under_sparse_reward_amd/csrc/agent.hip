@@ -112,7 +112,14 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_join, hipEventDisableTiming));
     }
     bool join_pending = false;
-    if (split) {   // Q' of the first update's minibatch (every later one is computed one launch ahead)
+    // split form: Q' of the FIRST update's minibatch comes from a prologue launch of target chains (every later one from the
+    // launch before).  Round 4 also built the alternative -- the first update's critic chains run k_fb_slab8's whole critic side
+    // and hand off to the tiles at their end, no prologue: 37.90 vs 37.92 us/update over cycles, 40.97 vs 41.14 in the driver's
+    // 20-step form, and an intermittent optimizer mismatch in the teacher-forced test that the prologue form never showed;
+    // removed.
+    if (split && a->split_one == 1)   // (opt-in one-launch form: no tile launch behind it that clears the counters)
+        HP_CHECK_HIP(hipMemsetAsync(a->k1_sync, 0, 2 * SPLIT_SET_WORDS * sizeof(unsigned), a->ctx->stream));
+    if (split) {
         GatherCtx g0{b, on, gn, a->plan.as<PlanRec>(), sq};
         HP_TRY(enqueue_split_prologue(a, &g0));
     }

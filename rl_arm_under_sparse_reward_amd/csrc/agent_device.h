@@ -44,6 +44,7 @@ struct AdamFuse {
     unsigned gate_sel;                // 4 bits per problem of the group: the counter its step waits for (SPLIT_CTR_NONE: none)
     unsigned *fault, *fault_host;
     unsigned long long gate_ticks;
+    unsigned *reset_sync;             // the launch BEHIND k_fb_split8: its workgroup 0 clears the counter set that launch counted in
     int tl_mark;                      // time-line builds: record this launch's gate stamps
 };
 

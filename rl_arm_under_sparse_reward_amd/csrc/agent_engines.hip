@@ -830,6 +830,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         AdamFuse Fa = adam_fuse(a);
         Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
         if (gc->polyak_after) fold_polyak(a, Fa);
+        Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
         hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
@@ -876,7 +877,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.grads_base = a->grads; F.st = a->d_state; F.scal = &a->d_state->neg_step_actor; F.am = arena_map(a); F.n_actor = a->la.total;
     F.keep_grads = 1;
     F.tgt = nullptr; F.fragFT = nullptr; F.polyak = 0.f; F.one_minus = 0.f;
-    F.gate = nullptr; F.gate_need = 0u; F.gate_sel = 0u; F.fault = nullptr; F.fault_host = nullptr; F.gate_ticks = 0ull; F.tl_mark = 0;
+    F.gate = nullptr; F.gate_need = 0u; F.gate_sel = 0u; F.fault = nullptr; F.fault_host = nullptr; F.gate_ticks = 0ull; F.reset_sync = nullptr; F.tl_mark = 0;
     F.w = (float)(1.0 - a->cfg.adam_beta1); F.b2 = (float)a->cfg.adam_beta2;
     F.omb2 = (float)(1.0 - a->cfg.adam_beta2); F.eps = (float)a->cfg.adam_eps;
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : S32_ROWS); F.B = a->B;

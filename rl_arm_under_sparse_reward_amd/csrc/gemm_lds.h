@@ -193,6 +193,8 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     const int tid = threadIdx.x, wave = UNI ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     GL_STAMP(0);
     if (ADAM && finalize_loss && tid < 64) loss_finalize(*F);
+    if (ADAM && finalize_loss && tid >= 64 && tid < 64 + SPLIT_COUNTERS * 8 && F->reset_sync)   // the launch BEHIND a split launch clears
+        __hip_atomic_store(F->reset_sync + (tid - 64) * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the set that launch counted in
     const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32, vn = (p.N - n0) < 32 ? (p.N - n0) : 32;
     const bool a_rowk = (p.a_sk == 1), b_rowk = (p.b_sk == 1);
     float *ldsA = lds, *ldsB = lds + GL_OPERAND_FLOATS;
