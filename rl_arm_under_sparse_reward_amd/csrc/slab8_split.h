@@ -154,6 +154,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     unsigned long long *tl = nullptr;
 #ifdef SLAB_TIMELINE
     if (slab == 0 && role <= SR_T) tl = A.tl + role * 32;
+    if (role == SR_A && slab == nslab / 4) tl = A.tl + 96;   // the first actor-side chain of the SECOND XCD that holds them (placement 1 / 2)
 #endif
     const SlabNetPtrs &on = A.online;
     if (role == SR_PLAN) {   // the index-plan workgroup ends here (ended waves take no part in barriers)

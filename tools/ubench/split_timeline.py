@@ -51,8 +51,12 @@ for role, nm in enumerate(names):
         if role != 6 and k in (2, 5): continue
         v = [(r[1][k] - base) / 100 for r in sel if r[1][k]]
         if v: print(f"[split] {nm:26s} {kn:15s} {stat(v)}")
+for role, nm in ((0, "A"), (1, "C"), (2, "T")):      # by XCD: is the spread of a role's end times a property of the XCD it runs on?
+    for x in range(8):
+        v = [(r[1][3] - base) / 100 for r in rows if r[1][4] == role and r[0] % 8 == x and r[1][0] >= base - 200]
+        if v: print(f"[split by XCD] {nm} chains on XCD {x}: n={len(v):2d} end min {min(v):6.2f} med {st.median(v):6.2f} max {max(v):6.2f}")
 tl = (C.c_uint64 * 192)(); _lib.check(lib.hp_agent_debug_timeline(h, tl))
-for ch, nm in ((0, "A chain slab 0"), (1, "C chain slab 0"), (2, "T chain slab 0")):
+for ch, nm in ((0, "A chain slab 0"), (3, "A chain, first slab of the next XCD"), (1, "C chain slab 0"), (2, "T chain slab 0")):
     v = [tl[ch * 32 + k] for k in range(32)]
     if v[0]: print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(32) if v[k]))
 try:
