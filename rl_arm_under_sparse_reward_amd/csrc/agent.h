@@ -404,7 +404,7 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     int peer_u = -1;
     const PlanRec *t_plan = nullptr;
 };
-#define SPLIT_MIN_UPDATES 4   // shorter sequences keep the two-launch form (the target prologue would cost more than it saves)
+#define SPLIT_MIN_UPDATES 12  // shorter sequences keep the two-launch form: the prologue launch costs ~17 us per sequence, an update gains ~1.4
 
 // workgroups of the chain kernel that carry chains (the spare ones -- index plan, look-ahead gather, L2 warmers -- follow)
 static inline int chain_wgs(const hp_agent *a) { return 2 * (a->Mp / a->s8_rows); }
@@ -423,6 +423,7 @@ int enqueue_forward_backward(hp_agent *a, const GatherCtx *gc = nullptr, bool fu
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only = 0);
 // split launch: does this agent's shape fit it (4-row slabs, three kinds of chains + spare workgroups on the CUs)?
 bool split_fits(const hp_agent *a);
+bool split_fits_rows(const hp_agent *a, int rows);
 // ... and its prologue: the target chains of a sequence's FIRST update (plan = that update's index plan) into Q' set 0
 int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc);
 // a bounded in-launch hand-off gave up earlier (k_cycle_open, k_fb_split8): HP_ERR_STATE + message; free for the host

@@ -326,7 +326,14 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // at 448, 47.5 vs 49.6 at 480, 48.4 vs 49.9 at 512 (256 chains: the look-ahead then rides in the weight-gradient
         // launch), 73.4 vs 52.0 at 544 (two rounds); 8 vs 16 rows 59.1 vs 81.4 at 1024, 98.3 vs 90.9 at 1280.
         const int cus = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
+        auto tri = [](const char *name) { const char *e = getenv(name); return e ? (e[0] != '0' ? 1 : 0) : -1; };
         a->s8_rows = 2 * (a->Mp / 4) <= cus ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
+        // Round 4: where the split launch (slab8_split.h) does not fit with 4-row slabs but does with 8-row ones (batch 321-640: the
+        // per-GPU shape of BASELINE config 5), take 8 rows: three kinds of 8-row chains leave CUs idle for the critic's tiles and
+        // spare workgroups, where 256 four-row chains saturate the L2s (measured at batch 512 k8: see DESIGN.md 3.3)
+        if (a->slab8 && tri("RLARM_SPLIT") != 0 && a->s8_rows == 4 && !split_fits_rows(a, 4) && split_fits_rows(a, 8) &&
+            (tri("RLARM_SPLIT8") != 0))
+            a->s8_rows = 8;
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;
@@ -334,7 +341,6 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         }
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');
-        auto tri = [](const char *name) { const char *e = getenv(name); return e ? (e[0] != '0' ? 1 : 0) : -1; };
         a->gemm_xcd = tri("RLARM_GEMM_XCD") != 0;
         a->fb_xcd = tri("RLARM_FB_XCD");
         a->fb_prefetch = tri("RLARM_FB_PREFETCH");

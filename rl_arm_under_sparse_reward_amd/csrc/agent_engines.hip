@@ -429,16 +429,20 @@ static int dw64_args(hp_agent *a, const Launch &L, Dw64Args &X) {
 // ---- split launch (slab8_split.h) ------------------------------------------------------------------------------------------
 static int split_warmers(const hp_agent *a) {   // L2 warmers per XCD that still fit beside three kinds of chains + the spare workgroups
     const int per_xcd = a->ctx->cu_count / 8;
-    const int nslab = a->Mp / 4;
+    const int nslab = a->Mp / a->s8_rows;
     const int chains = 3 * ((nslab + 7) / 8) + 1;   // worst XCD: its share of every kind of chain + a plan / gather workgroup
     return per_xcd - chains >= 2 ? 2 : (per_xcd - chains >= 1 ? 1 : 0);
 }
-bool split_fits(const hp_agent *a) {
-    if (!a->slab8 || a->s8_rows != 4 || a->dw64 || !a->fuse_adam_ok || a->comm || a->peer) return false;
-    if (a->Mp < GL_RING_MIN_K || a->dw_ksplit > 1) return false;   // the in-launch tiles take the ring path, unsplit
-    if (a->ctx->cu_count % 8 != 0) return false;
-    const int per_xcd = a->ctx->cu_count / 8, nslab = a->Mp / 4;
+// three kinds of chains of `rows`-row slabs + a plan / gather workgroup per XCD on this device's CUs?
+bool split_fits_rows(const hp_agent *a, int rows) {
+    if (a->ctx->cu_count % 8 != 0 || (rows != 4 && rows != 8)) return false;
+    const int per_xcd = a->ctx->cu_count / 8, nslab = a->Mp / rows;
     return 3 * ((nslab + 7) / 8) + 1 <= per_xcd;
+}
+bool split_fits(const hp_agent *a) {
+    if (!a->slab8 || a->dw64 || !a->fuse_adam_ok || a->comm || a->peer) return false;
+    if (a->Mp < GL_RING_MIN_K || a->dw_ksplit > 1) return false;   // the in-launch tiles take the ring path, unsplit
+    return split_fits_rows(a, a->s8_rows);
 }
 
 // Who runs where.  Workgroup b of the launch lands on XCD b % 8, and within an XCD in index order: chains first, then the spare
@@ -448,10 +452,9 @@ bool split_fits(const hp_agent *a) {
 // halves: 39.2; 2 (default) = the actor-side chains ALONE on XCDs 0-3 -- the launch's critical path keeps an L2 to itself, 16
 // streams per XCD like in k_fb_slab8 -- and every short chain on XCDs 4-7, whose 32 streams per XCD saturate their L2s
 // (the short chains end 1.5 us later: they have 10 us of slack): 38.3.
-static unsigned build_split_roles(const hp_agent *a, s8r4::FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
+static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
                                   int n_tiles) {
-    using namespace s8r4;
-    const int nslab = a->Mp / 4, per_xcd = a->ctx->cu_count / 8;
+    const int nslab = a->Mp / a->s8_rows, per_xcd = a->ctx->cu_count / 8;
     int n[8][SR_N];
     memset(n, 0, sizeof(n));
     auto spread = [&](int role, int count, int x0, int nx) {   // evenly over XCDs x0 .. x0 + nx - 1, remainder to the first ones
@@ -743,7 +746,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
 
 // ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step [+ the actor's]), then -- in
 // the two-launch form -- the actor's tiles
-static void split_common(hp_agent *a, s8r4::FbSplitArgs &Q, int set) {
+static void split_common(hp_agent *a, FbSplitArgs &Q, int set) {
     Q.sync = a->k1_sync + (set & 1) * SPLIT_SET_WORDS;
     Q.sync_other = a->k1_sync + ((set + 1) & 1) * SPLIT_SET_WORDS;
     Q.fault = a->k1_sync + SPLIT_FAULT;
@@ -757,8 +760,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     hipStream_t s = a->ctx->stream;
     FbSlabArgs &P = built.P;
     const int xs = built.xs, nslab = built.nslab;
-    static s8r4::FbSplitArgs Qz;   // zero template (the struct has padding the kernel never reads)
-    s8r4::FbSplitArgs Q = Qz;
+    static FbSplitArgs Qz;   // zero template (the struct has padding the kernel never reads)
+    FbSplitArgs Q = Qz;
     P.n_plan = built.ride ? 1 : 0;
     P.n_ahead = 0;
     P.xcd_split = 0;
@@ -821,7 +824,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
-        hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
+        if (a->s8_rows == 4) hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
+        else hipLaunchKernelGGL(s8r8::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
     if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
@@ -847,8 +851,8 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     g0.rng = nullptr;
     build_fb_args(a, &g0, built);
     FbSlabArgs &P = built.P;
-    static s8r4::FbSplitArgs Qz;
-    s8r4::FbSplitArgs Q = Qz;
+    static FbSplitArgs Qz;
+    FbSplitArgs Q = Qz;
     P.n_plan = P.n_ahead = P.xcd_split = P.n_pref = 0;
     P.ahead = P.f.gs;
     P.aXT = P.aXA = P.aXP = nullptr;
@@ -866,7 +870,8 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
     ProfScope ps(a, PROF_PLAN);   // (once per sequence, with the index draws: not an update's launch)
-    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
+    if (a->s8_rows == 4) hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
+    else hipLaunchKernelGGL(s8r8::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -1258,9 +1263,9 @@ int hp_debug_split_timeline(uint64_t *out5120) {
     HP_CHECK_HIP(hipDeviceSynchronize());
     static unsigned long long tl[1024][4], gate[1024][2];
     static int role[1024];
-    HP_CHECK_HIP(hipMemcpyFromSymbol(tl, HIP_SYMBOL(s8r4::g_split_tl), sizeof(tl)));
+    HP_CHECK_HIP(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_split_tl), sizeof(tl)));
     HP_CHECK_HIP(hipMemcpyFromSymbol(gate, HIP_SYMBOL(g_split_tl_gate), sizeof(gate)));
-    HP_CHECK_HIP(hipMemcpyFromSymbol(role, HIP_SYMBOL(s8r4::g_split_role), sizeof(role)));
+    HP_CHECK_HIP(hipMemcpyFromSymbol(role, HIP_SYMBOL(g_split_role), sizeof(role)));
     for (int b = 0; b < 1024; ++b) {
         out5120[5 * b + 0] = tl[b][0]; out5120[5 * b + 1] = tl[b][1]; out5120[5 * b + 2] = gate[b][0]; out5120[5 * b + 3] = tl[b][3];
         out5120[5 * b + 4] = (uint64_t)role[b] | (gate[b][1] << 8);   // role | gate passed << 8 (the stamps are < 2^56)

@@ -99,6 +99,8 @@ struct PolicyArgs {
     float *actions;               // [rows][act_dim]
 };
 
+#include "slab8_split_args.h"
+
 #endif  // RLARM_SLAB8_SHARED
 
 // ---- everything below is compiled once per slab height: S8_NRG row groups of 4 (S8_NRG = 1: 4-row slabs, the
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 #endif
 
-#if S8_NRG == 1
+#if S8_NRG <= 2   // the split launch exists for 4- and 8-row slabs (batch <= 320 / <= 640)
 #include "slab8_split.h"
 #endif
 

@@ -489,16 +489,20 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           # round 4: the split launch (target chains one update ahead, critic tiles + optimizer
                                           # inside the chain launch; default where it fits) against the two-launch form, its other
                                           # placement, and forced on for the single-update tail of a sequence
-                                          ("RLARM_SPLIT=0", 256), ("RLARM_SPLIT=0", 128), ("RLARM_SPLIT=0", 288), ("RLARM_SPLIT=0", 64),
-                                          ("RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT_PLACE=1", 256), ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT_ONE=0", 256), ("RLARM_SPLIT_ONE=0", 128)])
+                                          # (the 4-update sequences of this test take the two-launch form by default: the split
+                                          # launch is forced on, alone and with its other placements / the one-launch form)
+                                          ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT=1", 128), ("RLARM_SPLIT=1", 288), ("RLARM_SPLIT=1", 64),
+                                          ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=1", 256),
+                                          ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 128)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
     torch.manual_seed(0)
     ref_agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     want = _run_cycles(ref_agent, graph=True)
-    k, v = switch.split("=")
-    monkeypatch.setenv(k, v)          # read by hp_agent_create
+    for assignment in switch.split(","):
+        k, v = assignment.split("=")
+        monkeypatch.setenv(k, v)      # read by hp_agent_create
     torch.manual_seed(0)
     agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     got = _run_cycles(agent, graph=True)
@@ -531,9 +535,12 @@ def test_split_launch_is_bit_identical(batch, n_updates, monkeypatch):
     got = run()
     monkeypatch.setenv("RLARM_SPLIT", "1")
     forced = run()
-    monkeypatch.setenv("RLARM_SPLIT_ONE", "0")       # the actor's tiles as a launch of their own behind the split launch
-    two = run()
-    for other in (got, forced, two):
+    monkeypatch.setenv("RLARM_SPLIT_ONE", "1")       # opt-in: the actor's tiles inside the split launch too (one launch per update)
+    one = run()
+    monkeypatch.setenv("RLARM_SPLIT_PLACE", "1")
+    monkeypatch.delenv("RLARM_SPLIT_ONE")
+    placed = run()
+    for other in (got, forced, one, placed):
         for a, b in zip(want, other):
             assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
