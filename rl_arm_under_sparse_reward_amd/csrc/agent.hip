@@ -328,12 +328,9 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         const int cus = a->ctx->cu_count > 0 ? a->ctx->cu_count : 256;
         auto tri = [](const char *name) { const char *e = getenv(name); return e ? (e[0] != '0' ? 1 : 0) : -1; };
         a->s8_rows = 2 * (a->Mp / 4) <= cus ? 4 : (2 * (a->Mp / 8) <= cus ? 8 : 16);
-        // Round 4: where the split launch (slab8_split.h) does not fit with 4-row slabs but does with 8-row ones (batch 321-640: the
-        // per-GPU shape of BASELINE config 5), take 8 rows: three kinds of 8-row chains leave CUs idle for the critic's tiles and
-        // spare workgroups, where 256 four-row chains saturate the L2s (measured at batch 512 k8: see DESIGN.md 3.3)
-        if (a->slab8 && tri("RLARM_SPLIT") != 0 && a->s8_rows == 4 && !split_fits_rows(a, 4) && split_fits_rows(a, 8) &&
-            (tri("RLARM_SPLIT8") != 0))
-            a->s8_rows = 8;
+        // (Round 4 also compiled the split launch for 8-row slabs and took them where three kinds of 4-row chains do not fit the CUs:
+        // batch 384 k8: 44.7 vs 41.1 us/update with 4-row slabs in two launches, 512 k8: 45.6 vs 44.5, 640: 47.4 vs 47.4 -- an 8-row
+        // layer is matrix-issue bound at 2.6-3.0 us, so the actor side gets longer, not shorter.  Removed)
         if (const char *sr = getenv("RLARM_SLAB_ROWS")) {
             if (strcmp(sr, "4") == 0) a->s8_rows = 4;
             if (strcmp(sr, "8") == 0) a->s8_rows = 8;

@@ -435,7 +435,7 @@ static int split_warmers(const hp_agent *a) {   // L2 warmers per XCD that still
 }
 // three kinds of chains of `rows`-row slabs + a plan / gather workgroup per XCD on this device's CUs?
 bool split_fits_rows(const hp_agent *a, int rows) {
-    if (a->ctx->cu_count % 8 != 0 || (rows != 4 && rows != 8)) return false;
+    if (a->ctx->cu_count % 8 != 0 || rows != 4) return false;   // (the kernel is compiled for 4-row slabs only)
     const int per_xcd = a->ctx->cu_count / 8, nslab = a->Mp / rows;
     return 3 * ((nslab + 7) / 8) + 1 <= per_xcd;
 }
@@ -824,8 +824,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
-        if (a->s8_rows == 4) hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
-        else hipLaunchKernelGGL(s8r8::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
+        hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
     if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
@@ -870,8 +869,7 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
     ProfScope ps(a, PROF_PLAN);   // (once per sequence, with the index draws: not an update's launch)
-    if (a->s8_rows == 4) hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
-    else hipLaunchKernelGGL(s8r8::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
+    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }

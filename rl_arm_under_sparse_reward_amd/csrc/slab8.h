@@ -906,7 +906,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 #endif
 
-#if S8_NRG <= 2   // the split launch exists for 4- and 8-row slabs (batch <= 320 / <= 640)
+#if S8_NRG == 1   // the split launch exists for 4-row slabs (8-row: built, measured, lost -- agent.hip at the slab-height table)
 #include "slab8_split.h"
 #endif
 
