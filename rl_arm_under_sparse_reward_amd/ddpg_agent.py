@@ -249,6 +249,10 @@ class ddpg_agent:
         if n_updates is None:
             if self._defer_updates and (not self.comm.active or self._native_comm is not None or self._peer is not None):
                 with _lib.pending_lock:
+                    if self._pending_updates == 0:      # where the first of these deferred calls was made: named if their flush fails
+                        import sys
+                        f = sys._getframe(1)
+                        self._pending_site = f"{f.f_code.co_filename}:{f.f_lineno}"
                     self._pending_updates += 1
                     if self._pending_updates >= int(self.args.n_batches):
                         self._flush_updates()
@@ -275,7 +279,8 @@ class ddpg_agent:
                 except Exception as e:
                     self._pending_updates += n                 # nothing of this chunk was enqueued: still owed
                     _lib.register_pending(self)
-                    note = f"deferred _update_network() x {n} (issued by a later library call, _lib.py 'deferred updates')"
+                    note = (f"deferred _update_network() x {n}, first called at {getattr(self, '_pending_site', '?')} "
+                            "(issued by a later library call, _lib.py 'deferred updates')")
                     if hasattr(e, "add_note"):
                         e.add_note(note)
                         raise

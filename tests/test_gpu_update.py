@@ -765,7 +765,7 @@ def test_a_failing_deferred_update_names_itself_and_stays_owed():
     agent._update_network()
     other._update_network()
     assert agent._pending_updates == 2 and other._pending_updates == 1
-    with pytest.raises(ValueError, match=r"high <= 0.*deferred _update_network\(\) x 2"):
+    with pytest.raises(ValueError, match=r"high <= 0.*deferred _update_network\(\) x 2, first called at .*test_gpu_update\.py:\d+"):
         agent.o_norm.mean                                # an unrelated library call triggers the flush
     assert agent._pending_updates == 2                   # still owed, not dropped
     assert other._pending_updates in (0, 1)              # issued, or still registered -- never lost
