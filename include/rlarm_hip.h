@@ -346,9 +346,7 @@ int hp_agent_train_cycle_pinned(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, h
 int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *dw_split);
 /* Launch structure of a sequence of n_updates sampled updates (ddpg_agent.py:145-147) on this agent: *form = 0 chain launch +
  * weight-gradient launch per update; 1 split launch (target networks one update ahead, the critic's weight gradients + Adam inside
- * the chain launch) + the actor's weight-gradient launch; 2 the split launch holds the actor's tiles too (one launch per update);
- * 3 the split launch of update u carries the actor's weight gradients + Adam of update u - 1 at its head (one launch per update,
- * one actor launch behind the sequence's last). */
+ * the chain launch) + the actor's weight-gradient launch; 2 the split launch holds the actor's tiles too (one launch per update). */
 int hp_agent_update_form(hp_agent *ag, int32_t n_updates, int32_t *form);
 /* Sticky health word of the learner, free for the host (pinned memory, no synchronisation): 0 = healthy.  Bit 0: a bounded
  * in-launch hand-off gave up (bits 4-7: which -- 1 critic chains -> weight-gradient tiles, 2 actor chains -> critic optimizer

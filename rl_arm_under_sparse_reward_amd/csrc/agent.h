@@ -60,8 +60,6 @@ struct GemmGroup {
     int n;
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
     int uni;    // ring loop with the wave index in a scalar register (gemm_lds.h)
-    int bias0;  // > 0: the bias gradients + their optimizer step run in workgroups of their own from this index on (one per
-                // 32-row panel of every problem that has a bias vector: gemm_lds.h gemm_bias_tile); the tiles then skip them
     float *part;                  // split tiles: GL_PART floats per (tile, slice)
     unsigned long long *ticket;   // split tiles: arrival counter per tile, monotonic over the life of the agent
     GemmProb p[MAX_PROBS];
@@ -77,9 +75,6 @@ struct AgentDevState {      // small device-resident scalars
     // per-step Adam scalars (torch computes them in Python doubles and narrows where used)
     float neg_step_actor, neg_step_critic, bc2_sqrt;
     unsigned open_timeouts; // k_cycle_open: hand-off polls that gave up (always 0; reported by hp_agent_get_losses)
-    // split launch (slab8_split.h): the same three scalars per update PARITY -- in the carry form a launch holds the actor's tiles
-    // of update u - 1 (set (u - 1) % 2) next to the chain that prepares update u's (set u % 2)
-    float scal2[2][4];
 };
 
 struct AdamCfg {
@@ -100,8 +95,7 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 // other one for its successor) of SPLIT_COUNTERS counters x 8 XCD copies, SPLIT_CTR_STRIDE words apart, then the learner's
 // sticky fault word
 #define SPLIT_CTR_STRIDE 64          // 256 bytes: another memory channel
-#define SPLIT_COUNTERS 8             // 0-2 stages of the critic chains, 3-5 gates of the actor-side chains, 6 actor-side chains done,
-                                     // 7 carried tiles (the actor's weight gradients + optimizer step of the update BEFORE) done
+#define SPLIT_COUNTERS 8             // 0-2 stages of the critic chains, 3-5 gates of the actor-side chains, 6 actor-side chains done
 #define SPLIT_CTR_NONE 15u           // "no counter" in the 4-bit per-problem tables
 #define SPLIT_SET_WORDS (SPLIT_COUNTERS * 8 * SPLIT_CTR_STRIDE)
 #define SPLIT_FAULT (2 * SPLIT_SET_WORDS)
@@ -239,7 +233,6 @@ struct hp_agent {
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
     // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
     int split_mode = -1, split_place = 2;
-    int split_carry = -1;                // RLARM_SPLIT_CARRY=1: the actor's tiles of update u - 1 at the head of update u's split launch (one launch per update): built, parity-green, 40.9 vs 38.6 us -- opt-in
     int split_one = -1;                  // RLARM_SPLIT_ONE=1: the actor's tiles inside the split launch too (ONE launch per update): built, parity-green, 45.7 vs 39.2 us -- opt-in
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
@@ -293,19 +286,10 @@ struct Launch {  // builds one grouped launch
         g.n = 0;
         g.xcd = 0;
         g.uni = 0;
-        g.bias0 = 0;
         g.part = nullptr;
         g.ticket = nullptr;
     }
     int split_tiles = 0;   // tiles whose reduction is split (entries of part / ticket in use)
-    // bias vectors in workgroups of their own behind the tiles (call last); returns how many
-    int separate_bias() {
-        int nb = 0;
-        for (int i = 0; i < g.n; ++i)
-            if (g.p[i].bias_grad) nb += (g.p[i].M + 31) / 32;
-        g.bias0 = tiles;
-        return nb;
-    }
     // split the reduction of the problem added last over `ks` workgroups per tile
     void split_last(int ks) {
         GemmProb &p = g.p[g.n - 1];
@@ -416,9 +400,6 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     // NEXT update, whose Q' the target chains of this launch compute into the other set (nullptr: last update of the sequence)
     bool split = false;
     int qset = 0;
-    // carry form of the split launch: the actor's tiles of update u - 1 run at the head of update u's launch; the sequence's
-    // last update is followed by the stand-alone tile launch
-    bool carry = false, seq_first = false, seq_last = false;
     // data-parallel ranks, tile-wise exchange: index of this update in its sequence (the exchange epoch), -1: not this form
     int peer_u = -1;
     const PlanRec *t_plan = nullptr;

@@ -127,9 +127,6 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
         gc.split = split;
         gc.qset = u & 1;
-        gc.carry = split && a->split_carry == 1;
-        gc.seq_first = u == 0;
-        gc.seq_last = u == n_updates - 1;
         gc.t_plan = (split && u + 1 < n_updates) ? a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B : nullptr;
         hipStream_t ms = a->ctx->stream;
         if (join_pending) {   // the plan drawn beside the previous update is what this launch gathers from
@@ -305,7 +302,7 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
     A(&a->dP3, Mp * H); A(&a->dP2, Mp * H); A(&a->dP1, Mp * H); A(&a->dXP, Mp * ldx);
     A(&a->dZ, Mp * 16); A(&a->dK3, Mp * H); A(&a->dK2, Mp * H); A(&a->dK1, Mp * H);
     A(&a->loss_log, LOSS_LOG * 2);
-    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 2 * 3 * (Mp / 4));   // (two sets: split launch, per update parity)
+    A(&a->fragF, a->n_arena); A(&a->fragD, a->n_arena); A(&a->fragFT, a->n_arena); A(&a->part, 3 * (Mp / 4));
     {
         // RLARM_ENGINE = slab8 | slab32 | layers overrides the table below (A/B runs, debugging)
         const char *e = getenv("RLARM_ENGINE");
@@ -349,7 +346,6 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
         a->split_mode = tri("RLARM_SPLIT");
         a->split_one = tri("RLARM_SPLIT_ONE");
-        a->split_carry = tri("RLARM_SPLIT_CARRY");
         if (const char *sp = getenv("RLARM_SPLIT_PLACE")) a->split_place = atoi(sp);
         a->gl_uni = tri("RLARM_GEMM_UNI");
         a->adam_wt = tri("RLARM_ADAM_WT");
@@ -843,15 +839,14 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 
 // which launch structure a sequence of n_updates sampled updates takes on this agent: 0 = chain launch + weight-gradient launch,
 // 1 = split launch (slab8_split.h: target chains one update ahead, the critic's tiles + optimizer step inside the chain launch)
-// + the actor's tile launch, 2 = split launch holding the actor's tiles as well (one launch per update), 3 = split launch
-// carrying the actor's tiles of the update BEFORE at its head (one launch per update + one tile launch per sequence)
+// + the actor's tile launch, 2 = split launch holding the actor's tiles as well (one launch per update)
 int hp_agent_update_form(hp_agent *a, int32_t n_updates, int32_t *form) {
     HP_REQUIRE(a && form, HP_ERR_INVALID, "hp_agent_update_form: null argument");
     const int chains = chain_wgs(a);
     const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
     const bool split = a->slab8 && a->gather_ahead && !full && a->plan_side <= 0 && split_fits(a) &&
                        (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
-    *form = split ? (a->split_one == 1 ? 2 : (a->split_carry == 1 ? 3 : 1)) : 0;
+    *form = split ? (a->split_one == 1 ? 2 : 1) : 0;
     return HP_OK;
 }
 

@@ -86,6 +86,36 @@ __device__ __forceinline__ bool adam_gate_wait(const AdamFuse &F, int prob, int 
 }
 
 
+// AGENT: the step scalars were written (write-through) by a workgroup of the SAME launch: agent-scope loads
+template <bool AGENT>
+__device__ __forceinline__ float adam_scal(const AdamFuse &F, int i) {
+    if constexpr (AGENT) return __hip_atomic_load(F.scal + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return F.scal[i];
+}
+template <bool AGENT = false>
+__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
+    const float neg_step_size = adam_scal<AGENT>(F, idx < F.n_actor ? 0 : 1);
+    const float bc2_sqrt = adam_scal<AGENT>(F, 2);
+    float mi = F.m[idx], vi = F.v[idx];
+    mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
+    vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
+    const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
+    const float pn = __fadd_rn(F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
+    F.p_out[idx] = pn;
+    F.m[idx] = mi;
+    F.v[idx] = vi;
+    int of, od;
+    frag_offsets_any(F.am, idx, of, od);
+    if (of >= 0) F.fragF[of] = pn;
+    if (od >= 0) F.fragD[od] = pn;
+    if (F.tgt) {   // same expression as k_polyak_frag
+        const float t = __fadd_rn(__fmul_rn(F.one_minus, pn), __fmul_rn(F.polyak, F.tgt[idx]));
+        F.tgt[idx] = t;
+        if (of >= 0) F.fragFT[of] = t;
+    }
+}
+
 // write-through (sc1) stores: visible to other XCDs once drained (s_waitcnt vmcnt(0)); readers use agent-scope loads
 __device__ __forceinline__ void wt_store(float *p, float v) {   // write-through (sc1) store: visible to other XCDs once drained
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -96,49 +126,6 @@ __device__ __forceinline__ void wt_store4(float *p, const float4 v) {
     // asm statement -- without it the next instruction may overwrite x before the store has read it (cdna_hip_programming.md
     // 5.7 item 1; found when an experiment put this store in front of arithmetic that reused the registers: NaNs)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-}
-
-// optimizer state of ONE element fetched ahead (gemm_bias_tile: cold loads that otherwise sit behind the reduction)
-struct AdamState1 {
-    float p, m, v;
-};
-
-// AGENT: the step scalars were written (write-through) by a workgroup of the SAME launch: agent-scope loads
-template <bool AGENT>
-__device__ __forceinline__ float adam_scal(const AdamFuse &F, int i) {
-    if constexpr (AGENT) return __hip_atomic_load(F.scal + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return F.scal[i];
-}
-template <bool AGENT = false>
-__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi, const AdamState1 *pre = nullptr) {
-    const float neg_step_size = adam_scal<AGENT>(F, idx < F.n_actor ? 0 : 1);
-    const float bc2_sqrt = adam_scal<AGENT>(F, 2);
-    float mi = pre ? pre->m : F.m[idx], vi = pre ? pre->v : F.v[idx];
-    mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
-    vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
-    const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
-    const float pn = __fadd_rn(pre ? pre->p : F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
-    int of, od;
-    frag_offsets_any(F.am, idx, of, od);
-    if (F.wt) {   // write-through like adam_apply4 (and what the carry form of the split launch needs: readers on other XCDs in the SAME launch)
-        wt_store(F.p_out + idx, pn);
-        wt_store(F.m + idx, mi);
-        wt_store(F.v + idx, vi);
-        if (of >= 0) wt_store(F.fragF + of, pn);
-        if (od >= 0) wt_store(F.fragD + od, pn);
-    } else {
-        F.p_out[idx] = pn;
-        F.m[idx] = mi;
-        F.v[idx] = vi;
-        if (of >= 0) F.fragF[of] = pn;
-        if (od >= 0) F.fragD[od] = pn;
-    }
-    if (F.tgt) {   // same expression as k_polyak_frag
-        const float t = __fadd_rn(__fmul_rn(F.one_minus, pn), __fmul_rn(F.polyak, F.tgt[idx]));
-        F.tgt[idx] = t;
-        if (of >= 0) F.fragFT[of] = t;
-    }
 }
 
 // four consecutive arena elements at once (idx0 a multiple of 4): one vector load per state array, so the cold-cache
@@ -156,15 +143,13 @@ __device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, in
     S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
     S.v = *reinterpret_cast<const float4 *>(F.v + idx0);
 }
-// pn_out: the caller stores the dX-fragment copy itself from the stepped parameters handed back here (gemm_tile: whole lines
-// through an LDS transpose instead of 4 dwords 16 B apart per thread)
-__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S, float *pn_out = nullptr);
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S);
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
     AdamState4 S;
     adam_fetch4(S, F, idx0);
     adam_apply4(F, idx0, g, S);
 }
-__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S, float *pn_out) {
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S) {
     const float neg_step_size = S.neg_step_size;
     const float bc2_sqrt = S.bc2_sqrt;
     const float4 p4 = S.p, m4 = S.m, v4 = S.v;
@@ -210,10 +195,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
             else *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
         }
         if (of >= 0 && F.tgt) *reinterpret_cast<float4 *>(F.fragFT + of) = make_float4(tt[0], tt[1], tt[2], tt[3]);
-        if (od >= 0 && pn_out) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pn_out[j] = pp[j];
-        } else if (od >= 0) {
+        if (od >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (F.wt) wt_store(F.fragD + od + 4 * j, pp[j]);

@@ -453,7 +453,7 @@ bool split_fits(const hp_agent *a) {
 // streams per XCD like in k_fb_slab8 -- and every short chain on XCDs 4-7, whose 32 streams per XCD saturate their L2s
 // (the short chains end 1.5 us later: they have 10 us of slack): 38.3.
 static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
-                                  int n_tiles, int n_carry = 0) {
+                                  int n_tiles) {
     const int nslab = a->Mp / a->s8_rows, per_xcd = a->ctx->cu_count / 8;
     int n[8][SR_N];
     memset(n, 0, sizeof(n));
@@ -473,28 +473,13 @@ static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains
         if (chains_ac) { spread(SR_A, nslab, 0, 8); spread(SR_C, nslab, 0, 8); }
         if (chains_t) spread(SR_T, nslab, 0, 8);
     }
-    // carried tiles (the actor's, of the update before): on the CUs the actor-side chains leave, in proportion -- the short chains
-    // come behind them in the dispatch order and start when they have ended
-    if (n_carry > 0) {
-        int room[8], total = 0, given = 0;
-        for (int x = 0; x < 8; ++x) {
-            room[x] = per_xcd - n[x][SR_A] > 0 ? per_xcd - n[x][SR_A] : 0;
-            total += room[x];
-        }
-        for (int x = 0; x < 8; ++x) {
-            n[x][SR_ATILE] = total ? n_carry * room[x] / total : 0;
-            given += n[x][SR_ATILE];
-        }
-        for (int x = 7; given < n_carry; x = (x + 7) % 8) { n[x][SR_ATILE] += 1; ++given; }
-    }
     for (int i = 0; i < n_plan; ++i) n[i % (half ? 4 : 8)][SR_PLAN] += 1;
     for (int i = 0; i < n_ahead; ++i) n[(n_plan + i) % (half ? 4 : 8)][SR_AHEAD] += 1;
     int warm = a->fb_prefetch == 0 ? 0 : split_warmers(a);
     Q.warm_side = 0u;
     for (int x = 0; x < 8; ++x) {
-        int used = 0;   // (the carried tiles are gone when the warmers matter: not counted)
-        for (int r = 0; r < SR_N; ++r)
-            if (r != SR_WARM && r != SR_TILE && r != SR_ATILE) used += n[x][r];
+        int used = 0;
+        for (int r = 0; r < SR_WARM; ++r) used += n[x][r];
         const int w = (per_xcd - used) < warm ? (per_xcd - used > 0 ? per_xcd - used : 0) : warm;
         n[x][SR_WARM] = (!chains_ac && !chains_t) ? 0 : w;
         // what this XCD's chains stream: 1 = the actor side's sets, 0 = the critic side's (targets + critic), 2 = all
@@ -799,11 +784,6 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     Q.qt_in = gc->qset ? a->QT2 : a->QT;
     Q.qt_out = gc->qset ? a->QT : a->QT2;
     split_common(a, Q, gc->qset);
-    // step scalars and loss partials per update parity (the carry form reads the previous update's beside this one's)
-    const int set = gc->qset & 1;
-    const size_t part_words = 3 * (size_t)(a->Mp / 4);
-    Q.scal_set = set;
-    P.b.part = a->part + set * part_words;
     const bool one = split_one_launch(a);
     // tile problems in the order their operands are published: the critic's W3, W4 (stage 0), W2 (stage 1), W1 (stage 2), then
     // the actor's (counter 6: every actor-side chain has ended).  Gates of the optimizer steps: W3c after the actor-side chains'
@@ -826,19 +806,12 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         L.g.n += La.g.n;
         L.tiles += La.tiles;
     }
-    // bias vectors in workgroups of their own behind the tiles (gemm_bias_tile): with ~one tile per CU the tiles that carried them
-    // were each launch's tail.  RLARM_SPLIT_BIAS=0: inside the tn == 0 tiles as in the two-launch form (same bits either way)
-    static const bool sep_env = !(getenv("RLARM_SPLIT_BIAS") && getenv("RLARM_SPLIT_BIAS")[0] == '0');
-    const bool sep_bias = sep_env && a->B >= GL_RING_MIN_K;   // gemm_bias_tile restates the ring path's summation order only
-    const int n_bias = sep_bias ? L.separate_bias() : 0;
     Q.tiles = L.g;
     Q.need_c = (unsigned)nslab;
     Q.tl_mark = gc->t_plan != nullptr ? 1 : 0;
     AdamFuse F = adam_fuse(a);
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;
     if (gc->polyak_after) fold_polyak(a, F);
-    F.scal = a->d_state->scal2[set];
-    F.part = a->part + set * part_words;
     F.gate = Q.sync;
     F.gate_need = (unsigned)nslab;
     F.gate_sel = gate_sel;
@@ -848,41 +821,20 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     F.tl_mark = Q.tl_mark;
     Q.adam = F;
     Q.s = P;
-    // carry form: the actor's tiles of the update BEFORE ride at the head of this launch (inputs: the other input set, step
-    // scalars and loss partials: the other parity); the sequence's last update is followed by the stand-alone launch below
-    const bool carry = gc->carry && !one;
-    auto actor_tiles = [&](const float *sX, int pset, Launch &La, AdamFuse &Fa) {
-        La = build_dw_half(a, false, sX, nullptr);
-        Fa = adam_fuse(a);
-        Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
-        Fa.scal = a->d_state->scal2[pset];
-        Fa.part = a->part + pset * part_words;
-        return sep_bias ? La.separate_bias() : 0;
-    };
-    Q.carry_need = 0u;
-    if (carry && !gc->seq_first) {
-        Launch Lp;
-        AdamFuse Fp;
-        const int nb_p = actor_tiles(xs ? a->XP : a->XP2, set ^ 1, Lp, Fp);
-        HP_REQUIRE(Fp.wt, HP_ERR_STATE, "split launch, carry form: needs write-through optimizer stores");
-        Q.carry = Lp.g;
-        Q.carry_adam = Fp;
-        Q.carry_need = (unsigned)(Lp.tiles + nb_p);
-    }
-    const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles + n_bias, (int)Q.carry_need);
+    const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
         hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
-    if (!one && (!carry || gc->seq_last)) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
+    if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
         ProfScope ps(a, PROF_DW);
-        Launch La;
-        AdamFuse Fa;
-        const int nb_a = actor_tiles(built.sXP, set, La, Fa);
+        Launch La = build_dw_half(a, false, built.sXP, nullptr);
+        AdamFuse Fa = adam_fuse(a);
+        Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
         if (gc->polyak_after) fold_polyak(a, Fa);
         Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
-        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles + nb_a), dim3(GL_THREADS), 0, s, La.g, Fa);
+        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;

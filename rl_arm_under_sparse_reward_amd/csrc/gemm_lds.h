@@ -288,7 +288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
     float *my = lds + wave * (32 * 33);
-    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0 && grp.bias0 == 0;   // (bias0 > 0: gemm_bias_tile does it)
+    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0;
     if (ring_path) {   // 32 x 32 accumulator layout: register r -> row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
         const int h = lane >> 5, l = lane & 31;
 #pragma unroll
@@ -437,22 +437,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         if (!SC1 || !ADAM || F->keep_grads) p.bias_grad[m0 + tid] = sb;
         if (ADAM) adam_apply<SC1>(*F, (int)(p.bias_grad - F->grads_base) + m0 + tid, sb);
     }
-    // dX-fragment copy of a whole 32 x 32 tile of a 256 x 256 layer (slab8 fragment order): per thread it is 4 dwords 16 B apart
-    // -- every 128-byte line received four partial write-through stores of 32 scattered bytes -- but for 4 consecutive OUTPUT rows of
-    // one input column it is one float4, 32 columns = 512 contiguous bytes: the stepped parameters go through LDS once and
-    // out as whole lines (same values, same addresses)
-    bool dxT = false;
-    int od0 = -1;
-    if (ADAM) {
-        if (F->am.mode == 1 && vm == 32 && vn == 32 && p.ldc == F->am.H && p.n_store >= n0 + 32) {
-            int of0;
-            frag8_offsets(F->am, (int)(p.C - F->grads_base) + m0 * p.ldc + n0, of0, od0);
-            dxT = od0 >= 0 && of0 >= 0 && p.M == F->am.H;
-        }
-    }
-    if (!etile && !dxT) return;
-    float pn4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (etile) {
+    if (!etile) return;
     switch (p.epi) {
         case EPI_BIAS_RELU:
 #pragma unroll
@@ -492,116 +477,20 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     if (ADAM) {
         const int base = (int)(p.C - F->grads_base) + em * p.ldc + en;
         if (adam_vec) {
-            adam_apply4(*F, base, v, ast, dxT ? pn4 : nullptr);
+            adam_apply4(*F, base, v, ast);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (en + j < p.n_store) adam_apply<SC1>(*F, base + j, v[j]);
         }
     }
-    }
-    if (ADAM && dxT) {   // (uniform over the workgroup; the tile is whole: etile == tid < 256 and every thread took adam_apply4)
-        float *tp = lds + GL_WAVES * 32 * 33;   // behind the reduction partials
-        if (etile) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tp[erow * 33 + ecol + j] = pn4[j];
-        }
-        __syncthreads();
-        if (tid < 256) {
-            const int ng = tid >> 5, kk = tid & 31;
-            const float4 o = make_float4(tp[(4 * ng + 0) * 33 + kk], tp[(4 * ng + 1) * 33 + kk], tp[(4 * ng + 2) * 33 + kk],
-                                         tp[(4 * ng + 3) * 33 + kk]);
-            float *dst = F->fragD + od0 + (ng << 8) + (kk << 2);
-            if (F->wt) wt_store4(dst, o);
-            else *reinterpret_cast<float4 *>(dst) = o;
-        }
-    }
     GL_STAMP(5);
-}
-
-// Bias gradient (column sums of dY over the batch rows) + its optimizer step for ONE 32-row panel of one problem, as a workgroup of
-// its own.  In gemm_tile the tile with tn == 0 carries them, and with one tile per CU (the launches of the split form) those
-// tiles are the launch's tail: their three cold optimizer-state loads sit behind the reduction (7.6 vs 5.0 us in the workgroup;
-// prefetching them in the tile cost every tile more than it saved).  Here the same A-operand stream through the
-// same per-wave ring and the SAME summation order as gemm_tile's `asr` (block by block, kp = 0..3, halves, waves 0..7) -- the
-// bits do not change -- with nothing else to do, and the state loads issued at entry.
-template <bool ADAM, bool SC1 = false>
-__device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamFuse *F_arg, int bidx, float *lds, float (*bsum)[32],
-                                               int &prob_out) {
-    AdamFuse F_pinned;
-    const AdamFuse *F = F_arg;
-    if constexpr (ADAM && SC1) {
-        F_pinned = adam_pinned(*F_arg);
-        F = &F_pinned;
-    }
-    int pi = 0, first = 0, acc = 0;
-#pragma unroll
-    for (int i = 0; i < MAX_PROBS; ++i) {
-        const int nb = (i < grp.n && grp.p[i].bias_grad) ? (grp.p[i].M + 31) >> 5 : 0;
-        if (bidx >= acc && bidx < acc + nb) { pi = i; first = acc; }
-        acc += nb;
-    }
-    prob_out = pi;
-    const GemmProb &p = grp.p[pi];
-    const int tm = bidx - first, m0 = tm * 32;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32;
-    const int gidx = (int)(p.bias_grad - F->grads_base) + m0 + tid;
-    float sp = 0.f, sm = 0.f, sv = 0.f;
-    if (ADAM && tid < vm) { sp = F->p[gidx]; sm = F->m[gidx]; sv = F->v[gidx]; }
-    const float *Abase = p.A + (long long)m0 * p.a_si;
-    float *ring = lds + wave * (4 * 512);
-    const int h = lane >> 5, l = lane & 31, rsub = lane >> 3, chunk = lane & 7;
-    const int gchA = chunk < (vm >> 2) ? chunk : (vm >> 2) - 1;
-    const float *srcA = Abase + (long long)(8 * wave + rsub) * p.a_sk + 4 * gchA;
-    const long long stepA = 64LL * p.a_sk;
-    const int nblk = p.K > 8 * wave ? (p.K - 8 * wave + 63) >> 6 : 0;
-    float asr = 0.f;
-    for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) gl_dma<SC1>(ring + (i2 & 3) * 512, srcA + i2 * stepA);
-    for (int i2 = 0; i2 < nblk; ++i2) {
-        const int ahead = i2 + 3;
-        if (ahead < nblk) {
-            gl_dma<SC1>(ring + (ahead & 3) * 512, srcA + ahead * stepA);
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            const int rem = nblk - 1 - i2;
-            if (rem >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const float *blk = ring + (i2 & 3) * 512 + h * 32 + l;
-#pragma unroll
-        for (int kp = 0; kp < 4; ++kp) asr += blk[kp * 64];
-    }
-    asr += __shfl_xor(asr, 32);
-    if (h == 0) bsum[wave][l] = asr;
-    __syncthreads();
-    float sb = 0.f;
-    if (tid < vm) {
-#pragma unroll
-        for (int w = 0; w < GL_WAVES; ++w) sb += bsum[w][tid];
-    }
-    if constexpr (ADAM && SC1) {
-        if (!adam_gate_wait(*F, pi, reinterpret_cast<int *>(&bsum[0][0]))) return;
-    }
-    if (tid < vm) {
-        if (!SC1 || !ADAM || F->keep_grads) p.bias_grad[m0 + tid] = sb;
-        if (ADAM) {
-            const AdamState1 st{sp, sm, sv};
-            adam_apply<SC1>(*F, gidx, sb, &st);
-        }
-    }
 }
 
 template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
-    if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0) {
-        int pi;
-        gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum, pi);
-        return;
-    }
     gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
 }
 

@@ -605,24 +605,20 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
 // fragments the XCD's chains will stream, in the order they use them, one dword per 128-byte line, so that the chains find them
 // in their L2 instead of behind the fabric
 // side: 0 = the sets of the critic-side chains, 1 = of the actor-side chains, 2 = all; per / mine: warmers on this XCD, my index
-// part (side 1 only; carry form of the split launch): 0 = everything, 1 = only the CRITIC's fragments (final when the launch
-// starts), 2 = only the ACTOR's (stepped by the carried tiles of the same launch: touch them after those have finished)
-__device__ __forceinline__ void s8_l2_warm_at(const FbSlabArgs &P, int side, int per, int mine, float *sink, int part = 0) {
+__device__ __forceinline__ void s8_l2_warm_at(const FbSlabArgs &P, int side, int per, int mine, float *sink) {
     const FwdSlabArgs &A = P.f;
     const int tid = threadIdx.x;
     const int na = A.la.total, nall = na + A.lc.total;
     const float *r0 = side == 1 ? A.online.wf : A.target.wf;
-    int n0 = nall;
+    const int n0 = nall;
     const float *r1 = side == 1 ? A.online.wd + na : A.online.wf + (side == 0 ? na : 0);
-    int n1 = side == 2 ? nall : A.lc.total;
+    const int n1 = side == 2 ? nall : A.lc.total;
     const float *r2 = side == 1 ? A.online.wd : A.online.wd + (side == 0 ? na : 0);
-    int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
-    if (part == 1) { r0 += na; n0 = A.lc.total; n2 = 0; }
-    if (part == 2) { n0 = na; n1 = 0; }
+    const int n2 = side == 1 ? na : (side == 0 ? A.lc.total : nall);
     const float *rs[3] = {r0, r1, r2};
     const int ns[3] = {n0, n1, n2};
     float acc = 0.f;
-    if (tid < 256 && part != 1) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
+    if (tid < 256) {   // first the few lines every layer epilogue and head reads from the canonical arenas: biases, head rows
         const int grp = tid >> 6, i = tid & 63;
         const float *canon = (grp >> 1) ? A.online.canon : A.target.canon;
         const NetLayout &l = (grp & 1) ? A.lc : A.la;

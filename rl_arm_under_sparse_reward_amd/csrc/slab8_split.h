@@ -70,31 +70,16 @@ __device__ __forceinline__ int split_role(const FbSplitArgs &Q, int &idx, int &i
     return role;
 }
 
-// rank of workgroup (slot in_xcd, this XCD) among the workgroups of `role` in slot-major order (slot, XCD): the block index it
-// would have in a launch of that role alone; XCDs may hold different numbers
-__device__ __forceinline__ int split_rank(const FbSplitArgs &Q, int role, int in_xcd) {
-    const int x = (int)(blockIdx.x & 7);
-    int rank = 0;
-#pragma unroll
-    for (int xx = 0; xx < 8; ++xx) {
-        const int nt = (int)((Q.nrole[xx] >> (8 * role)) & 0xffull);
-        rank += nt < in_xcd ? nt : in_xcd;
-        if (xx < x && nt > in_xcd) rank += 1;
-    }
-    return rank;
-}
-
 // the optimizer's step scalars, written through so that the tiles of THIS launch (other XCDs) can read them
-// (row `set` of AgentDevState::scal2: the carried tiles of the launch read the OTHER row, the previous update's)
-__device__ __forceinline__ void adam_prepare_wt(AgentDevState *st, const AdamCfg c, int set) {
+__device__ __forceinline__ void adam_prepare_wt(AgentDevState *st, const AdamCfg c) {
     const long long stepi = st->step + 1;
     const double step = (double)stepi;
     const double bc1 = 1.0 - pow(c.beta1, step);
     const double bc2 = 1.0 - pow(c.beta2, step);
     __hip_atomic_store(&st->step, stepi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wt_store(&st->scal2[set][0], (float)(-(c.lr_actor / bc1)));
-    wt_store(&st->scal2[set][1], (float)(-(c.lr_critic / bc1)));
-    wt_store(&st->scal2[set][2], (float)sqrt(bc2));
+    wt_store(&st->neg_step_actor, (float)(-(c.lr_actor / bc1)));
+    wt_store(&st->neg_step_critic, (float)(-(c.lr_critic / bc1)));
+    wt_store(&st->bc2_sqrt, (float)sqrt(bc2));
 }
 
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_split8(const FbSplitArgs Q) {
@@ -136,7 +121,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     int rbase = 0;
     unsigned long long *tl = nullptr;
 #ifdef SLAB_TIMELINE
-    if (slab == 0 && (role == SR_A || role == SR_C || role == SR_T)) tl = A.tl + (role == SR_A ? 0 : role == SR_C ? 1 : 2) * 32;
+    if (slab == 0 && role <= SR_T) tl = A.tl + role * 32;
     if (role == SR_A && slab == nslab / 4) tl = A.tl + 96;   // the first actor-side chain of the SECOND XCD that holds them (placement 1 / 2)
 #endif
     const SlabNetPtrs &on = A.online;
@@ -146,73 +131,38 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
         return;
     } else if (role == SR_AHEAD) {
-        // (carry form: the set it fills held the inputs of the update BEFORE, which the carried tiles still read)
-        if (Q.carry_need && !handoff_wait(split_ctr(Q.sync, 7, (int)(blockIdx.x & 7)), Q.carry_need, Q.wait_ticks, Q.fault,
-                                          Q.fault_host, 4u, reinterpret_cast<int *>(dq)))
-            return;
         s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, idx, P.n_ahead);
     } else if (role == SR_WARM) {
-        const int side = (int)((Q.warm_side >> (4 * (blockIdx.x & 7))) & 15u);
-        if (Q.carry_need && side != 0) {   // the actor's fragments are being stepped by the carried tiles: the critic's first
-            if (side == 1) s8_l2_warm_at(P, 1, n_in_xcd, in_xcd, dq, 1);
-            if (!handoff_wait(split_ctr(Q.sync, 7, (int)(blockIdx.x & 7)), Q.carry_need, Q.wait_ticks, Q.fault, Q.fault_host, 4u,
-                              reinterpret_cast<int *>(dq)))
-                return;
-            s8_l2_warm_at(P, side, n_in_xcd, in_xcd, dq, side == 1 ? 2 : 0);
-        } else {
-            s8_l2_warm_at(P, side, n_in_xcd, in_xcd, dq);
-        }
-    } else if (role == SR_ATILE) {
-        // ---- carry form: the ACTOR's weight gradients + optimizer step of the update BEFORE this one (their operands were
-        // complete when the previous launch ended: plain loads, no gate), dispatched first on every XCD like the tiles of a
-        // launch of their own; the stepped parameters and fragment copies go out write-through (AdamFuse::wt), and once they
-        // are drained the workgroup counts itself in counter 7, which this launch's actor-side chains, its warmers and its
-        // gather workgroups wait for.  Workgroup (slot, XCD) takes the block of that stand-alone launch that has its slot-major rank.
-        float *tlds = reinterpret_cast<float *>(&wring[0][0][0]);
-        float(*bsum)[32] = reinterpret_cast<float(*)[32]>(pbuf);
-        const int vb = split_rank(Q, SR_ATILE, in_xcd);
-        if (Q.carry.bias0 > 0 && vb >= Q.carry.bias0) {
-            int pi2;
-            gemm_bias_tile<true, false>(Q.carry, &Q.carry_adam, vb - Q.carry.bias0, tlds, bsum, pi2);
-        } else {
-            gemm_tile<true, false, false>(Q.carry, &Q.carry_adam, vb, tlds, bsum, vb == 0);
-        }
-        split_publish(Q.sync, 7);
-        SPLIT_STAMP(3);
+        s8_l2_warm_at(P, (int)((Q.warm_side >> (4 * (blockIdx.x & 7))) & 15u), n_in_xcd, in_xcd, dq);
     } else if (role == SR_TILE) {
         // ---- critic weight gradients + optimizer step of THIS update, on a CU a short chain has left (or that held none).
         // Tile ids are slot-major (the workgroups dispatched first on every XCD take the lowest ids): those are the tiles whose
         // operands the C chains publish first (the group lists W3, W4, W2, W1).
         float *tlds = reinterpret_cast<float *>(&wring[0][0][0]);
         float(*bsum)[32] = reinterpret_cast<float(*)[32]>(pbuf);
-        const int tile = split_rank(Q, SR_TILE, in_xcd);
-        int pi = 0, first_tile = 0;
-        const bool bias_wg = Q.tiles.bias0 > 0 && tile >= Q.tiles.bias0;   // gemm_lds.h: gemm_bias_tile
-        if (bias_wg) {
-            int acc = 0;
+        // rank of (slot, XCD) among all tile workgroups in the order (slot, XCD): XCDs may hold different numbers of tiles
+        int tile = 0;
+        {
+            const int x = (int)(blockIdx.x & 7);
 #pragma unroll
-            for (int i = 0; i < MAX_PROBS; ++i) {
-                const int nb = (i < Q.tiles.n && Q.tiles.p[i].bias_grad) ? (Q.tiles.p[i].M + 31) >> 5 : 0;
-                if (tile - Q.tiles.bias0 >= acc && tile - Q.tiles.bias0 < acc + nb) pi = i;
-                acc += nb;
+            for (int xx = 0; xx < 8; ++xx) {
+                const int nt = (int)((Q.nrole[xx] >> (8 * SR_TILE)) & 0xffull);
+                tile += nt < in_xcd ? nt : in_xcd;
+                if (xx < x && nt > in_xcd) tile += 1;
             }
-        } else {
-#pragma unroll
-            for (int i = 1; i < MAX_PROBS; ++i)
-                if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) {
-                    pi = i;
-                    first_tile = Q.tiles.p[i].tile0;
-                }
         }
+        int pi = 0, first_tile = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_PROBS; ++i)
+            if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) {
+                pi = i;
+                first_tile = Q.tiles.p[i].tile0;
+            }
         const int stage = (int)((Q.tile_stage >> (4 * pi)) & 15u);
         if (!handoff_wait(split_ctr(Q.sync, stage, (int)(blockIdx.x & 7)), Q.need_c, Q.wait_ticks, Q.fault, Q.fault_host,
                           1u, reinterpret_cast<int *>(dq)))
             return;
         SPLIT_STAMP(1);
-        if (bias_wg) {
-            int pi2;
-            gemm_bias_tile<true, true>(Q.tiles, &Q.adam, tile - Q.tiles.bias0, tlds, bsum, pi2);
-        } else
         gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, pi == Q.loss_prob && tile == first_tile);
         SPLIT_STAMP(3);
     } else if (role == SR_T) {
@@ -304,7 +254,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const float w4c = on.canon[ca + lc.w4 + (tid & 255)];
         if (ekh0_) { ebA[1] = on.canon[ca + lc.b2 + ecol_]; ebA[2] = on.canon[ca + lc.b3 + ecol_]; }
         const float *pA = ebA;
-        if (slab == 0 && tid == 0) adam_prepare_wt(Bk.st, Bk.adam, Q.scal_set);   // step scalars of this update's optimizer epilogues (this chain is not the launch's critical path)
+        if (slab == 0 && tid == 0) adam_prepare_wt(Bk.st, Bk.adam);   // step scalars of this update's optimizer epilogues (this chain is not the launch's critical path)
         __builtin_amdgcn_sched_barrier(0);
         s8_sync();
         S8_TSTAMP(tl, 13);
@@ -374,11 +324,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         S8_TSTAMP(tl, 0);
         if (slab == 0 && tid < SPLIT_COUNTERS * 8)   // the NEXT launch's counter set (nobody of this launch touches it)
             __hip_atomic_store(Q.sync_other + tid * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // carry form: the actor's parameters of THIS update are what the carried tiles at the head of the launch store
-        if (Q.carry_need && !handoff_wait(split_ctr(Q.sync, 7, (int)(blockIdx.x & 7)), Q.carry_need, Q.wait_ticks, Q.fault,
-                                          Q.fault_host, 4u, reinterpret_cast<int *>(dq)))
-            return;
-        SPLIT_STAMP(2);
 #define S8_AFTER_CRITIC_FWD do { split_bump(Q.sync, 3); } while (0)
 #define S8_AFTER_CRITIC_DX1 do { split_bump(Q.sync, 4); } while (0)
 #define S8_AFTER_CRITIC_DX do { split_bump(Q.sync, 5); SPLIT_STAMP(1); } while (0)

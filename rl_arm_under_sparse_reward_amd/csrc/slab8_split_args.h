@@ -11,11 +11,7 @@ __device__ int g_split_role[1024];
 #define SPLIT_STAMP(k) do { } while (0)
 #endif
 
-// roles, in the order their workgroups are dispatched on every XCD: what others wait for comes first (actor-side chains, the
-// carried tiles they wait for, critic chains), what has slack last (target chains: needed by the NEXT launch; this update's tiles)
-// (with 4-row slabs the three kinds of chains of batch 256 are 192 workgroups: the carried tiles only fit beside the actor-side
-// chains, so the short chains start when the carried tiles have ended -- they have that slack)
-enum { SR_A = 0, SR_ATILE = 1, SR_PLAN = 2, SR_AHEAD = 3, SR_WARM = 4, SR_C = 5, SR_T = 6, SR_TILE = 7, SR_N = 8 };
+enum { SR_A = 0, SR_C = 1, SR_T = 2, SR_PLAN = 3, SR_AHEAD = 4, SR_WARM = 5, SR_TILE = 6, SR_N = 7 };
 
 struct FbSplitArgs {
     FbSlabArgs s;                    // what the chains and the spare workgroups of k_fb_slab8 take (s.n_plan / n_ahead / n_pref: totals)
@@ -36,12 +32,6 @@ struct FbSplitArgs {
     int tl_mark;                     // time-line builds: this launch records its per-workgroup stamps (the last one WITH target chains)
     GemmGroup tiles;                 // weight-gradient problems: the critic's four, then (one-launch form) the actor's four
     AdamFuse adam;                   // their optimizer epilogue
-    // carry form: the ACTOR's weight-gradient tiles + optimizer step of the update BEFORE this one (operands complete since the
-    // previous launch ended) run first; this launch's actor-side chains, warmers and gather workgroups wait for counter 7
-    GemmGroup carry;
-    AdamFuse carry_adam;
-    unsigned carry_need;             // carried workgroups (tiles + bias panels); 0: none (first update of a sequence / two-launch form)
-    int scal_set;                    // AgentDevState::scal2 row this update's step scalars go to
 };
 static_assert(sizeof(FbSplitArgs) <= 4096, "kernel arguments of k_fb_split8 exceed the 4 KB kernarg segment");
 

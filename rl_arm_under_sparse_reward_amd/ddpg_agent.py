@@ -397,9 +397,7 @@ class ddpg_agent:
                 "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32",
                 "launches_per_update": {0: "chains | weight gradients + Adam",
                                         1: "split: chains (targets one update ahead) + critic weight gradients + Adam | actor weight gradients + Adam",
-                                        2: "split, one launch: chains + all weight gradients + Adam",
-                                        3: "split, carry: actor weight gradients + Adam of the update before + chains (targets one "
-                                           "update ahead) + critic weight gradients + Adam; one actor launch per sequence"}[f.value]}
+                                        2: "split, one launch: chains + all weight gradients + Adam"}[f.value]}
 
     def policy_snapshot(self):
         """Publish the current actor + normalizer statistics to feeders that call the policy while cycles run

@@ -40,8 +40,8 @@ fn = lib._cdll.hp_debug_split_timeline
 out = (C.c_uint64 * 5120)(); fn.restype = C.c_int; fn(out)
 rows = [(b, [out[5 * b + 0], out[5 * b + 1], out[5 * b + 2], out[5 * b + 3], out[5 * b + 4] & 255, out[5 * b + 4] >> 8]) for b in range(1024) if out[5 * b]]
 base = min(r[1][0] for r in rows)
-names = ["A actor side", "carried tile (actor dW + Adam of the update before)", "plan", "gather", "warm", "C critic", "T target", "tile (critic dW + Adam)"]
-TILE = 7
+names = ["A actor side", "C critic", "T target", "plan", "gather", "warm", "tile (critic dW + Adam)"]   # slab8_split_args.h: SR_*
+TILE = 6
 def stat(v): return f"n={len(v):3d} min {min(v):6.2f} med {st.median(v):6.2f} max {max(v):6.2f}" if v else "-"
 rows = [r for r in rows if r[1][3] >= r[1][0]]
 base = min(r[1][0] for r in rows if r[1][4] == 0)      # first actor-side chain's start
@@ -53,10 +53,10 @@ for role, nm in enumerate(names):
         if role not in (TILE, 0) and k == 2: continue
         v = [(r[1][k] - base) / 100 for r in sel if r[1][k]]
         if v: print(f"[split] {nm:26s} {kn:15s} {stat(v)}")
-late = sorted((r[0], r[1][4], (r[1][0] - base) / 100, (r[1][3] - base) / 100) for r in rows if r[1][0] >= base - 200 and r[1][4] in (1, 4) and (r[1][0] - base) / 100 > 1.0)
+late = sorted((r[0], r[1][4], (r[1][0] - base) / 100, (r[1][3] - base) / 100) for r in rows if r[1][0] >= base - 200 and r[1][4] in (0, 1, 2) and (r[1][0] - base) / 100 > 1.0)
 print("[split] workgroups of the first roles that started > 1 us late (block, XCD, slot, role, start, end):",
       " ".join(f"{b}:x{b % 8}s{b // 8}r{ro}:{t0:.1f}-{t1:.1f}" for b, ro, t0, t1 in late[:60]))
-for role, nm in ((0, "A"), (5, "C"), (6, "T")):      # by XCD: is the spread of a role's end times a property of the XCD it runs on?
+for role, nm in ((0, "A"), (1, "C"), (2, "T")):      # by XCD: is the spread of a role's end times a property of the XCD it runs on?
     for x in range(8):
         v = [(r[1][3] - base) / 100 for r in rows if r[1][4] == role and r[0] % 8 == x and r[1][0] >= base - 200]
         if v: print(f"[split by XCD] {nm} chains on XCD {x}: n={len(v):2d} end min {min(v):6.2f} med {st.median(v):6.2f} max {max(v):6.2f}")
