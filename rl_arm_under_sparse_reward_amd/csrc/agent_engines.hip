@@ -500,7 +500,13 @@ static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains
             n[x][SR_TILE] = total ? n_tiles * room[x] / total : 0;
             given += n[x][SR_TILE];
         }
-        for (int x = 0; given < n_tiles; x = (x + 1) % 8) { n[x][SR_TILE] += 1; ++given; }
+        while (given < n_tiles) {   // the remainder: one at a time to the XCD with the most room left (never to one without, while any has)
+            int best = 0;
+            for (int x = 1; x < 8; ++x)
+                if (room[x] - n[x][SR_TILE] > room[best] - n[best][SR_TILE]) best = x;
+            n[best][SR_TILE] += 1;
+            ++given;
+        }
     }
     unsigned rows = 0;
     for (int x = 0; x < 8; ++x) {
@@ -808,7 +814,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     }
     Q.tiles = L.g;
     Q.need_c = (unsigned)nslab;
-    Q.tl_mark = gc->t_plan != nullptr ? 1 : 0;
+    // time-line builds: the last launch with target chains AND a plan workgroup stamps (RLARM_TL_LAST: the last with target chains)
+    Q.tl_mark = (gc->t_plan != nullptr && (P.n_plan > 0 || getenv("RLARM_TL_LAST"))) ? 1 : 0;
     AdamFuse F = adam_fuse(a);
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;
     if (gc->polyak_after) fold_polyak(a, F);

@@ -129,11 +129,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (tid >= MT_THREADS) return;
         mt_her_plan(Bk.rng, Bk.meta->current_size, Bk.T, Bk.plan_batch, 1, Bk.future_p, Bk.next_plan,
                     reinterpret_cast<uint32_t(*)[MT_N]>(&wring[0][0][0]), reinterpret_cast<int *>(pbuf));
+        SPLIT_STAMP(3);
         return;
     } else if (role == SR_AHEAD) {
         s8_gather_ahead(P.ahead, P.aXT, P.aXA, P.aXP, A.ldx, A.act_off, A.act_dim, A.max_action, idx, P.n_ahead);
+        SPLIT_STAMP(3);
     } else if (role == SR_WARM) {
         s8_l2_warm_at(P, (int)((Q.warm_side >> (4 * (blockIdx.x & 7))) & 15u), n_in_xcd, in_xcd, dq);
+        SPLIT_STAMP(3);
     } else if (role == SR_TILE) {
         // ---- critic weight gradients + optimizer step of THIS update, on a CU a short chain has left (or that held none).
         // Tile ids are slot-major (the workgroups dispatched first on every XCD take the lowest ids): those are the tiles whose
