@@ -19,6 +19,10 @@ def run(cycles, batch):
     for c in range(cycles):
         ag.train_cycle(pool[c % 8], 40)
     ctx.synchronize()
+    import ctypes as C
+    word = C.c_uint32()
+    _lib.check(ag.lib.hp_agent_status(ag.h, C.byref(word)))   # sticky fault word of the in-launch hand-offs (k_cycle_open, k_fb_split8)
+    assert word.value == 0, hex(word.value)
     h = hashlib.sha256()
     for slot in (NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET):
         h.update(ag._get_flat(slot).tobytes())
@@ -27,8 +31,10 @@ def run(cycles, batch):
     return h.hexdigest(), ag.last_losses(1)[0]
 
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-for batch in (256, 1024):
+for batch in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("256", "1024"))]:
     a = run(cycles, batch); b = run(cycles, batch)
     os.environ["RLARM_AHEAD"] = "0"; c = run(cycles, batch); del os.environ["RLARM_AHEAD"]
-    print(f"batch {batch}: {cycles} cycles  run1 {a[0][:16]} run2 {b[0][:16]} no-ahead {c[0][:16]}  losses {a[1]}",
-          "OK" if a[0] == b[0] == c[0] else "MISMATCH")
+    # the split launch (in-launch counters between chains and tiles, slab8_split.h) against the two-launch form
+    os.environ["RLARM_SPLIT"] = "0"; d = run(cycles, batch); del os.environ["RLARM_SPLIT"]
+    print(f"batch {batch}: {cycles} cycles = {40 * cycles} updates  run1 {a[0][:16]} run2 {b[0][:16]} no-ahead {c[0][:16]} "
+          f"two-launch form {d[0][:16]}  losses {a[1]}", "OK" if a[0] == b[0] == c[0] == d[0] else "MISMATCH")
