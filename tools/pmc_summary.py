@@ -64,7 +64,9 @@ def main():
     for path in args:
         print(path)
         for name, counter, n, avg, _ in per_kernel(path)[:14]:
-            print(f"  {str(name)[:50]:50s} {counter:12s} n={n:6d} avg={avg:12.1f} KiB/launch")
+            # FETCH_SIZE / WRITE_SIZE count KiB (the x2 fetch correction is applied further down); every other counter is a plain count
+            unit = "KiB/launch" if counter in ("FETCH_SIZE", "WRITE_SIZE") else "per launch"
+            print(f"  {str(name)[:50]:50s} {counter:12s} n={n:6d} avg={avg:12.1f} {unit}")
             short = str(name).split("(")[0].split("::")[-1]   # k_fb_slab8 lives in a namespace per slab height
             table.setdefault(short, {})[counter] = avg
     if out_json:
