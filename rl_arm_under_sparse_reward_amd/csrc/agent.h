@@ -60,6 +60,8 @@ struct GemmGroup {
     int n;
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)
     int uni;    // ring loop with the wave index in a scalar register (gemm_lds.h)
+    int bias0;  // > 0: the bias gradients + their optimizer step run in workgroups of their own from this block index on (one per
+                // 32-row panel of every problem that has a bias vector: gemm_lds.h gemm_bias_tile); the tiles then skip them
     float *part;                  // split tiles: GL_PART floats per (tile, slice)
     unsigned long long *ticket;   // split tiles: arrival counter per tile, monotonic over the life of the agent
     GemmProb p[MAX_PROBS];
@@ -286,10 +288,19 @@ struct Launch {  // builds one grouped launch
         g.n = 0;
         g.xcd = 0;
         g.uni = 0;
+        g.bias0 = 0;
         g.part = nullptr;
         g.ticket = nullptr;
     }
     int split_tiles = 0;   // tiles whose reduction is split (entries of part / ticket in use)
+    // bias vectors in workgroups of their own behind the tiles (call last); returns how many
+    int separate_bias() {
+        int nb = 0;
+        for (int i = 0; i < g.n; ++i)
+            if (g.p[i].bias_grad) nb += (g.p[i].M + 31) / 32;
+        g.bias0 = tiles;
+        return nb;
+    }
     // split the reduction of the problem added last over `ks` workgroups per tile
     void split_last(int ks) {
         GemmProb &p = g.p[g.n - 1];

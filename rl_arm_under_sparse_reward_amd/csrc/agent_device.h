@@ -86,6 +86,11 @@ __device__ __forceinline__ bool adam_gate_wait(const AdamFuse &F, int prob, int 
 }
 
 
+// optimizer state of ONE element fetched ahead (gemm_bias_tile: cold loads that otherwise sit behind the reduction)
+struct AdamState1 {
+    float p, m, v;
+};
+
 // AGENT: the step scalars were written (write-through) by a workgroup of the SAME launch: agent-scope loads
 template <bool AGENT>
 __device__ __forceinline__ float adam_scal(const AdamFuse &F, int i) {
@@ -93,15 +98,15 @@ __device__ __forceinline__ float adam_scal(const AdamFuse &F, int i) {
     else return F.scal[i];
 }
 template <bool AGENT = false>
-__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi) {
+__device__ __forceinline__ void adam_apply(const AdamFuse &F, int idx, float gi, const AdamState1 *pre = nullptr) {
     const float neg_step_size = adam_scal<AGENT>(F, idx < F.n_actor ? 0 : 1);
     const float bc2_sqrt = adam_scal<AGENT>(F, 2);
-    float mi = F.m[idx], vi = F.v[idx];
+    float mi = pre ? pre->m : F.m[idx], vi = pre ? pre->v : F.v[idx];
     mi = __fadd_rn(mi, __fmul_rn(F.w, __fsub_rn(gi, mi)));                      // exp_avg.lerp_(grad, 1 - beta1)
     vi = __fadd_rn(__fmul_rn(vi, F.b2), __fmul_rn(__fmul_rn(F.omb2, gi), gi));  // mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float sq = __fsqrt_rn(vi);                             // correctly rounded float32 sqrt
     const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
-    const float pn = __fadd_rn(F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
+    const float pn = __fadd_rn(pre ? pre->p : F.p[idx], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
     F.p_out[idx] = pn;
     F.m[idx] = mi;
     F.v[idx] = vi;

@@ -114,6 +114,10 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
                                                const PeerTile *PT = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
     __shared__ float bsum[GL_WAVES][32];
+    if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0 && (int)blockIdx.x < tiles) {   // (`tiles` counts the bias panels behind the tiles)
+        gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum);
+        return;
+    }
     if ((int)blockIdx.x < tiles) {
         gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, PT);
         return;
@@ -618,6 +622,13 @@ static void build_fb_args(hp_agent *a, const GatherCtx *gc, FbBuilt &O) {
     O.nslab = nslab; O.xs = xs; O.sXA = sXA; O.sXP = sXP; O.sXT = sXT; O.sR = sR; O.ride_dw = ride_dw; O.ride = ride;
 }
 
+// bias gradients + their optimizer step in workgroups of their own behind the tiles (gemm_lds.h: gemm_bias_tile; the ring path's
+// summation order only).  RLARM_SEP_BIAS=0: inside the tn == 0 tiles (same bits either way)
+static bool sep_bias_on(const hp_agent *a) {
+    static const bool env = !(getenv("RLARM_SEP_BIAS") && getenv("RLARM_SEP_BIAS")[0] == '0');
+    return env && a->Mp >= GL_RING_MIN_K && !a->dw64;
+}
+
 static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only);
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
     const int ldx = a->ldx;
@@ -724,14 +735,15 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             HP_CHECK_HIP(hipGetLastError());
         } else if (riders) {
             ProfScope ps(a, PROF_DW);
-            const unsigned grid = L.tiles + R.n_plan + R.n_ahead;
+            const int front = L.tiles + (sep_bias_on(a) ? L.separate_bias() : 0);   // tiles, then the bias panels, then the riders
+            const unsigned grid = front + R.n_plan + R.n_ahead;
             if (fuse_adam) {
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 if (gc->polyak_after) fold_polyak(a, F);
-                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, L.tiles);
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, front);
             } else {
-                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, L.tiles);
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, front);
             }
             HP_CHECK_HIP(hipGetLastError());
         } else if (fuse_adam) {
@@ -741,7 +753,8 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             AdamFuse F = adam_fuse(a);
             F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
             if (gc && gc->polyak_after) fold_polyak(a, F);
-            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(L.tiles), dim3(GL_THREADS), 0, s, L.g, F);
+            const int front = L.tiles + (sep_bias_on(a) ? L.separate_bias() : 0);
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
             HP_TRY(launch_group(a, L, PROF_DW));
@@ -841,7 +854,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
         if (gc->polyak_after) fold_polyak(a, Fa);
         Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
-        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g, Fa);
+        const int front = La.tiles + (sep_bias_on(a) ? La.separate_bias() : 0);
+        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;

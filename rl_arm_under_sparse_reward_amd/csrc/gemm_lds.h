@@ -288,7 +288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
     float *my = lds + wave * (32 * 33);
-    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0;
+    const bool want_bias_grad = p.bias_grad != nullptr && tn == 0 && grp.bias0 == 0;   // (bias0 > 0: gemm_bias_tile does it)
     if (ring_path) {   // 32 x 32 accumulator layout: register r -> row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
         const int h = lane >> 5, l = lane & 31;
 #pragma unroll
@@ -487,10 +487,93 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     GL_STAMP(5);
 }
 
+// Bias gradient (column sums of dY over the batch rows) + its optimizer step for ONE 32-row panel of one problem, as a workgroup
+// of its own (GemmGroup::bias0).  In gemm_tile the tile with tn == 0 carries them, and those tiles are every launch's tail: at
+// batch 512 they end 4 us after the median tile (11.8 vs 7.6 us in the workgroup), at 256 2.6 us after (7.6 vs 5.0) -- the
+// scalar optimizer step with its three cold state loads sits behind the reduction, in front of the tile's own epilogue.  Here:
+// the same A-operand stream through the same per-wave ring and the SAME summation order as gemm_tile's `asr` (block by block,
+// kp = 0..3, halves, waves 0..7; a split problem slice by slice, the slices' sums added in slice order) -- the bits do not
+// change -- with nothing else to do, on a CU slot the tiles leave free, and the state loads issued at entry.
+template <bool ADAM, bool SC1 = false>
+__device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamFuse *F_arg, int bidx, float *lds, float (*bsum)[32]) {
+    AdamFuse F_pinned;
+    const AdamFuse *F = F_arg;
+    if constexpr (ADAM && SC1) {
+        F_pinned = adam_pinned(*F_arg);
+        F = &F_pinned;
+    }
+    int pi = 0, first = 0, acc = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_PROBS; ++i) {
+        const int nb = (i < grp.n && grp.p[i].bias_grad) ? (grp.p[i].M + 31) >> 5 : 0;
+        if (bidx >= acc && bidx < acc + nb) { pi = i; first = acc; }
+        acc += nb;
+    }
+    const GemmProb &p = grp.p[pi];
+    const int tm = bidx - first, m0 = tm * 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int vm = (p.M - m0) < 32 ? (p.M - m0) : 32;
+    const int gidx = ADAM ? (int)(p.bias_grad - F->grads_base) + m0 + tid : 0;
+    AdamState1 st{0.f, 0.f, 0.f};
+    if (ADAM && tid < vm) { st.p = F->p[gidx]; st.m = F->m[gidx]; st.v = F->v[gidx]; }
+    const float *Abase = p.A + (long long)m0 * p.a_si;
+    float *ring = lds + wave * (4 * 512);
+    const int h = lane >> 5, l = lane & 31, rsub = lane >> 3, chunk = lane & 7;
+    const int gchA = chunk < (vm >> 2) ? chunk : (vm >> 2) - 1;
+    const long long stepA = 64LL * p.a_sk;
+    const int ks = p.ks > 1 ? p.ks : 1;
+    const int kslice = p.ks > 1 ? (((p.K + p.ks - 1) / p.ks + 63) & ~63) : p.K;
+    float sb = 0.f;
+    for (int slice = 0; slice < ks; ++slice) {
+        const int k_begin = slice * kslice;
+        const int k_len = (k_begin + kslice < p.K ? k_begin + kslice : p.K) - k_begin;
+        const float *srcA = Abase + (long long)(k_begin + 8 * wave + rsub) * p.a_sk + 4 * gchA;
+        const int nblk = k_len > 8 * wave ? (k_len - 8 * wave + 63) >> 6 : 0;
+        float asr = 0.f;
+        for (int i2 = 0; i2 < 3 && i2 < nblk; ++i2) gl_dma<SC1>(ring + (i2 & 3) * 512, srcA + i2 * stepA);
+        for (int i2 = 0; i2 < nblk; ++i2) {
+            const int ahead = i2 + 3;
+            if (ahead < nblk) {
+                gl_dma<SC1>(ring + (ahead & 3) * 512, srcA + ahead * stepA);
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                const int rem = nblk - 1 - i2;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const float *blk = ring + (i2 & 3) * 512 + h * 32 + l;
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) asr += blk[kp * 64];
+        }
+        asr += __shfl_xor(asr, 32);
+        if (slice) __syncthreads();   // the sums of the slice before have been read
+        if (h == 0) bsum[wave][l] = asr;
+        __syncthreads();
+        if (tid < vm) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < GL_WAVES; ++w) s1 += bsum[w][tid];
+            sb = slice ? sb + s1 : s1;
+        }
+    }
+    if constexpr (ADAM && SC1) {
+        if (!adam_gate_wait(*F, pi, reinterpret_cast<int *>(&bsum[0][0]))) return;
+    }
+    if (tid < vm) {
+        if (!SC1 || !ADAM || F->keep_grads) p.bias_grad[m0 + tid] = sb;
+        if (ADAM) adam_apply<SC1>(*F, gidx, sb, &st);
+    }
+}
+
 template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
+    if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0) {
+        gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum);
+        return;
+    }
     gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
 }
 

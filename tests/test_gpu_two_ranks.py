@@ -192,8 +192,9 @@ def two_ranks(request, tmp_path_factory):
                 mp.spawn(_worker, args=(world, _free_port(), str(out), transport), nprocs=world, join=True)
                 break
             except Exception as e:      # mp.spawn re-raises the first failing rank's error as ProcessRaisedException
-                if "timed out" not in str(e) and "hand-off" not in str(e):
+                if not any(t in str(e) for t in ("exchange is dead", "waited longer than the bound", "timed out")):
                     raise
+                print(f"[peertiles rehearsal] attempt {attempt + 1}: the two ranks' launches were not co-resident (bounded waits gave up)")
                 if attempt == 2:
                     pytest.skip("two ranks' launches were not co-resident on the one device in three attempts: " + str(e)[-200:])
     else:
