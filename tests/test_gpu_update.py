@@ -493,7 +493,13 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
                                           # launch is forced on, alone and with its other placements / the one-launch form)
                                           ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT=1", 128), ("RLARM_SPLIT=1", 288), ("RLARM_SPLIT=1", 64),
                                           ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=1", 256),
-                                          ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 128)])
+                                          ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 128),
+                                          # bias gradients + their optimizer step inside the tn = 0 tiles instead of in workgroups of
+                                          # their own (gemm_bias_tile): two-launch form, split launch, ride kernels, split narrow
+                                          # tiles (4 slices from 768 rows: the panel adds the slices' sums in slice order)
+                                          ("RLARM_SEP_BIAS=0", 256), ("RLARM_SEP_BIAS=0,RLARM_SPLIT=1", 256), ("RLARM_SEP_BIAS=0", 449),
+                                          ("RLARM_SEP_BIAS=0", 512), ("RLARM_SEP_BIAS=0", 768), ("RLARM_SEP_BIAS=0", 1024),
+                                          ("RLARM_SEP_BIAS=0", 100)])
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
     epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
