@@ -293,6 +293,15 @@ struct Launch {  // builds one grouped launch
         g.ticket = nullptr;
     }
     int split_tiles = 0;   // tiles whose reduction is split (entries of part / ticket in use)
+    // first tiles of the problems, 16 bits each (gemm_lds.h: TileHead -- leading scalar kernel arguments)
+    unsigned long long head(int half) const {
+        unsigned long long w = 0ull;
+        for (int i = 0; i < 4; ++i) {
+            const int pi = 4 * half + i;
+            w |= (unsigned long long)(pi < g.n ? (g.p[pi].tile0 & 0xffff) : 0xffff) << (16 * i);
+        }
+        return w;
+    }
     // bias vectors in workgroups of their own behind the tiles (call last); returns how many
     int separate_bias() {
         int nb = 0;

@@ -111,7 +111,7 @@ struct RideArgs {
 
 template <bool ADAM, bool UNI = false, bool PEER = false>
 __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamFuse *F, const RideArgs &R, int tiles,
-                                               const PeerTile *PT = nullptr) {
+                                               const PeerTile *PT = nullptr, const TileHead *TH = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
     __shared__ float bsum[GL_WAVES][32];
     if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0 && (int)blockIdx.x < tiles) {   // (`tiles` counts the bias panels behind the tiles)
@@ -119,7 +119,7 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
         return;
     }
     if ((int)blockIdx.x < tiles) {
-        gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, PT);
+        gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, PT, TH);
         return;
     }
     const int extra = (int)blockIdx.x - tiles;
@@ -138,17 +138,19 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride(const GemmGroup grp, const RideArgs R, int tiles) {
     gemm_ride_body<false>(grp, nullptr, R, tiles);
 }
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(const GemmGroup grp, const AdamFuse F, const RideArgs R,
-                                                                   int tiles) {
-    gemm_ride_body<true>(grp, &F, R, tiles);
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(unsigned long long t03, unsigned long long t47, int tiles,
+                                                                   const GemmGroup grp, const AdamFuse F, const RideArgs R) {
+    const TileHead TH{t03, t47};   // (leading scalars: preloaded with the wave, gemm_lds.h)
+    gemm_ride_body<true>(grp, &F, R, tiles, nullptr, &TH);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride_u(const GemmGroup grp, const RideArgs R, int tiles) {
     gemm_ride_body<false, true>(grp, nullptr, R, tiles);
 }
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(const GemmGroup grp, const AdamFuse F, const RideArgs R,
-                                                                     int tiles) {
-    gemm_ride_body<true, true>(grp, &F, R, tiles);
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(unsigned long long t03, unsigned long long t47, int tiles,
+                                                                     const GemmGroup grp, const AdamFuse F, const RideArgs R) {
+    const TileHead TH{t03, t47};
+    gemm_ride_body<true, true>(grp, &F, R, tiles, nullptr, &TH);
 }
 
 // data-parallel ranks, tile-wise one-shot exchange (gemm_lds.h PEER): weight gradients + rank exchange + optimizer step in ONE
@@ -741,7 +743,8 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 if (gc->polyak_after) fold_polyak(a, F);
-                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R, front);
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.head(0), L.head(1),
+                                   front, L.g, F, R);
             } else {
                 hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, front);
             }
@@ -754,7 +757,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
             if (gc && gc->polyak_after) fold_polyak(a, F);
             const int front = L.tiles + (sep_bias_on(a) ? L.separate_bias() : 0);
-            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, L.g, F);
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, L.head(0), L.head(1), L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
             HP_TRY(launch_group(a, L, PROF_DW));
@@ -765,6 +768,15 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
 
 // ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step [+ the actor's]), then -- in
 // the two-launch form -- the actor's tiles
+// k_fb_split8 with its role table as leading scalar arguments: word r = role r, byte x = its workgroups on XCD x
+static void launch_split(unsigned grid, hipStream_t s, const FbSplitArgs &Q) {
+    unsigned long long w[SR_N];
+    for (int r = 0; r < SR_N; ++r) {
+        w[r] = 0ull;
+        for (int x = 0; x < 8; ++x) w[r] |= ((Q.nrole[x] >> (8 * r)) & 0xffull) << (8 * x);
+    }
+    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, w[0], w[1], w[2], w[3], w[4], w[5], w[6], Q);
+}
 static void split_common(hp_agent *a, FbSplitArgs &Q, int set) {
     Q.sync = a->k1_sync + (set & 1) * SPLIT_SET_WORDS;
     Q.sync_other = a->k1_sync + ((set + 1) & 1) * SPLIT_SET_WORDS;
@@ -844,7 +856,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
-        hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, Q);
+        launch_split(grid, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
     if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
@@ -855,7 +867,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         if (gc->polyak_after) fold_polyak(a, Fa);
         Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
         const int front = La.tiles + (sep_bias_on(a) ? La.separate_bias() : 0);
-        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, La.g, Fa);
+        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;
@@ -890,7 +902,7 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
     ProfScope ps(a, PROF_PLAN);   // (once per sequence, with the index draws: not an update's launch)
-    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, a->ctx->stream, Q);
+    launch_split(grid, a->ctx->stream, Q);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
@@ -1289,6 +1301,11 @@ int hp_debug_split_timeline(uint64_t *out5120) {
         out5120[5 * b + 0] = tl[b][0]; out5120[5 * b + 1] = tl[b][1]; out5120[5 * b + 2] = gate[b][0]; out5120[5 * b + 3] = tl[b][3];
         out5120[5 * b + 4] = (uint64_t)role[b] | (gate[b][1] << 8);   // role | gate passed << 8 (the stamps are < 2^56)
     }
+    return HP_OK;
+}
+int hp_debug_split_entry(uint64_t *out1024) {   // wall clock at each workgroup's first instruction (before any kernel argument is read)
+    HP_CHECK_HIP(hipDeviceSynchronize());
+    HP_CHECK_HIP(hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_split_entry), 1024 * 8));
     return HP_OK;
 }
 int hp_debug_gemm_blk_timeline(uint64_t *out512) {   // [wave][block]{landed, issued} of one workgroup's product loop

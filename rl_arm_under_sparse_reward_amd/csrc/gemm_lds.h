@@ -150,9 +150,25 @@ struct PeerTile {
     const PeerDev *D;
     int u, mean;
 };
+// First tile of problems 0-3 / 4-7 (16 bits each, 0xffff: no such problem) and the first bias panel, handed to the kernel as LEADING
+// SCALAR arguments: those are preloaded into SGPRs when the wave starts (gfx942+ kernarg preload, Makefile), so the
+// workgroup knows its problem without waiting for a first fetch of the argument block (0.4-0.7 us under load,
+// tools/ubench/kernarg_preload.hip) and the problem's own fields are fetched in the FIRST round trip, not the second.
+struct TileHead {
+    unsigned long long t03, t47;
+};
+__host__ __device__ __forceinline__ int tile_head_prob(const TileHead &H, int bx) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PROBS; ++i) {
+        const int t0 = (int)(((i < 4 ? H.t03 >> (16 * i) : H.t47 >> (16 * (i - 4)))) & 0xffffull);
+        if (bx >= t0) pi = i;
+    }
+    return pi;
+}
 template <bool ADAM, bool UNI = false, bool SC1 = false, bool PEER = false>
 __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *F_arg, int bx, float *lds, float (*bsum)[32],
-                                          bool finalize_loss, const PeerTile *PT = nullptr) {
+                                          bool finalize_loss, const PeerTile *PT = nullptr, const TileHead *TH = nullptr) {
     AdamFuse F_pinned;
     const AdamFuse *F = F_arg;
     if constexpr (ADAM && SC1) {   // (agent_device.h: adam_pinned)
@@ -160,9 +176,13 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
         F = &F_pinned;
     }
     int pi = 0;
+    if (TH) {
+        pi = tile_head_prob(*TH, bx);
+    } else {
 #pragma unroll
-    for (int i = 1; i < MAX_PROBS; ++i)
-        if (i < grp.n && bx >= grp.p[i].tile0) pi = i;
+        for (int i = 1; i < MAX_PROBS; ++i)
+            if (i < grp.n && bx >= grp.p[i].tile0) pi = i;
+    }
     const bool placed = grp.xcd == 1 && bx < 256;   // Launch::place_on_xcds: four 256 x 256 problems, one pair of XCDs each
     const bool placed2 = grp.xcd == 2 && bx < 128;  // ... two of them (actor-only launch behind k_fb_split8): four XCDs each
     if (placed) pi = (bx & 7) >> 1;
@@ -567,24 +587,28 @@ __device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamF
 }
 
 template <bool ADAM, bool UNI = false>
-__device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F) {
+__device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F, const TileHead *TH = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
     if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0) {
         gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum);
         return;
     }
-    gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0);
+    gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, nullptr, TH);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }
 
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam(const GemmGroup grp, const AdamFuse F) {
-    gemm_lds_body<true>(grp, &F);
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
+                                                              const AdamFuse F) {
+    const TileHead TH{t03, t47};
+    gemm_lds_body<true>(grp, &F, &TH);
 }
 // the same kernels with the wave index in a scalar register (gemm_tile's UNI; kernels of their own so that each form keeps
 // its own register allocation: both forms inside one kernel cost either of them 0.3-0.6 us/update)
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_u(const GemmGroup grp) { gemm_lds_body<false, true>(grp, nullptr); }
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_u(const GemmGroup grp, const AdamFuse F) {
-    gemm_lds_body<true, true>(grp, &F);
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_u(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
+                                                                const AdamFuse F) {
+    const TileHead TH{t03, t47};
+    gemm_lds_body<true, true>(grp, &F, &TH);
 }

@@ -43,29 +43,33 @@ __device__ __forceinline__ void split_publish(unsigned *sync, int which) {
     split_bump(sync, which);
 }
 
-// role of this workgroup, its index among the workgroups of that role (XCD-major: all of XCD 0's first) and on its XCD.
-// Static indices and shifts only: a dynamically indexed by-value kernel argument is copied to scratch by the compiler.
-__device__ __forceinline__ int split_role(const FbSplitArgs &Q, int &idx, int &in_xcd, int &n_in_xcd) {
+// Role table of the launch: word r = workgroups of role r, byte x = on XCD x (workgroup b runs on XCD b % 8, in role order within
+// the XCD).  The seven words are the kernel's LEADING SCALAR arguments: they arrive in SGPRs with the wave (kernarg preload,
+// Makefile; 14 dwords is the limit), so a workgroup knows its role at its first instruction and fetches what that role needs in
+// its FIRST round trip to the argument block -- the fetch of the table itself cost every chain 0.45-0.75 us at the launch's start
+// (tools/ubench/split_timeline.py: "first instruction -> role known").
+struct SplitRoles {
+    unsigned long long w[SR_N];
+};
+// role of this workgroup, its index among the workgroups of that role (XCD-major: all of XCD 0's first) and on its XCD
+__device__ __forceinline__ int split_role(const SplitRoles &R, int &idx, int &in_xcd, int &n_in_xcd) {
     const int x = blockIdx.x & 7;
-    unsigned long long mine = 0ull;
-#pragma unroll
-    for (int xx = 0; xx < 8; ++xx)
-        if (xx == x) mine = Q.nrole[xx];
     int s = blockIdx.x >> 3, role = SR_N;
+    unsigned long long mine = 0ull;   // the word of this workgroup's role
 #pragma unroll
     for (int r = 0; r < SR_N; ++r) {
-        const int n = (int)((mine >> (8 * r)) & 0xffull);
+        const int n = (int)((R.w[r] >> (8 * x)) & 0xffull);
         if (role == SR_N) {
-            if (s < n) role = r;
+            if (s < n) { role = r; mine = R.w[r]; }
             else s -= n;
         }
     }
     int before = 0;
 #pragma unroll
     for (int xx = 0; xx < 8; ++xx)
-        if (xx < x && role < SR_N) before += (int)((Q.nrole[xx] >> (8 * role)) & 0xffull);
+        if (xx < x) before += (int)((mine >> (8 * xx)) & 0xffull);
     in_xcd = s;
-    n_in_xcd = role < SR_N ? (int)((mine >> (8 * role)) & 0xffull) : 0;
+    n_in_xcd = role < SR_N ? (int)((mine >> (8 * x)) & 0xffull) : 0;
     idx = before + s;
     return role;
 }
@@ -82,7 +86,11 @@ __device__ __forceinline__ void adam_prepare_wt(AgentDevState *st, const AdamCfg
     wt_store(&st->bc2_sqrt, (float)sqrt(bc2));
 }
 
-__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_split8(const FbSplitArgs Q) {
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long long r2, unsigned long long r3, unsigned long long r4,
+                 unsigned long long r5, unsigned long long r6, const FbSplitArgs Q) {
+    static_assert(SR_N == 7, "the role table is seven preloaded words");
+    const SplitRoles R{{r0, r1, r2, r3, r4, r5, r6}};
     const FbSlabArgs &P = Q.s;
     const FwdSlabArgs &A = P.f;
     const BwdSlabArgs &Bk = P.b;
@@ -99,11 +107,16 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) RingSlot wring[S8_WAVES][S8_RING];
     static_assert(sizeof(RingSlot) * S8_WAVES * S8_RING >= sizeof(float) * GL_LDS_FLOATS, "the weight ring must hold a tile's operand images");
     static_assert(S8_THREADS == GL_THREADS, "gemm_tile runs on the chain kernel's workgroup shape");
+#ifdef SLAB_TIMELINE
+    unsigned long long t_entry = wall_clock64();   // (needs no kernel argument: what the first argument fetch costs shows against stamp 0)
+    asm volatile("" : "+s"(t_entry));
+#endif
     int idx, in_xcd, n_in_xcd;
-    const int role = split_role(Q, idx, in_xcd, n_in_xcd);
+    const int role = split_role(R, idx, in_xcd, n_in_xcd);
     if (role == SR_N) return;
 #ifdef SLAB_TIMELINE
     if (Q.tl_mark && threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_split_entry[blockIdx.x] = t_entry;
         g_split_role[blockIdx.x] = role;
         g_split_tl[blockIdx.x][1] = g_split_tl[blockIdx.x][2] = 0ull;
     }
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const int x = (int)(blockIdx.x & 7);
 #pragma unroll
             for (int xx = 0; xx < 8; ++xx) {
-                const int nt = (int)((Q.nrole[xx] >> (8 * SR_TILE)) & 0xffull);
+                const int nt = (int)((R.w[SR_TILE] >> (8 * xx)) & 0xffull);
                 tile += nt < in_xcd ? nt : in_xcd;
                 if (xx < x && nt > in_xcd) tile += 1;
             }

@@ -6,6 +6,7 @@
 #ifdef SLAB_TIMELINE   // time-line builds: every workgroup of the last split launch stamps {start, hand-off point, -, end}
 __device__ unsigned long long g_split_tl[1024][4];
 __device__ int g_split_role[1024];
+__device__ unsigned long long g_split_entry[1024];   // wall clock at the kernel's first instruction, before any kernel argument is read
 #define SPLIT_STAMP(k) do { if (Q.tl_mark && threadIdx.x == 0 && blockIdx.x < 1024) g_split_tl[blockIdx.x][(k)] = wall_clock64(); } while (0)
 #else
 #define SPLIT_STAMP(k) do { } while (0)
@@ -15,7 +16,8 @@ enum { SR_A = 0, SR_C = 1, SR_T = 2, SR_PLAN = 3, SR_AHEAD = 4, SR_WARM = 5, SR_
 
 struct FbSplitArgs {
     FbSlabArgs s;                    // what the chains and the spare workgroups of k_fb_slab8 take (s.n_plan / n_ahead / n_pref: totals)
-    unsigned long long nrole[8];     // byte r of nrole[x]: workgroups of role r on XCD x (workgroup b runs on XCD b % 8), in role order within the XCD
+    unsigned long long nrole[8];     // HOST side only (build_split_roles): byte r of nrole[x] = workgroups of role r on XCD x; the kernel takes the
+                                     // transposed table as leading scalar arguments (slab8_split.h: SplitRoles)
     unsigned warm_side;              // 4 bits per XCD: what its warmers touch (s8_l2_warm_at)
     GatherSrc tgs;                   // T chains: replay buffer, normalizers and the plan of the NEXT update
     const float *qt_in;              // C chains: Q' of this update's minibatch, [Mp][16] column 0

@@ -53,6 +53,14 @@ for role, nm in enumerate(names):
         if role not in (TILE, 0) and k == 2: continue
         v = [(r[1][k] - base) / 100 for r in sel if r[1][k]]
         if v: print(f"[split] {nm:26s} {kn:15s} {stat(v)}")
+try:
+    fe = lib._cdll.hp_debug_split_entry
+    ent = (C.c_uint64 * 1024)(); fe.restype = C.c_int; fe(ent)
+    for role, nm in ((0, "A"), (1, "C"), (2, "T"), (TILE, "tile")):
+        v = [(r[1][0] - ent[r[0]]) / 100 for r in rows if r[1][4] == role and ent[r[0]] and r[1][0] >= ent[r[0]]]
+        if v: print(f"[split] {nm}: first instruction -> role known (the first kernel-argument fetch)  {stat(v)}")
+except AttributeError:
+    pass
 late = sorted((r[0], r[1][4], (r[1][0] - base) / 100, (r[1][3] - base) / 100) for r in rows if r[1][0] >= base - 200 and r[1][4] in (0, 1, 2) and (r[1][0] - base) / 100 > 1.0)
 print("[split] workgroups of the first roles that started > 1 us late (block, XCD, slot, role, start, end):",
       " ".join(f"{b}:x{b % 8}s{b // 8}r{ro}:{t0:.1f}-{t1:.1f}" for b, ro, t0, t1 in late[:60]))
