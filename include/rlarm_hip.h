@@ -37,9 +37,10 @@ extern "C" {
 
 /* Version of the STABLE surface declared in this header.  2 (round 4): the diagnostic / test-hook entry points moved to
  * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
- * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  hp_abi_version() returns the library's value; a host
+ * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  3 (round 5): hp_buffer_sample_dev (device-output fused
+ * sampler) was added.  hp_abi_version() returns the library's value; a host
  * must refuse a library whose version differs from the header it was built against. */
-#define HP_ABI_VERSION 2
+#define HP_ABI_VERSION 3
 
 typedef enum {
     HP_OK = 0,
@@ -64,7 +65,8 @@ const char *hp_last_error(void);
 /* ---- context ---------------------------------------------------------------------- */
 int hp_ctx_create(int device_id, hp_ctx **out);
 /* stream == NULL selects a stream owned by the context; to run on the legacy default stream (e.g. to be ordered
- * with a framework that uses it) pass hipStreamLegacy, i.e. (void *)1 */
+ * with a framework that uses it) pass hipStreamLegacy, i.e. (void *)1.  A change of stream keeps the context's work in
+ * order: the new stream waits (on the device, not the host) for what the context enqueued on the old one. */
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
@@ -134,6 +136,26 @@ typedef struct {
 } hp_sample_out;
 int hp_buffer_sample(hp_buffer *buf, hp_rng *rng, int64_t batch, double future_p, double sq_threshold,
                      const hp_sample_out *host_out);
+
+/* replay_buffer.sample (:46-55) followed by the learner's own preprocessing of the minibatch (ddpg_agent.py:227-243:
+ * _preproc_og clip :214-217, o_norm / g_norm .normalize normalizer.py:67-70, np.concatenate, torch.tensor(.., float32)) in ONE
+ * gather kernel with DEVICE outputs -- the `hp_sample(... out device ptrs x, x', a, r)` of SURVEY.md section 8b.  What a
+ * GPU learner consumes never crosses PCIe:
+ *   x        float32 [B, obs+goal]  inputs_norm_tensor       (ddpg_agent.py:236,240)
+ *   x_next   float32 [B, obs+goal]  inputs_next_norm_tensor  (:237,241)
+ *   actions  float32 [B, act]       actions_tensor           (:242; unscaled, the critic divides by max_action itself)
+ *   r        float32 [B]            r_tensor                 (:243; reshape to [B, 1])
+ *   e, t, future_t (int64 [B]), her (uint8 [B]): the drawn indices, for parity tests
+ * Any pointer may be NULL.  The normalizers' default_clip_range is the clip of normalize(); clip_obs is arguments.py:87.
+ * Same random stream, same draws and same float64 arithmetic as hp_buffer_sample + hp_norm_normalize (bit-identical
+ * float32 results).  Asynchronous on the context's stream; outputs are caller-owned device memory (torch tensors). */
+typedef struct {
+    float *x, *x_next, *actions, *r;
+    int64_t *e, *t, *future_t;
+    uint8_t *her;
+} hp_sample_dev_out;
+int hp_buffer_sample_dev(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
+                         double sq_threshold, double clip_obs, const hp_sample_dev_out *dev_out);
 
 /* ---- GoalEnv reward / success as batched device ops --------------------------------------------
  * compute_reward (bmirobot_env_push_F.py:84-90 -> goal_distance :20-23; byte-identical in

@@ -31,6 +31,11 @@ class SampleOut(C.Structure):
                 ("r", f32p), ("e", i64p), ("t", i64p), ("future_t", i64p), ("her", u8p), ("r64", f64p)]
 
 
+class SampleDevOut(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_next", C.c_void_p), ("actions", C.c_void_p), ("r", C.c_void_p),
+                ("e", C.c_void_p), ("t", C.c_void_p), ("future_t", C.c_void_p), ("her", C.c_void_p)]
+
+
 class AgentCfg(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("goal_dim", C.c_int32), ("act_dim", C.c_int32), ("hidden", C.c_int32),
                 ("batch", C.c_int32), ("grad_world_size", C.c_int32),
@@ -40,10 +45,11 @@ class AgentCfg(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
 
 
-ABI_VERSION = 2     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
+ABI_VERSION = 3     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
 
 # entry points declared in include/rlarm_hip_debug.h: diagnostics and test hooks, outside the stable surface
 DEBUG_SYMBOLS = {"hp_ctx_launch_floor", "hp_ctx_event_pair_us", "hp_ctx_clock_mhz", "hp_ctx_calibrate", "hp_buffer_sample_device_us",
+                 "hp_buffer_sample_dev_us",
                  "hp_agent_set_adam", "hp_agent_debug_chain", "hp_agent_debug_timeline"}
 
 # name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h and include/rlarm_hip_debug.h
@@ -80,6 +86,10 @@ PROTOTYPES = {
     "hp_buffer_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.POINTER(SampleOut)]),
     "hp_buffer_sample_device_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int32, f64p,
                                              f64p]),
+    "hp_buffer_sample_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                       C.c_double, C.POINTER(SampleDevOut)]),
+    "hp_buffer_sample_dev_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                          C.c_double, C.c_int32, f64p, f64p]),
     "hp_buffer_destroy": (None, [C.c_void_p]),
     "hp_compute_reward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
@@ -296,6 +306,7 @@ class Context:
 
     def set_stream(self, stream_ptr):
         check(self.lib.hp_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+        self._bound_stream = stream_ptr or 0
 
     def use_torch_stream(self):
         import torch
@@ -304,6 +315,16 @@ class Context:
         # torch's default stream has handle 0, which hp_ctx_set_stream reads as "the context's own stream": name the
         # legacy default stream explicitly (hipStreamLegacy == 1), or the two sides would run unordered
         self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream or 1)
+
+    def on_torch_stream(self):
+        """Bind the context to torch's current stream unless it already is (device outputs handed to torch, e.g.
+        replay_buffer.sample_device, must be written on the stream torch consumes them on)."""
+        import torch
+
+        want = torch.cuda.current_stream(self.device_id).cuda_stream or 1
+        if getattr(self, "_bound_stream", None) != want:
+            torch.cuda.set_device(self.device_id)
+            self.set_stream(want)
 
     def synchronize(self):
         check(self.lib.hp_ctx_synchronize(self.h))

@@ -61,6 +61,107 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
     }
 }
 
+// The learner's view of a minibatch (ddpg_agent.py:227-243) straight out of the replay buffer: gather (her.py:26), relabel
+// (:35-36), reward (:38), _preproc_og clip (:214-217), both normalizers (normalizer.py:67-70), concatenate, float32 -- the
+// arithmetic of the chain kernels' in-launch gather (slab8.h s8_gather), as a kernel of its own with DEVICE outputs:
+//   x [B][od+gd] = norm(clip(obs[e][t])) | norm(clip(g'))      x_next = norm(clip(obs[e][t+1])) | norm(clip(g'))
+//   a [B][ad]    = float32(actions[e][t])  (the critic divides by max_action itself, models.py:38)     r [B]
+// One wavefront per transition, FS_FLIGHT transitions in flight per wavefront.  A transition's source elements are
+// [obs t | obs t+1 | ag t+1 | g' | action] = 2 od + 2 gd + ad doubles -- exactly 64 for the bmirobot shapes (27, 3, 4), i.e.
+// ONE 8-byte load per lane, of which the first 54 lanes read one contiguous 432-byte run.  HBM-bound: 67 doubles read,
+// 65 floats written per transition.
+#define FS_FLIGHT 4
+struct FusedSampleArgs {
+    const double *obs, *ag, *g, *act;
+    const PlanRec *plan;
+    const NormDev *onz, *gnz;
+    long long batch;
+    int T, od, gd, ad;
+    double sq_threshold, clip_obs, clip_o, clip_g;
+    float *x, *xn, *a, *r;
+    long long *o_e, *o_t, *o_fut;
+    unsigned char *o_her;
+};
+
+__global__ __launch_bounds__(256) void k_gather_fused(const FusedSampleArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int od = A.od, gd = A.gd, ad = A.ad, ldx = od + gd, Q = 2 * od + 2 * gd + ad;
+    for (long long base = wave * FS_FLIGHT; base < A.batch; base += n_waves * FS_FLIGHT) {
+        PlanRec rec[FS_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FS_FLIGHT; ++k) rec[k] = A.plan[base + k < A.batch ? base + k : A.batch - 1];
+        for (int q0 = 0; q0 < Q; q0 += 64) {   // one pass for the bmirobot shapes
+            const int q = q0 + lane;
+            // what this lane's source element is: 0 obs t, 1 obs t+1, 2 ag t+1 (reward only), 3 g', 4 action, 5 nothing
+            const int kind = q < od ? 0 : q < 2 * od ? 1 : q < 2 * od + gd ? 2 : q < 2 * od + 2 * gd ? 3 : q < Q ? 4 : 5;
+            const int j = kind == 0 ? q : kind == 1 ? q - od : kind == 2 ? q - 2 * od : kind == 3 ? q - 2 * od - gd : q - 2 * od - 2 * gd;
+            float mu = 0.f;
+            double sd = 1.0, clip = 0.0;
+            if (kind <= 1) { mu = A.onz->mean[j]; sd = A.onz->std[j]; clip = A.clip_o; }
+            if (kind == 3) { mu = A.gnz->mean[j]; sd = A.gnz->std[j]; clip = A.clip_g; }
+            double v[FS_FLIGHT];
+#pragma unroll
+            for (int k = 0; k < FS_FLIGHT; ++k) {
+                const long long e = rec[k].e;
+                const int t = rec[k].t;
+                const double *obs0 = A.obs + (e * (A.T + 1) + t) * od;
+                const double *g_src = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;
+                // address-selected, unconditional load (idle lanes re-read element 0 of the observation row)
+                const double *p = kind <= 1 ? obs0 + q : kind == 2 ? A.ag + (e * (A.T + 1) + t + 1) * gd + j
+                                : kind == 3 ? g_src + j : kind == 4 ? A.act + (e * A.T + t) * ad + j : obs0;
+                v[k] = *p;
+            }
+#pragma unroll
+            for (int k = 0; k < FS_FLIGHT; ++k) {
+                const long long m = base + k;
+                if (m >= A.batch) continue;
+                if (kind <= 1 || kind == 3) {
+                    double c = fmin(fmax(v[k], -A.clip_obs), A.clip_obs);                 // _preproc_og
+                    c = __ddiv_rn(__dsub_rn(c, (double)mu), sd);                          // normalizer.normalize
+                    const float x = (float)fmin(fmax(c, -clip), clip);
+                    if (kind == 0) { if (A.x) A.x[m * ldx + j] = x; }
+                    else if (kind == 1) { if (A.xn) A.xn[m * ldx + j] = x; }
+                    else {
+                        if (A.x) A.x[m * ldx + od + j] = x;
+                        if (A.xn) A.xn[m * ldx + od + j] = x;
+                    }
+                } else if (kind == 4) {
+                    if (A.a) A.a[m * ad + j] = (float)v[k];
+                }
+            }
+        }
+        // reward: lanes < gd hold (ag_next - g')^2 of their component, lane 0 adds them in index order (numpy's add.reduce
+        // over < 8 contiguous elements is a left-to-right sum)
+        double sq[FS_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FS_FLIGHT; ++k) {
+            const long long e = rec[k].e;
+            const int t = rec[k].t, c = lane < gd ? lane : gd - 1;
+            const double *g_src = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;
+            const double d = __dsub_rn(A.ag[(e * (A.T + 1) + t + 1) * gd + c], g_src[c]);
+            sq[k] = __dmul_rn(d, d);
+        }
+#pragma unroll
+        for (int k = 0; k < FS_FLIGHT; ++k) {
+            const long long m = base + k;
+            double s = 0.0;
+            for (int c = 0; c < gd; ++c) {
+                const double sc = __shfl(sq[k], c);
+                s = (c == 0) ? sc : __dadd_rn(s, sc);
+            }
+            if (m < A.batch && lane == 0) {
+                if (A.r) A.r[m] = hp_reward(s, A.sq_threshold);
+                if (A.o_e) A.o_e[m] = rec[k].e;
+                if (A.o_t) A.o_t[m] = rec[k].t;
+                if (A.o_fut) A.o_fut[m] = rec[k].fut;
+                if (A.o_her) A.o_her[m] = (unsigned char)rec[k].her;
+            }
+        }
+    }
+}
+
 // Batched compute_reward / _is_success of the bmirobot GoalEnvs (bmirobot_env_push_F.py:84-90, :243-245; identical in
 // bmirobot_env_pickandplace_v2.py) on device arrays [n][goal_dim] float64.  mode 0: sparse reward -(d > thr) as float32
 // (bits 0x80000000 / 0xBF800000); mode 1: dense reward -d as float64; mode 2: success (d < thr) as float32.
@@ -425,6 +526,95 @@ int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, 
         if (o->future_t) o->future_t[i] = hplan[i].fut;
         if (o->her) o->her[i] = (uint8_t)hplan[i].her;
     }
+    return HP_OK;
+}
+
+// replay_buffer.sample + the learner's preprocessing (ddpg_agent.py:227-243) with device outputs: index draw, then the fused
+// gather.  Asynchronous on the context's stream; the outputs are caller-owned device memory (e.g. torch tensors).
+static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_norm *on, hp_norm *gn, int64_t batch,
+                                      double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+    FusedSampleArgs A;
+    A.obs = b->d_obs; A.ag = b->d_ag; A.g = b->d_g; A.act = b->d_act;
+    A.plan = d_plan;
+    A.onz = on->d; A.gnz = gn->d;
+    A.batch = batch;
+    A.T = b->T; A.od = b->obs_dim; A.gd = b->goal_dim; A.ad = b->act_dim;
+    A.sq_threshold = sq_threshold;
+    A.clip_obs = clip_obs;
+    A.clip_o = on->clip; A.clip_g = gn->clip;
+    A.x = o->x; A.xn = o->x_next; A.a = o->actions; A.r = o->r;
+    A.o_e = reinterpret_cast<long long *>(o->e); A.o_t = reinterpret_cast<long long *>(o->t);
+    A.o_fut = reinterpret_cast<long long *>(o->future_t);
+    A.o_her = o->her;
+    const int64_t waves = (batch + FS_FLIGHT - 1) / FS_FLIGHT, wgs = (waves + 3) / 4;
+    const int64_t cap = (int64_t)b->ctx->cu_count * 8;            // grid-stride beyond 8 workgroups per compute unit
+    hipLaunchKernelGGL(k_gather_fused, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
+static int sample_dev_check(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double clip_obs,
+                            const hp_sample_dev_out *o, const char *who) {
+    HP_REQUIRE(b && rng && on && gn && o, HP_ERR_INVALID, "%s: null argument", who);
+    HP_REQUIRE(on->ctx == b->ctx && gn->ctx == b->ctx && rng->ctx == b->ctx, HP_ERR_INVALID, "%s: handles of different contexts", who);
+    HP_REQUIRE(on->size == b->obs_dim && gn->size == b->goal_dim, HP_ERR_INVALID,
+               "%s: normalizer sizes (%d, %d) do not match the buffer's observation / goal widths (%d, %d)", who, on->size, gn->size,
+               b->obs_dim, b->goal_dim);
+    HP_REQUIRE(batch > 0, HP_ERR_INVALID, "%s: batch must be positive", who);
+    HP_REQUIRE(clip_obs > 0, HP_ERR_INVALID, "%s: clip_obs must be positive (arguments.py:87; pass a huge value for none)", who);
+    HP_REQUIRE(b->goal_dim <= 64, HP_ERR_INVALID, "%s: goal_dim > 64", who);
+    return HP_OK;
+}
+
+extern "C" int hp_buffer_sample_dev(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double future_p,
+                                    double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+    HP_TRY(sample_dev_check(b, rng, on, gn, batch, clip_obs, o, "hp_buffer_sample_dev"));
+    HP_SERIALISE(b);
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");  // np.random.randint(0, 0, B), her.py:24
+    HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
+    PlanRec *d_plan = b->plan.as<PlanRec>();
+    HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    return buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, o);
+}
+
+// diagnostic twin of hp_buffer_sample_device_us for the fused kernel (outputs into library scratch)
+extern "C" int hp_buffer_sample_dev_us(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double future_p,
+                                       double sq_threshold, double clip_obs, int32_t reps, double *draw_us, double *gather_us) {
+    hp_sample_dev_out o;
+    memset(&o, 0, sizeof(o));
+    HP_TRY(sample_dev_check(b, rng, on, gn, batch, clip_obs, &o, "hp_buffer_sample_dev_us"));
+    HP_REQUIRE(draw_us && gather_us && reps > 0, HP_ERR_INVALID, "hp_buffer_sample_dev_us: bad argument");
+    HP_SERIALISE(b);
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    hipStream_t s = b->ctx->stream;
+    const size_t ldx = (size_t)(b->obs_dim + b->goal_dim);
+    HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
+    HP_TRY(b->out.ensure((size_t)batch * (2 * ldx + b->act_dim + 1) * 4));
+    PlanRec *d_plan = b->plan.as<PlanRec>();
+    o.x = b->out.as<float>();
+    o.x_next = o.x + batch * ldx;
+    o.actions = o.x_next + batch * ldx;
+    o.r = o.actions + batch * b->act_dim;
+    hipEvent_t e0, e1, e2;
+    HP_CHECK_HIP(hipEventCreate(&e0));
+    HP_CHECK_HIP(hipEventCreate(&e1));
+    HP_CHECK_HIP(hipEventCreate(&e2));
+    HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));   // warm
+    HP_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    HP_CHECK_HIP(hipEventRecord(e1, s));
+    for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));
+    HP_CHECK_HIP(hipEventRecord(e2, s));
+    HP_CHECK_HIP(hipEventSynchronize(e2));
+    float ms01 = 0.f, ms12 = 0.f;
+    HP_CHECK_HIP(hipEventElapsedTime(&ms01, e0, e1));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms12, e1, e2));
+    *draw_us = 1e3 * ms01 / reps;
+    *gather_us = 1e3 * ms12 / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
     return HP_OK;
 }
 

@@ -101,8 +101,19 @@ int hp_ctx_create(int device_id, hp_ctx **out) {
 
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream) {
     HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_set_stream: null ctx");
-    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    CtxGuard guard(ctx);
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream) {
+        // what the context enqueued so far stays ordered in front of what it enqueues next (a store on the old stream, a
+        // sample on the new one): the new stream waits for an event behind the old stream's work, no host wait
+        hipEvent_t ev;
+        HP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+        (void)hipEventDestroy(ev);    // released once the wait has been satisfied
+        HP_CHECK_HIP(e);
+    }
+    ctx->stream = next;
     return HP_OK;
 }
 

@@ -110,6 +110,32 @@ class DeviceEpisodeBuffer:
             return tr, idx
         return tr
 
+    def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False):
+        """hp_buffer_sample_dev: the minibatch as the learner consumes it (ddpg_agent.py:227-243) in torch CUDA tensors
+        allocated here, written on torch's current stream: x, x_next [B, obs+goal], actions [B, act], r [B, 1], float32."""
+        import torch
+
+        self.ctx.on_torch_stream()
+        B = int(batch)
+        dev = torch.device("cuda", self.ctx.device_id)
+        ldx = self.dims["obs"] + self.dims["g"]
+        out = {"x": torch.empty((B, ldx), dtype=torch.float32, device=dev),
+               "x_next": torch.empty((B, ldx), dtype=torch.float32, device=dev),
+               "actions": torch.empty((B, self.dims["actions"]), dtype=torch.float32, device=dev),
+               "r": torch.empty((B, 1), dtype=torch.float32, device=dev)}
+        o = _lib.SampleDevOut()
+        for k, t in out.items():
+            setattr(o, k, t.data_ptr())
+        idx = None
+        if with_indices:
+            idx = {k: torch.empty(B, dtype=torch.int64, device=dev) for k in ("e", "t", "future_t")}
+            idx["her"] = torch.empty(B, dtype=torch.uint8, device=dev)
+            for k, t in idx.items():
+                setattr(o, k, t.data_ptr())
+        _lib.check(self.lib.hp_buffer_sample_dev(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold),
+                                                 float(clip_obs), C.byref(o)))
+        return (out, idx) if with_indices else out
+
     def __del__(self):
         try:
             self.lib.hp_buffer_destroy(self.h)
@@ -177,3 +203,14 @@ class replay_buffer:
         if self._sampler is None:
             raise TypeError("replay_buffer was built without a sample_func")
         return self._dev.sample(self.rng, batch_size, self._sampler.future_p, self._sampler.sq_threshold)
+
+    def sample_device(self, batch_size, o_norm, g_norm, clip_obs=200):
+        """`sample(batch_size)` followed by the learner's preprocessing (ddpg_agent.py:227-243: _preproc_og, both
+        normalizers, concatenate, float32 tensors) in one gather kernel with device outputs: a dict of torch CUDA tensors
+        `x` (inputs_norm_tensor), `x_next` (inputs_next_norm_tensor), `actions` (actions_tensor), `r` (r_tensor, [B, 1]).
+        Same draws from the same stream and bit-identical float32 values as sample() + normalize() on the host; nothing
+        crosses PCIe.  o_norm / g_norm: this package's normalizer objects; clip_obs: arguments.py:87."""
+        if self._sampler is None:
+            raise TypeError("replay_buffer was built without a sample_func")
+        return self._dev.sample_device(self.rng, o_norm, g_norm, batch_size, self._sampler.future_p,
+                                       self._sampler.sq_threshold, clip_obs)

@@ -51,7 +51,7 @@ def test_stable_and_diagnostic_surfaces_are_separate():
     assert debug == _lib.DEBUG_SYMBOLS
     assert not [s for s in stable if "debug" in s or s in ("hp_agent_set_adam", "hp_ctx_launch_floor")]
     version = int(re.search(r"#define\s+HP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert version == _lib.ABI_VERSION == 2
+    assert version == _lib.ABI_VERSION == 3
     if os.path.exists(os.path.join(PKG, "librlarm_hip.so")):
         assert ctypes.CDLL(os.path.join(PKG, "librlarm_hip.so")).hp_abi_version() == version
 

@@ -5,7 +5,7 @@ import pytest
 
 from conftest import bits, load_golden
 from gpu_common import ENV_PARAMS, DeviceEpisodeBuffer, fresh_rng, state_equal
-from oracle.her_replay import EpisodeStore, future_probability
+from oracle.her_replay import EpisodeStore, compute_reward, future_probability
 from rl_arm_under_sparse_reward_amd.her import her_sampler, squared_threshold
 from rl_arm_under_sparse_reward_amd.replay_buffer import replay_buffer
 from rl_arm_under_sparse_reward_amd.synthetic import episode_checksum, make_episodes
@@ -284,3 +284,116 @@ def test_wide_goals_are_refused_not_relabelled_with_other_bits():
         with pytest.raises(NotImplementedError, match="fewer than 8 goal components"):
             her_sampler("future", 4, None, goal_dim=gd)
     her_sampler("future", 4, None, goal_dim=7)
+
+
+# ---- device-output fused sampler (hp_buffer_sample_dev; SURVEY 8b `hp_sample(... out device ptrs x, x', a, r)`) -------------
+def _primed_normalizers(eps, seed=9):
+    """Oracle normalizers with non-trivial statistics + device normalizers holding exactly the same state."""
+    from oracle.running_norm import RunningNorm
+    from rl_arm_under_sparse_reward_amd.normalizer import normalizer
+    from gpu_common import ctx
+
+    rs = np.random.RandomState(seed)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    o_dev, g_dev = normalizer(27, default_clip_range=5, ctx=ctx()), normalizer(3, default_clip_range=5, ctx=ctx())
+    rows = rs.randint(0, eps[0].shape[0], 100)
+    o = eps[0][rows, rs.randint(0, 100, 100)] * 3.0 + 0.25        # wide enough that the +-5 clip bites on some columns
+    g = eps[2][rows, rs.randint(0, 100, 100)]
+    for a, b in ((on, o_dev), (gn, g_dev)):
+        v = o if a is on else g
+        a.update(v); b.update(v)
+        a.recompute_stats(); b.recompute_stats()
+    assert np.array_equal(bits(on.mean), bits(o_dev.mean)) and np.array_equal(bits(gn.std), bits(g_dev.std))
+    return on, gn, o_dev, g_dev
+
+
+def _assert_minibatch_equal(got, tr, on, gn, clip_obs=200):
+    from oracle.ddpg_update import minibatch_tensors
+
+    x, xn, a, r = (t.numpy() for t in minibatch_tensors(tr, on, gn, clip_obs))
+    for key, ref in (("x", x), ("x_next", xn), ("actions", a), ("r", r)):
+        dev = got[key].cpu().numpy()
+        assert dev.dtype == np.float32 and dev.shape == ref.shape, (key, dev.shape, ref.shape)
+        assert np.array_equal(bits(dev), bits(ref)), key
+
+
+def test_sample_device_golden_bitwise():
+    """The reference-generated HER goldens through ddpg_agent.py:227-243's preprocessing (oracle.minibatch_tensors) ==
+    hp_buffer_sample_dev's device tensors, bit for bit, and the random stream ends where the reference's did."""
+    g = load_golden("her_sample.npz")
+    for tag in g["cases"]:
+        tag = str(tag)
+        n, B, k, seed, dseed = (int(x) for x in g[tag + "_meta"])
+        eps = make_episodes(n, seed=dseed, mode=str(g[tag + "_mode"]))
+        on, gn, o_dev, g_dev = _primed_normalizers(eps)
+        dev = fresh_rng(seed)
+        sampler = her_sampler("future", k, rng=dev)
+        buf = replay_buffer(ENV_PARAMS, n * 100, sampler.sample_her_transitions, rng=dev)
+        buf.store_episode(eps)
+        got = buf.sample_device(B, o_dev, g_dev, clip_obs=200)
+        assert set(got) == {"x", "x_next", "actions", "r"} and all(t.is_cuda for t in got.values())
+        _assert_minibatch_equal(got, {key: g[f"{tag}_{key}"] for key in KEYS}, on, gn)
+        assert state_equal(dev, g[tag + "_key"], g[tag + "_pos"]), tag
+
+
+@pytest.mark.parametrize("n,B,k,mode,clip_obs", [(5000, 256, 4, "iid", 200), (5000, 4096, 8, "walk", 200),
+                                                  (37, 1001, 4, "walk", 0.4), (5000, 65536, 4, "iid", 200)])
+def test_sample_device_matches_oracle_at_baseline_sizes(n, B, k, mode, clip_obs):
+    """5000-episode shard at batch 256 / 4096 (BASELINE configs 2, 5), a ragged batch with a biting _preproc_og clip, and a
+    batch large enough that the kernel grid-strides; indices, rewards and float32 rows bit-equal, three draws in a row
+    interleaved with the host-output sampler on the same stream."""
+    eps = make_episodes(n, seed=1, mode=mode)
+    fp = future_probability("future", k)
+    st = EpisodeStore(100, 27, 3, 4, n * 100)
+    rs = np.random.RandomState(125)
+    st.store_episode(eps, rs)
+    on, gn, o_dev, g_dev = _primed_normalizers(eps)
+    dev = fresh_rng(125)
+    buf = DeviceEpisodeBuffer(n, 100, 27, 3, 4)
+    buf.store(dev, eps)
+    for i in range(3):
+        ref, ridx = st.sample(B, fp, rs)
+        if i == 1:       # the host-output sampler draws from the same stream in between
+            tr = buf.sample(dev, B, fp, squared_threshold(0.05))
+            assert np.array_equal(bits(tr["obs"]), bits(ref["obs"]))
+            continue
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, fp, squared_threshold(0.05), clip_obs, with_indices=True)
+        _assert_minibatch_equal(got, ref, on, gn, clip_obs)
+        for key in ("e", "t", "future_t"):
+            assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), key
+        assert np.array_equal(idx["her"].cpu().numpy().astype(bool), ridx["her"])
+    assert state_equal(dev, *rs.get_state()[1:3])
+    assert set(np.unique(got["r"].cpu().numpy().view(np.uint32))) <= {0x80000000, 0xBF800000}
+
+
+def test_sample_device_dense_reward_partial_outputs_and_errors():
+    """Dense reward (compute_reward :89-90 narrowed to float32 as ddpg_agent.py:243 does), NULL outputs, and the reference's
+    error on an empty buffer."""
+    import ctypes as C
+    import torch
+    from rl_arm_under_sparse_reward_amd import _lib
+
+    eps = make_episodes(12, seed=4, mode="walk")
+    on, gn, o_dev, g_dev = _primed_normalizers(eps)
+    st = EpisodeStore(100, 27, 3, 4, 1200)
+    rs = np.random.RandomState(7)
+    st.store_episode(eps, rs)
+    dev = fresh_rng(7)
+    buf = DeviceEpisodeBuffer(12, 100, 27, 3, 4)
+    with pytest.raises(ValueError, match="high <= 0"):
+        buf.sample_device(dev, o_dev, g_dev, 8, 0.8, squared_threshold(0.05), 200)
+    buf.store(dev, eps)
+    ref, _ = st.sample(300, 0.8, rs, reward_fn=lambda a, b: compute_reward(a, b, reward_type="dense"))
+    got = buf.sample_device(dev, o_dev, g_dev, 300, 0.8, -1.0, 200)
+    assert ref["r"].dtype == np.float64            # compute_reward :89-90; torch.tensor(.., float32) narrows it (:243)
+    _assert_minibatch_equal(got, ref, on, gn)
+    # only r requested
+    r = torch.empty(64, dtype=torch.float32, device="cuda")
+    o = _lib.SampleDevOut()
+    o.r = r.data_ptr()
+    lib = buf.lib
+    _lib.check(lib.hp_buffer_sample_dev(buf.h, dev.h, o_dev.h, g_dev.h, 64, 0.8, squared_threshold(0.05), 200.0, C.byref(o)))
+    torch.cuda.synchronize()
+    assert set(np.unique(r.cpu().numpy().view(np.uint32))) <= {0x80000000, 0xBF800000}
+    with pytest.raises(ValueError, match="normalizer sizes"):
+        buf.sample_device(dev, g_dev, o_dev, 8, 0.8, squared_threshold(0.05), 200)
