@@ -457,8 +457,10 @@ int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rn
 // utils.sync_grads (utils.py:43-48) + both Adam steps of update u as the peer exchange's optimizer kernel(s) (peer.hip)
 int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after = false);
 // data-parallel ranks: do the weight-gradient tiles exchange by themselves (one launch: gradients + rank exchange + optimizer)?
+// (a launch with more tiles than flag rows takes the separate exchange + optimizer kernel instead of failing)
 static inline bool peer_tiles_ok(const hp_agent *a) {
-    return a->peer && a->peer->tiles && a->peer->phases == 1 && !a->peer->gate && a->slab && !a->dw64 && a->fuse_adam_ok;
+    return a->peer && a->peer->tiles && a->peer->phases == 1 && !a->peer->gate && a->slab && !a->dw64 && a->fuse_adam_ok &&
+           build_dw_group(a, a->XA, a->XP).tiles <= HP_PEER_TILES;
 }
 // can the optimizer launches of this agent apply the soft target update themselves?  (slab engines: yes)
 static inline bool polyak_foldable(const hp_agent *a) { return a->slab; }

@@ -410,8 +410,12 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             // 2. my slot of this tile's flag row on every peer; wait for theirs (bounded; a dead exchange steps nothing)
-            peer_signal_row(D, D.flags_t, bx, epoch);
-            if (!peer_wait(D, D.flags_t[D.rank] + (size_t)bx * HP_PEER_MAX, epoch, 1u)) return;
+            // The flag row names the TILE, not the workgroup: with a split reduction (p.ks > 1) the workgroup that gets here is
+            // whichever slice arrived last -- another slice on another rank, so bx would differ from rank to rank.  tile0 + t
+            // lies inside the problem's own range of the launch order (slice 0's workgroup index) and is the same everywhere.
+            const int row = p.ks > 1 ? p.tile0 + t : bx;
+            peer_signal_row(D, D.flags_t, row, epoch);
+            if (!peer_wait(D, D.flags_t[D.rank] + (size_t)row * HP_PEER_MAX, epoch, 1u)) return;
             // 3. rank-ordered sum (the same float32 expression on every rank: the replicas stay bit-identical)
             const size_t gbytes = (size_t)F->am.la.total * 4 + (size_t)F->am.lc.total * 4;
             float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;

@@ -39,7 +39,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
         os.environ["RLARM_PEER_PHASES"] = "1"
     if transport == "peer2":                 # reduce-scatter + all-gather over the same peer memory (default from 4 ranks)
         os.environ["RLARM_PEER_PHASES"] = "2"
-    if transport == "peertiles":
+    if transport.startswith("peertiles"):
         # Round 4: the tile-wise exchange INSIDE the weight-gradient launch (gemm_lds.h PEER), which ranks that share a device
         # normally avoid (their waits go into gate kernels and the exchange stays a launch of its own).  Forced here with the
         # gates off and a batch small enough that both ranks' launches are co-resident on the one device (53 chain workgroups
@@ -50,6 +50,11 @@ def _worker(rank, world, port, out_dir, transport="torch"):
         os.environ["RLARM_PEER_PHASES"] = "1"
         os.environ["RLARM_PEER_GATE"] = "0"
         os.environ["RLARM_PEER_TIMEOUT_S"] = "5"
+    if transport == "peertilesks":
+        # with a SPLIT reduction of the narrow problems (default from batch 768) the workgroup that reaches the
+        # exchange is whichever slice arrived last -- a different workgroup index on every rank -- so the flag row must name the
+        # tile, not the workgroup.  Forced at a batch that still lets both ranks' launches share the device.
+        os.environ["RLARM_DW_KSPLIT"] = "2"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -70,7 +75,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     torch.set_num_threads(2)
     comm = Communicator(0)
     assert comm.active and comm.world_size == world
-    n_eps, batch, seed = 32, (64 if transport == "peertiles" else 256), 125 + rank
+    n_eps, batch, seed = 32, {"peertiles": 64, "peertilesks": 128}.get(transport, 256), 125 + rank
     eps = make_episodes(n_eps, seed=40 + rank, mode="walk")
     # ---- device side
     torch.manual_seed(100 + rank)            # ranks start from DIFFERENT nets; sync_networks must fix that (C1)
@@ -167,7 +172,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("peertiles", 2), ("auto", 4), ("torch", 4), ("peer", 4)],
+@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("peertiles", 2), ("peertilesks", 2), ("auto", 4), ("torch", 4), ("peer", 4)],
                 ids=lambda p: f"{p[0]}-w{p[1]}")
 def two_ranks(request, tmp_path_factory):
     """torch: collectives through torch.distributed (gloo, host-staged) from a host-driven loop.
@@ -180,7 +185,7 @@ def two_ranks(request, tmp_path_factory):
     at 4 ranks, (torch, 4) the host-driven fallback.  All against the 4-rank oracle."""
     transport, world = request.param
     out = tmp_path_factory.mktemp(f"gpu{world}_{transport}")
-    if transport == "peertiles":
+    if transport.startswith("peertiles"):
         # The tile-wise form lets a launch WAIT for the peer's launch: on real ranks (a device each) that is the design; with
         # two processes on ONE device it only works while both launches are resident together, which the dispatcher does not
         # promise (one rank's waiting tiles can hold the LDS the other rank's chain workgroups need).  A rehearsal that starved
