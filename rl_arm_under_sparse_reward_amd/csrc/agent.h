@@ -62,6 +62,7 @@ struct GemmGroup {
     int uni;    // ring loop with the wave index in a scalar register (gemm_lds.h)
     int bias0;  // > 0: the bias gradients + their optimizer step run in workgroups of their own from this block index on (one per
                 // 32-row panel of every problem that has a bias vector: gemm_lds.h gemm_bias_tile); the tiles then skip them
+    int loss_wg; // 1: the LAST workgroup of the launch writes the loss log (gemm_lds.h gemm_loss_wg), workgroup 0 is a plain tile
     float *part;                  // split tiles: GL_PART floats per (tile, slice)
     unsigned long long *ticket;   // split tiles: arrival counter per tile, monotonic over the life of the agent
     GemmProb p[MAX_PROBS];
@@ -228,6 +229,7 @@ struct hp_agent {
     unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
     int adam_wt = -1;                    // RLARM_ADAM_WT=0|1 overrides write-through optimizer stores (default: up to 768 batch rows)
     int gl_uni = -1;                     // RLARM_GEMM_UNI=0|1 overrides the choice by reduction length (gemm_lds.h)
+    int loss_wg = 1;                     // the loss log is written by a workgroup of its own behind the weight-gradient tiles (gemm_lds.h gemm_loss_wg)
     int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
     float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)
     unsigned long long *gl_ticket = nullptr;
@@ -289,6 +291,7 @@ struct Launch {  // builds one grouped launch
         g.xcd = 0;
         g.uni = 0;
         g.bias0 = 0;
+        g.loss_wg = 0;
         g.part = nullptr;
         g.ticket = nullptr;
     }

@@ -114,12 +114,16 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
                                                const PeerTile *PT = nullptr, const TileHead *TH = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];
     __shared__ float bsum[GL_WAVES][32];
+    if (ADAM && !PEER && grp.loss_wg && blockIdx.x == gridDim.x - 1) {   // behind the riders: the loss log's own workgroup (gemm_lds.h)
+        gemm_loss_wg(*F);
+        return;
+    }
     if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0 && (int)blockIdx.x < tiles) {   // (`tiles` counts the bias panels behind the tiles)
         gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum);
         return;
     }
     if ((int)blockIdx.x < tiles) {
-        gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, PT, TH);
+        gemm_tile<ADAM, UNI, false, PEER>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0 && (PEER || !grp.loss_wg), PT, TH);
         return;
     }
     const int extra = (int)blockIdx.x - tiles;
@@ -141,7 +145,9 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride(const GemmGroup gr
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride(unsigned long long t03, unsigned long long t47, int tiles,
                                                                    const GemmGroup grp, const AdamFuse F, const RideArgs R) {
     const TileHead TH{t03, t47};   // (leading scalars: preloaded with the wave, gemm_lds.h)
+    const unsigned sink = kernarg_prefetch<24 + sizeof(GemmGroup) + sizeof(AdamFuse) + sizeof(RideArgs)>();
     gemm_ride_body<true>(grp, &F, R, tiles, nullptr, &TH);
+    kernarg_prefetch_keep(sink);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride_u(const GemmGroup grp, const RideArgs R, int tiles) {
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride_u(const GemmGroup 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(unsigned long long t03, unsigned long long t47, int tiles,
                                                                      const GemmGroup grp, const AdamFuse F, const RideArgs R) {
     const TileHead TH{t03, t47};
+    const unsigned sink = kernarg_prefetch<24 + sizeof(GemmGroup) + sizeof(AdamFuse) + sizeof(RideArgs)>();
     gemm_ride_body<true, true>(grp, &F, R, tiles, nullptr, &TH);
+    kernarg_prefetch_keep(sink);
 }
 
 // data-parallel ranks, tile-wise one-shot exchange (gemm_lds.h PEER): weight gradients + rank exchange + optimizer step in ONE
@@ -743,7 +751,8 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 if (gc->polyak_after) fold_polyak(a, F);
-                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.head(0), L.head(1),
+                L.g.loss_wg = a->loss_wg;
+                hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid + L.g.loss_wg), dim3(GL_THREADS), 0, s, L.head(0), L.head(1),
                                    front, L.g, F, R);
             } else {
                 hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, front);
@@ -757,7 +766,8 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
             if (gc && gc->polyak_after) fold_polyak(a, F);
             const int front = L.tiles + (sep_bias_on(a) ? L.separate_bias() : 0);
-            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, L.head(0), L.head(1), L.g, F);
+            L.g.loss_wg = a->loss_wg;
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front + L.g.loss_wg), dim3(GL_THREADS), 0, s, L.head(0), L.head(1), L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
             HP_TRY(launch_group(a, L, PROF_DW));
@@ -867,7 +877,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         if (gc->polyak_after) fold_polyak(a, Fa);
         Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
         const int front = La.tiles + (sep_bias_on(a) ? La.separate_bias() : 0);
-        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa);
+        La.g.loss_wg = a->loss_wg;
+        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front + La.g.loss_wg), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa);
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;

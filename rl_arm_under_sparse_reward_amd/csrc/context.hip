@@ -106,12 +106,17 @@ int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream) {
     if (next != ctx->stream) {
         // what the context enqueued so far stays ordered in front of what it enqueues next (a store on the old stream, a
         // sample on the new one): the new stream waits for an event behind the old stream's work, no host wait
-        hipEvent_t ev;
-        HP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(ev, ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
-        (void)hipEventDestroy(ev);    // released once the wait has been satisfied
-        HP_CHECK_HIP(e);
+        // (one event per context, re-recorded at every switch: an event destroyed with a wait still pending is not safe).
+        // The special handles (hipStreamLegacy = 1, hipStreamPerThread = 2) take no event records on this runtime: a host wait
+        // for the old stream instead -- a switch is a rare, set-up time call.
+        const bool special = (uintptr_t)ctx->stream <= 2 || (uintptr_t)next <= 2;
+        if (special) {
+            HP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (!ctx->order_ev) HP_CHECK_HIP(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+            HP_CHECK_HIP(hipEventRecord(ctx->order_ev, ctx->stream));
+            HP_CHECK_HIP(hipStreamWaitEvent(next, ctx->order_ev, 0));
+        }
     }
     ctx->stream = next;
     return HP_OK;
@@ -279,6 +284,7 @@ void hp_ctx_destroy(hp_ctx *ctx) {
     if (!ctx) return;
     ctx->reward_ws.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     delete ctx;
 }
 

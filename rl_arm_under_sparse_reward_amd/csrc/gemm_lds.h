@@ -44,6 +44,7 @@ __device__ unsigned long long g_gemm_tl_blk[8][32][2];   // workgroup GL_BLK_WG'
 __device__ unsigned long long g_gemm_tl_wg[512][8];   // every tile workgroup's stamps (hp_debug_gemm_wg_timeline, time-line builds only)
 #define GL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_gemm_tl[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); \
                           if (threadIdx.x == 0 && blockIdx.x < 512) g_gemm_tl_wg[blockIdx.x][(k)] = wall_clock64(); \
+                          if (threadIdx.x == 0 && blockIdx.x < 512 && (k) == 0) g_gemm_tl_wg[blockIdx.x][6] = __builtin_amdgcn_s_getreg(63492);   /* HW_REG_HW_ID: which CU / SE the workgroup landed on */ \
                           if (threadIdx.x == 0 && blockIdx.x == 0 && (k) < 2) g_gemm_tl[24 + (k)] = __builtin_readcyclecounter(); } while (0)   /* shader cycles over the product loop */
 #else
 #define GL_BLK_STAMP(i, j) do { } while (0)
@@ -590,15 +591,57 @@ __device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamF
     }
 }
 
+// A launch's kernel-argument block is fetched field by field through the scalar cache, each field where the compiler first
+// uses it; the first workgroups of a launch to reach a field take the round trip to memory for it, in every stage (time line of
+// the actor's tile launch: the first five workgroups per XCD ended 0.5-2 us after the others).  Every workgroup therefore
+// touches the whole block with ONE vector load per 128-byte line at entry, so that the lines are on their way into the XCD's L2
+// before the scalar loads ask for them: -0.2 us/update at batch 256 (profiles/r05_ab_kernarg_prefetch.txt).  The same trick on
+// the kernel's CODE (s_getpc, 36 KB) changed nothing and is not kept.  The destination register must stay reserved until the load
+// has returned: the kernel keeps it alive to its end (kernarg_prefetch_keep).
+#ifndef GL_KERNARG_PREFETCH
+#define GL_KERNARG_PREFETCH 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ unsigned kernarg_prefetch() {
+    unsigned sink = 0;
+#if GL_KERNARG_PREFETCH
+    static_assert(BYTES <= GL_THREADS * 128, "one load per thread covers the block");
+    const char *ka = (const char *)(unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)threadIdx.x * 128;
+    if ((int)threadIdx.x * 128 < BYTES) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(ka) : "memory");
+#endif
+    return sink;
+}
+__device__ __forceinline__ void kernarg_prefetch_keep(unsigned sink) {
+#if GL_KERNARG_PREFETCH
+    asm volatile("" ::"v"(sink));
+#endif
+}
+
+// The loss log of the update (and, behind a split launch, the reset of the counter set that launch counted in) used to be
+// workgroup 0's first job: its wave 0 went through two dependent cold round trips before it issued its first operand block, so
+// that tile was the launch's last to end (7.6 us against a median of 5.4).  GemmGroup::loss_wg: the launch has one more
+// workgroup, its last, that does nothing else.
+__device__ __forceinline__ void gemm_loss_wg(const AdamFuse &F) {
+    const int tid = threadIdx.x;
+    if (tid < 64) loss_finalize(F);
+    else if (tid < 64 + SPLIT_COUNTERS * 8 && F.reset_sync)
+        __hip_atomic_store(F.reset_sync + (tid - 64) * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool ADAM, bool UNI = false>
 __device__ __forceinline__ void gemm_lds_body(const GemmGroup &grp, const AdamFuse *F, const TileHead *TH = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[GL_LDS_FLOATS];  // A image | B image; reused for the reduction
     __shared__ float bsum[GL_WAVES][32];
-    if (grp.bias0 > 0 && (int)blockIdx.x >= grp.bias0) {
-        gemm_bias_tile<ADAM>(grp, F, (int)blockIdx.x - grp.bias0, lds, bsum);
+    if (ADAM && grp.loss_wg && blockIdx.x == gridDim.x - 1) {
+        gemm_loss_wg(*F);
         return;
     }
-    gemm_tile<ADAM, UNI>(grp, F, (int)blockIdx.x, lds, bsum, blockIdx.x == 0, nullptr, TH);
+    const int bx = (int)blockIdx.x;
+    if (grp.bias0 > 0 && bx >= grp.bias0) {
+        gemm_bias_tile<ADAM>(grp, F, bx - grp.bias0, lds, bsum);
+        return;
+    }
+    gemm_tile<ADAM, UNI>(grp, F, bx, lds, bsum, bx == 0 && !grp.loss_wg, nullptr, TH);
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { gemm_lds_body<false>(grp, nullptr); }
@@ -606,7 +649,9 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds(const GemmGroup grp) { 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
                                                               const AdamFuse F) {
     const TileHead TH{t03, t47};
+    const unsigned sink = kernarg_prefetch<16 + sizeof(GemmGroup) + sizeof(AdamFuse)>();
     gemm_lds_body<true>(grp, &F, &TH);
+    kernarg_prefetch_keep(sink);
 }
 // the same kernels with the wave index in a scalar register (gemm_tile's UNI; kernels of their own so that each form keeps
 // its own register allocation: both forms inside one kernel cost either of them 0.3-0.6 us/update)
@@ -614,5 +659,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_u(const GemmGroup grp) 
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_u(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
                                                                 const AdamFuse F) {
     const TileHead TH{t03, t47};
+    const unsigned sink = kernarg_prefetch<16 + sizeof(GemmGroup) + sizeof(AdamFuse)>();
     gemm_lds_body<true, true>(grp, &F, &TH);
+    kernarg_prefetch_keep(sink);
 }

@@ -65,6 +65,7 @@ struct hp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // stream kernels are enqueued on
     hipStream_t own_stream = nullptr;  // created by the context
+    hipEvent_t order_ev = nullptr;     // hp_ctx_set_stream: orders the new stream behind the old one's work
     int cu_count = 0;
     char name[128] = {0};
     // Every entry point that enqueues on the stream or touches a handle's host mirror holds this for the duration of the

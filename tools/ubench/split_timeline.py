@@ -89,5 +89,14 @@ try:
         for k, kn in ((0, "start"), (1, "products done"), (3, "LDS sums ready"), (4, "gate + bias step done"), (5, "end")):
             c = [(wg[8 * b + k] - wg[8 * b]) / 100 for b in sel if wg[8 * b + k] and wg[8 * b]]
             if c: print(f"[{nm}] since own start: {kn:22s} {stat(c)}")
+        if nm.startswith("actor") and os.environ.get("TL_ROWS", "1") != "0":
+            # every workgroup of the launch behind the split launch: stamps since the launch's first start (0 start, 1 operands
+            # landed / products done, 2 product loop left, 3 LDS sums ready, 4 gate + bias, 5 end)
+            print(f"[{nm}] per workgroup (index: start | 1 2 3 4 5 since own start), slowest 40 by end:")
+            per = sorted(((wg[8 * b + 5] - b0) / 100, b) for b in sel if wg[8 * b + 5] and wg[8 * b])
+            for t, b in (per if os.environ.get('TL_ROWS') == 'all' else per[-40:]):
+                hw = wg[8 * b + 6]
+                print(f"   wg {b:3d} xcd {b % 8} slot {b // 8:2d} cu {(hw >> 8) & 15:2d} sh {(hw >> 12) & 1} se {(hw >> 13) & 7}: start {(wg[8 * b] - b0) / 100:5.2f} | " +
+                      " ".join(f"{(wg[8 * b + k] - wg[8 * b]) / 100:5.2f}" if wg[8 * b + k] else "  -  " for k in (1, 2, 3, 4, 5)) + f" | end {t:5.2f}")
 except AttributeError:
     pass
