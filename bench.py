@@ -283,8 +283,33 @@ def cpu_baseline(a, seconds):
                     break
     except OSError:
         pass
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case -- buffer 1e4 (100 episodes), batch 256, replay_k 4,
+    # ONE worker thread.  Timed beside the headline workload's figure, same oracle.
+    torch.set_num_threads(1)
+    eps1 = make_episodes(100, seed=1)
+    rs1 = np.random.RandomState(125)
+    st1 = EpisodeStore(100, 27, 3, 4, 100 * 100)
+    st1.store_episode(eps1, rs1)
+    fp1 = future_probability("future", 4)
+    on1, gn1 = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    update_normalizers(on1, gn1, [x[:2] for x in eps1], fp1, rs1)
+    learner = oupd.DDPGLearner(oupd.init_actor(27, 3, 4, 0), oupd.init_critic(27, 3, 4, 1))
+    for _ in range(3):
+        tr, _ = st1.sample(256, fp1, rs1)
+        learner.update(*oupd.minibatch_tensors(tr, on1, gn1))
+    n1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < max(2.0, seconds / 4):
+        tr, _ = st1.sample(256, fp1, rs1)
+        learner.update(*oupd.minibatch_tensors(tr, on1, gn1))
+        n1 += 1
+        if n1 % N_BATCHES == 0:
+            learner.soft_update()
+    dt1 = time.perf_counter() - t0
+    config1 = {"value": round(n1 * 256 / dt1, 1), "unit": "transitions/s", "cores": 1, "kind": "port",
+               "sample": f"{n1} sample+update steps at batch 256, replay_k 4 on a 100-episode buffer (buffer_size 1e4), 1 torch thread "
+                         f"({dt1:.1f} s): BASELINE.json configs[0]"}
     return {
-        "value": round(res[best][0], 1), "unit": "transitions/s", "cores": best, "kind": "port",
+        "value": round(res[best][0], 1), "unit": "transitions/s", "cores": best, "kind": "port", "config1": config1,
         "sample": f"{res[best][1]} sample+update steps at batch {a.batch} on a {n_eps}-episode buffer "
                   f"({res[best][2]:.1f} s), oracle = numpy legacy-RNG sampler + torch-CPU update",
         "value_by_threads": {str(k): round(v[0], 1) for k, v in res.items()}, "host_cpu": model, "host_cores": cores,
@@ -350,6 +375,108 @@ def first_cycle_or_fallback(a, rank, world, force_dp, shared):
     raise RuntimeError(f"no exchange transport completed the first cycle: {last}")
 
 
+def exchange_name(agent):
+    """What actually carries the gradient exchange of this agent: (transport, peer phases or None)."""
+    import ctypes as C
+    if agent._peer is not None:
+        ph = C.c_int32()
+        agent.lib.hp_peer_phases(agent._peer, C.byref(ph))
+        return "peer-memory", ph.value
+    return ("rccl" if agent._native_comm is not None else "torch.distributed"), None
+
+
+def replicas_identical(r, world, shared):
+    """Data-parallel replicas must hold the SAME networks bit for bit: every rank fingerprints its online + target
+    parameters, all ranks learn whether all fingerprints agree."""
+    import zlib
+
+    import torch
+    import torch.distributed as dist
+    crc = [zlib.crc32(r.agent._get_flat(slot).tobytes()) for slot in (0, 1, 2, 3)]
+    mine = torch.tensor(crc, dtype=torch.int64, device="cpu" if shared else "cuda")
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return all(bool(torch.equal(e, every[0])) for e in every)
+
+
+def time_exchange_alternatives(a, rank, world, shared, ran, n_cycles=10):
+    """N > 1 only, after the timed region (there may be exactly one multi-GPU run): a short timed pass on
+    each exchange transport that did NOT carry the headline -- library-side RCCL inside the cycle graph (what north_star names),
+    the peer-memory exchange in its other form(s), torch.distributed from a host loop -- with us/update and whether the replicas
+    stayed bit-identical.  Every step is agreed on by all ranks; a transport that fails is recorded with its error and the next
+    one is tried, the JSON line is printed whatever happens here."""
+    import torch
+    import torch.distributed as dist
+
+    plans = [("rccl in the cycle graph", {"RLARM_COMM": "rccl"}),
+             ("peer memory, one-shot inside the weight-gradient launch (tile-wise)", {"RLARM_COMM": "peer", "RLARM_PEER_PHASES": "1"}),
+             ("peer memory, one-shot as its own exchange + optimizer launch", {"RLARM_COMM": "peer", "RLARM_PEER_PHASES": "1", "RLARM_PEER_TILES": "0"}),
+             ("peer memory, two-phase (reduce-scatter + all-gather)", {"RLARM_COMM": "peer", "RLARM_PEER_PHASES": "2"}),
+             ("torch.distributed, host-driven loop", {"RLARM_COMM": "torch"})]
+    plain = argparse.Namespace(**{**vars(a), "feeder_episodes": 0, "feeder_envs": 0})   # the passes time the exchange, not a feeder
+    keys = sorted({k for _, env in plans for k in env})
+    saved = {k: os.environ.get(k) for k in keys}
+    out = []
+    dev = "cpu" if shared else "cuda"
+    for name, env in plans:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        rec, ok, r2, err = {"exchange": name, "env": env}, 1, None, None
+        try:
+            r2 = Runner(plain, rank, world, False)
+            if os.environ.get("RLARM_BENCH_FAIL_ALT") and name.startswith(os.environ["RLARM_BENCH_FAIL_ALT"]) and rank == 0:
+                raise RuntimeError("injected failure (RLARM_BENCH_FAIL_ALT)")     # test hook: one rank's pass "fails"
+            r2.run_steps(2 * N_BATCHES)
+            r2.sync()
+            r2.agent.check_exchange()
+        except Exception as e:      # noqa: BLE001 -- every rank must reach the agreement below
+            ok, err = 0, str(e)
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            got, phases = exchange_name(r2.agent)
+            rec["ran_as"] = got + (f", phases {phases}" if phases else "") + (", gate kernels (ranks share a device)" if r2.agent._peer is not None and r2.agent.comm.shared_device else "")
+            try:
+                barrier(world)
+                t0 = time.perf_counter()
+                r2.run_steps(n_cycles * N_BATCHES)
+                r2.sync()
+                barrier(world)
+                dt = time.perf_counter() - t0
+                r2.agent.check_exchange()
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0, str(e)
+                dt = float("nan")
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                td = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(td, op=dist.ReduceOp.MAX)
+                dt = float(td.item())
+                rec.update(us_per_update=round(1e6 * dt / (n_cycles * N_BATCHES), 3),
+                           value=round(world * a.batch * n_cycles * N_BATCHES / dt, 1), steps=n_cycles * N_BATCHES,
+                           replicas_bit_identical=replicas_identical(r2, world, shared),
+                           same_as_headline=(got, phases) == ran and "RLARM_PEER_TILES" not in env)
+            else:
+                rec["error"] = err or "failed on another rank"
+        else:
+            rec["error"] = err or "failed on another rank"
+        if r2 is not None:
+            try:
+                r2.agent.close_comm()
+            except Exception:       # noqa: BLE001
+                pass
+            del r2
+        out.append(rec)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -387,6 +514,10 @@ def main():
     # library capture the partial-cycle graphs that pattern needs (hp_agent_sample_and_update caches one graph per
     # chunk length), then the cycle is completed so that the measured pass starts at the same cycle position and
     # replays the same graphs.  Without it a short --steps would time graph instantiation instead of the hot path.
+    # A timed region shorter than a cycle is placed so that it ENDS on a cycle boundary: the soft target update (polyak) of
+    # that cycle is then inside the region; `pre` untimed steps in front of the warm-up do the placing.
+    pre = (-(a.warmup + a.steps)) % N_BATCHES if a.steps < N_BATCHES else 0
+    r.run_steps(pre)
     r.run_steps(a.warmup)
     r.run_steps(a.steps)
     r.run_steps((-r.in_cycle) % N_BATCHES)
@@ -402,6 +533,7 @@ def main():
     barrier(world)
     if r.env_feeder is not None:
         r.env_thread.start()                 # rollouts run concurrently with everything below
+    r.run_steps(pre)
     r.run_steps(a.warmup)
     r.sync()
     barrier(world)
@@ -431,7 +563,10 @@ def main():
     # cycle-boundary work inside the timed region: [store 2 episodes + normalizer refresh, polyak]; a steady state has
     # one of each per 40 steps
     boundaries = {"store_and_normalizer": r.opens - opens0, "polyak": r.closes - closes0,
-                  "steady_state_would_have": round(a.steps / N_BATCHES, 3)}
+                  "steady_state_would_have": round(a.steps / N_BATCHES, 3),
+                  **({"placement": f"the {a.steps} timed steps are the LAST {a.steps} updates of a cycle: its soft target update is "
+                                   "inside the region, the next cycle's store + normalizer refresh is not (cycle_inclusive_estimate "
+                                   "covers whole cycles)"} if a.steps < N_BATCHES else {})}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -463,14 +598,24 @@ def main():
     losses = r.agent.last_losses(1)[0]
     # data-parallel replicas must hold the SAME networks bit for bit (same summed gradients, same Adam): every rank
     # fingerprints its online + target parameters and rank 0 reports whether all fingerprints agree
-    replicas_identical = None
+    replicas_same = None
+    devices = None
     if world > 1:
-        import zlib
-        crc = [zlib.crc32(r.agent._get_flat(slot).tobytes()) for slot in (0, 1, 2, 3)]
-        mine = torch.tensor(crc, dtype=torch.int64, device="cpu" if shared else "cuda")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        replicas_identical = all(bool(torch.equal(e, every[0])) for e in every)
+        replicas_same = replicas_identical(r, world, shared)
+        # "N ranks on N devices" belongs in the record: every rank's PCI bus id, and how many ranks the exchange itself counts
+        import ctypes as _C0
+        bus = _C0.create_string_buffer(32)
+        r.ctx.lib.hp_ctx_pci_bus_id(r.ctx.h, bus, 32)
+        mine_id = torch.tensor(list(bus.raw), dtype=torch.uint8, device="cpu" if shared else "cuda")
+        ids = [torch.zeros_like(mine_id) for _ in range(world)]
+        dist.all_gather(ids, mine_id)
+        names = [bytes(t.cpu().tolist()).split(b"\0")[0].decode("ascii", "replace") for t in ids]
+        devices = {"pci_bus_ids_by_rank": names, "distinct_devices": len(set(names)), "process_group_backend": dist.get_backend(),
+                   "process_group_ranks": dist.get_world_size()}
+        if r.agent._native_comm is not None:
+            rk, wd = _C0.c_int32(), _C0.c_int32()
+            r.agent.lib.hp_comm_info(r.agent._native_comm, _C0.byref(rk), _C0.byref(wd))
+            devices["rccl_communicator_ranks"] = wd.value
     prof = None
     if rank == 0 and world == 1 and not a.no_profile:   # N=1 only: the eager profile pass would issue collectives alone
         prof = profile_kernels(r)
@@ -488,8 +633,15 @@ def main():
     mode = _C.c_int32()
     r.agent.lib.hp_agent_cycle_mode(r.agent.h, _C.byref(mode))
     cycle_mode = {0: "none", 1: "hipGraph", 2: "eager launches"}.get(mode.value, str(mode.value))
+    alternatives = None
+    ran = exchange_name(r.agent) if (world > 1 or force_dp) else None
     if world > 1 or force_dp:
         r.agent.close_comm()
+    if world > 1 and os.environ.get("RLARM_BENCH_ALTERNATIVES", "1") != "0":
+        try:
+            alternatives = time_exchange_alternatives(a, rank, world, shared, ran)
+        except Exception as e:      # noqa: BLE001 -- the headline line must survive anything that happens in the extra passes
+            alternatives = [{"error": f"alternatives pass aborted: {e}"}]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -518,6 +670,7 @@ def main():
         "cycle_boundaries_in_timed_region": boundaries,
         **({"cycle_inclusive_estimate": cycle_inclusive} if cycle_inclusive else {}),
         **({"host_feeder": feeder_stats} if feeder_stats else {}),
+        **({"exchange_alternatives": alternatives} if alternatives is not None else {}),
         "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
                                f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
                                "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
@@ -533,7 +686,8 @@ def main():
                                           2: "two-phase (reduce-scatter + all-gather over peer memory)"}.get(peer_phases),
                    "cycle_mode": cycle_mode,
                    "peer_gate_kernels": bool(r.agent.comm.shared_device) if dp_peer else None,
-                   "replicas_bit_identical": replicas_identical,
+                   "replicas_bit_identical": replicas_same,
+                   "devices": devices,
                    "devices_shared_by_ranks": bool(shared) if world > 1 else None,
                    "engine": r.agent.engine(),
                    "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
@@ -567,7 +721,8 @@ def main():
         # inside this run: it is read from the newest committed counter summary of this shape, which records a fingerprint of
         # the kernel sources it was taken on -- when the sources have changed since, the figure is reported as stale
         pmc, pmc_file, pmc_sha = {}, None, None
-        for cand in (f"r04_pmc_traffic_b{a.batch}.json", f"r03_pmc_traffic_b{a.batch}.json", f"r02_pmc_traffic_b{a.batch}.json"):
+        for cand in (f"r05_pmc_traffic_b{a.batch}.json", f"r04_pmc_traffic_b{a.batch}.json", f"r03_pmc_traffic_b{a.batch}.json",
+                     f"r02_pmc_traffic_b{a.batch}.json"):
             path = os.path.join(REPO, "profiles", cand)
             if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
                 with open(path) as fh:
@@ -583,13 +738,15 @@ def main():
             sha_now = None
         traffic_stale = (pmc_sha is None or sha_now is None or pmc_sha != sha_now) if pmc_file else None
         # committed rocprofv3 summary of this same configuration (tools/gpu_round3.sh): cross-check for the live numbers
-        prof_file = os.path.join(REPO, "profiles", f"r04_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
-        for older in ("r03", "r02"):
+        prof_file = os.path.join(REPO, "profiles", f"r05_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
+        for older in ("r04", "r03", "r02"):
             if not os.path.exists(prof_file):
                 prof_file = os.path.join(REPO, "profiles", f"{older}_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
-        prof_avg = {}
+        prof_avg, prof_sha = {}, None
         if os.path.exists(prof_file):
             for line in open(prof_file):
+                if line.startswith("# csrc_sha16"):      # tools/trace_summary.py: fingerprint of the kernel sources it was taken on
+                    prof_sha = line.split()[2]
                 parts = line.split()
                 if len(parts) >= 6 and parts[0][0] != "#" and parts[-1].endswith("%"):
                     try:
@@ -613,7 +770,8 @@ def main():
                       or prof_avg.get("k_gemm_lds_adam") or prof_avg.get("k_gemm_lds_adam_u", 0.0))   # _u: scalar wave index (batch 257..640)
             used = max(live, rp)
             tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
-            per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "live_event_pair_minus_empty_us": round(live, 3),
+            per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "duration_source": "live" if live >= rp else "committed",
+                         "live_event_pair_minus_empty_us": round(live, 3),
                          "rocprofv3_avg_us_committed": round(rp, 3) if rp else None,
                          "graph_replay_warm_us": round(us.value, 3) if us.value == us.value else None, "flop_per_launch": 2.0 * macs * a.batch,
                          "achieved_tflops": round(tf, 3), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5),
@@ -632,6 +790,13 @@ def main():
                             f"(csrc fingerprint then {pmc_sha}, now {sha_now})",
             "flop_per_launch": per[dom]["flop_per_launch"],
             "avg_launch_us": per[dom]["avg_launch_us"],
+            # which of the two durations decided `frac` in THIS run, and whether the committed file still describes these kernels
+            # (same fingerprint of the kernel sources as the PMC file's; a file without one reads as stale)
+            "duration_source": per[dom]["duration_source"],
+            "duration_stale": (prof_sha is None or sha_now is None or prof_sha != sha_now) if os.path.exists(prof_file) else None,
+            "duration_note": f"committed summary: profiles/{os.path.basename(prof_file)} (csrc fingerprint then {prof_sha}, now {sha_now}); "
+                             "with duration_source == 'committed' and duration_stale the fraction rests on an outdated file -- the live "
+                             "figure beside it is this run's",
             "duration_method": "avg_launch_us = the LARGER of (a) live_event_pair_minus_empty_us: one HIP event pair around each "
                                "eager launch of the training loop on the launch stream, minus event_pair_empty_us (what a pair with "
                                "nothing in between reads), and (b) rocprofv3_avg_us_committed: the kernel's average in the "
@@ -668,6 +833,33 @@ def main():
             "index_draw_kernel_us": round(dus.value, 3),
             "note": "256 random 0.5 KB rows of a 150 MB buffer per launch: two dependent memory latencies, nowhere near a "
                     "bandwidth bound; averages over 200 back-to-back launches between one HIP event pair"}
+        # ... and the device-output fused sampler (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32
+        # x, x', a, r in device memory), SURVEY 8d's 528 B / transition kernel.  This build stores float64 rows, so what one launch
+        # actually moves is 67 x 8 B read + a 16 B index record + 65 x 4 B written = 812 B per transition; both figures are given.
+        # At the bench batch the launch is two dependent memory latencies; the large-batch figure shows the kernel against the roof.
+        fd, fg = C.c_double(), C.c_double()
+        fused = {}
+        for nb, reps in ((a.batch, 200), (1 << 18, 20)):
+            _l.check(r.ctx.lib.hp_buffer_sample_dev_us(buf.h, r.rng.h, r.agent.o_norm.h, r.agent.g_norm.h, nb,
+                                                       float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, reps,
+                                                       C.byref(fd), C.byref(fg)))
+            fused[nb] = {"batch": nb, "avg_launch_us": round(fg.value, 3), "index_draw_kernel_us": round(fd.value, 3),
+                         "achieved_GBps_528B": round(528 * nb / (fg.value * 1e-6) / 1e9, 2),
+                         "achieved_GBps_812B_this_build": round(812 * nb / (fg.value * 1e-6) / 1e9, 2),
+                         "transitions_per_s_kernel_only": round(nb / (fg.value * 1e-6), 1)}
+        big = fused[1 << 18]
+        out["roofline_sample_kernel_fused"] = {
+            "bound": "hbm", "kernel": "k_gather_fused (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 device tensors)",
+            "achieved": big["achieved_GBps_528B"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(big["achieved_GBps_528B"] / HBM_PEAK_GBPS, 5),
+            "bytes_per_transition": 528, "bytes_per_transition_this_build": 812,
+            "achieved_this_build_bytes": big["achieved_GBps_812B_this_build"],
+            "frac_this_build_bytes": round(big["achieved_GBps_812B_this_build"] / HBM_PEAK_GBPS, 5),
+            "avg_launch_us": big["avg_launch_us"], "batch": 1 << 18, "traffic": None,
+            "at_bench_batch": fused[a.batch],
+            "note": "achieved = SURVEY 8d's algorithmic 528 B / transition (float32 storage) x 2^18 transitions / the kernel's average "
+                    "launch time; this build keeps float64 rows (bit-identical rewards and inputs), so the bytes it really moves are "
+                    "812 B / transition (the *_this_build figures).  Random 432-byte row pairs out of a 150 MB shard: the shard is "
+                    "Infinity-Cache resident.  At the bench batch one launch is two dependent memory latencies"}
         out["kernel_time_us_per_step_event_bracketed"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)

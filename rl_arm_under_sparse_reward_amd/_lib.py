@@ -179,7 +179,10 @@ _lock = threading.Lock()
 #     point, or `flush_pending()`) before reading such a view;
 #   * an error of a deferred update (an empty buffer: "high <= 0", a dead rank exchange, a hand-off fault) is raised by the call
 #     that triggers the flush, possibly from another thread -- the exception then names the deferred call it belongs to
-#     ("deferred _update_network() x n"); the updates that could not be issued stay pending and are NOT dropped.
+#     ("deferred _update_network() x n").  It is raised ONCE, like the reference's own error at `_update_network()`: the updates
+#     that could not be issued stay owed but parked -- no later library call retries them by itself, every object stays usable --
+#     until the next `_update_network()` call or `agent.retry_pending_updates()` tries them again, or
+#     `agent.discard_pending_updates()` drops them.
 pending_lock = threading.RLock()
 _pending = []            # objects with a `_flush_updates()` method and work outstanding
 _NO_FLUSH = {"hp_last_error", "hp_abi_version"}

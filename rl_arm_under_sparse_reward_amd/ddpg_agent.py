@@ -130,6 +130,7 @@ class ddpg_agent:
         self._norm_stage = None          # staging buffer of _update_normalizer(episode_batch)
         import threading
         self._pending_updates = 0              # argument-less _update_network() calls not issued yet (_lib.py: deferred updates)
+        self._pending_parked = False           # their last flush failed: not retried until the caller asks (see _flush_updates)
         self._defer_updates = os.environ.get("RLARM_DEFER_UPDATES", "1") != "0"
         self._stage_lock = threading.RLock()   # orders "store a wave, then sample ITS staged episodes" across feeder threads
         self.success_rates = []
@@ -254,6 +255,7 @@ class ddpg_agent:
                         f = sys._getframe(1)
                         self._pending_site = f"{f.f_code.co_filename}:{f.f_lineno}"
                     self._pending_updates += 1
+                    self._pending_parked = False            # a new update call is the natural point to try the owed ones again
                     if self._pending_updates >= int(self.args.n_batches):
                         self._flush_updates()
                     else:
@@ -266,9 +268,16 @@ class ddpg_agent:
     def _flush_updates(self):
         """Issue the counted `_update_network()` calls.  In chunks whose lengths are powers of two (at most n_batches): a loop
         that is flushed at irregular points would otherwise ask for a new sequence length -- a freshly captured graph -- every
-        time and thrash the library's 8-entry graph cache.  An error names the deferred call it belongs to, and what could not
-        be issued stays pending (the caller may fix the cause -- e.g. store an episode -- and carry on)."""
+        time and thrash the library's 8-entry graph cache.
+
+        A failing flush raises ONCE, like the reference's `_update_network()` does at the same cause (e.g. `ValueError: high <=
+        0` on an empty buffer, ddpg_agent.py:227): the error names the deferred call it belongs to, what could not be issued
+        stays owed (`pending_updates`) but is PARKED -- no later library call retries it by itself, so every object stays usable
+        and the caller can remove the cause (e.g. store an episode).  The owed updates are tried again by the next
+        `_update_network()` call, by `retry_pending_updates()`, or dropped by `discard_pending_updates()`."""
         with _lib.pending_lock:
+            if self._pending_parked:
+                return
             n, self._pending_updates = self._pending_updates, 0
             _lib.unregister_pending(self)
             cap = max(1, int(self.args.n_batches))
@@ -277,8 +286,8 @@ class ddpg_agent:
                 try:
                     self._issue_updates(chunk)
                 except Exception as e:
-                    self._pending_updates += n                 # nothing of this chunk was enqueued: still owed
-                    _lib.register_pending(self)
+                    self._pending_updates += n                 # nothing of this chunk was enqueued: still owed ...
+                    self._pending_parked = True                # ... but not retried behind the caller's back
                     note = (f"deferred _update_network() x {n}, first called at {getattr(self, '_pending_site', '?')} "
                             "(issued by a later library call, _lib.py 'deferred updates')")
                     if hasattr(e, "add_note"):
@@ -286,6 +295,25 @@ class ddpg_agent:
                         raise
                     raise type(e)(f"{e} [{note}]") from e
                 n -= chunk
+
+    @property
+    def pending_updates(self):
+        """Argument-less `_update_network()` calls counted but not issued yet (parked ones included)."""
+        return self._pending_updates
+
+    def retry_pending_updates(self):
+        """Issue the owed updates now (after a failed flush parked them and its cause has been removed).  Raises like the
+        flush did if they fail again."""
+        with _lib.pending_lock:
+            self._pending_parked = False
+            self._flush_updates()
+
+    def discard_pending_updates(self):
+        """Give up on the owed updates (what a caller that catches the reference's error and moves on does); returns how many."""
+        with _lib.pending_lock:
+            n, self._pending_updates, self._pending_parked = self._pending_updates, 0, False
+            _lib.unregister_pending(self)
+            return n
 
     def _issue_updates(self, n_updates):
         fp, sq = float(self.her_module.future_p), float(self.her_module.sq_threshold)

@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*flags, timeout=600, **extra_env):
-    env = dict(os.environ, **extra_env)
+    env = dict(os.environ, **{"RLARM_BENCH_ALTERNATIVES": "0", **extra_env})   # the extra passes have a test of their own
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], cwd=REPO, env=env, capture_output=True,
@@ -55,7 +55,14 @@ def test_driver_invocation_prints_the_contract_line():
     assert 0.0 < r["whole_update_frac"] < r["frac"] * 1.5
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "transitions/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert d["cycle_boundaries_in_timed_region"]["polyak"] == 0       # 20 steps never reach a cycle boundary: said so
+    # round 5: the 20 timed steps are the LAST 20 updates of a cycle -- its soft target update is inside the region, and the line
+    # says which of its two durations decided the roofline fraction
+    assert d["cycle_boundaries_in_timed_region"]["polyak"] == 1 and "placement" in d["cycle_boundaries_in_timed_region"]
+    assert r["duration_source"] in ("live", "committed") and r["duration_stale"] in (True, False)
+    assert c["config1"]["cores"] == 1 and c["config1"]["value"] > 0 and "100-episode" in c["config1"]["sample"]
+    f = d["roofline_sample_kernel_fused"]
+    assert f["bound"] == "hbm" and f["bytes_per_transition"] == 528 and 0.0 < f["frac"] < 1.0
+    assert f["achieved"] == pytest.approx(528 * f["batch"] / (f["avg_launch_us"] * 1e-6) / 1e9, rel=1e-3)
 
 
 @pytest.mark.parametrize("batch", [256, 3072])     # 3072: the 32-row engine + split weight-gradient tiles under the exchange
@@ -127,3 +134,35 @@ def test_multi_rank_launch_survives_a_failing_exchange_on_one_rank():
     instead of leaving the scaling run without a line."""
     d = _run("--gpus", "2", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", RLARM_BENCH_FAIL_FIRST="1")
     assert d["n_gpus"] == 2 and d["config"]["exchange"] in ("rccl", "torch.distributed")
+
+
+def test_eight_rank_rehearsal_times_the_exchange_alternatives():
+    """there may be exactly one multi-GPU run, so after the timed region of the transport that won, the same
+    process group times a short pass on every OTHER exchange (RCCL in the cycle graph, the peer exchange's other forms,
+    torch.distributed) and records us/update + replica identity for each; the per-rank PCI bus ids and the rank counts say
+    whether it was N ranks on N devices.  Rehearsed with eight ranks on the one device: RCCL cannot run there (it refuses two
+    ranks per device; the record must say what the pass ran as), every peer form and the torch fallback must."""
+    d = _run("--gpus", "8", "--episodes", "64", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", timeout=1500,
+             RLARM_BENCH_ALTERNATIVES="1")
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["replicas_bit_identical"] is True
+    dev = c["devices"]
+    assert len(dev["pci_bus_ids_by_rank"]) == 8 and dev["distinct_devices"] == 1 and dev["process_group_ranks"] == 8
+    alts = d["exchange_alternatives"]
+    assert len(alts) == 5 and all("exchange" in x for x in alts)
+    done = [x for x in alts if "us_per_update" in x]
+    assert len(done) >= 4, alts                                   # the peer forms + torch (+ whatever the rccl pass fell back to)
+    for x in done:
+        assert x["replicas_bit_identical"] is True and 10 < x["us_per_update"] < 1e5 and x["ran_as"]
+    forms = {x["ran_as"].split(",")[0] + (x["ran_as"].split("phases")[1][:2] if "phases" in x["ran_as"] else "") for x in done}
+    assert {"peer-memory 1", "peer-memory 2", "torch.distributed"} <= forms, forms
+
+
+def test_alternatives_pass_survives_a_failing_transport():
+    """... and a transport that fails in the extra passes costs its own entry, not the line."""
+    d = _run("--gpus", "2", "--episodes", "64", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", timeout=900,
+             RLARM_BENCH_ALTERNATIVES="1", RLARM_BENCH_FAIL_ALT="peer memory, two-phase", RLARM_PEER_TIMEOUT_S="3")
+    alts = d["exchange_alternatives"]
+    bad = [x for x in alts if x["exchange"].startswith("peer memory, two-phase")]
+    assert len(bad) == 1 and "error" in bad[0] and "injected" in bad[0]["error"]
+    assert sum("us_per_update" in x for x in alts) >= 3

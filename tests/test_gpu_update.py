@@ -760,9 +760,11 @@ def test_deferred_updates_and_a_held_device_view():
 
 
 def test_a_failing_deferred_update_names_itself_and_stays_owed():
-    """the reference raises `ValueError: high <= 0` from `_update_network()` itself when the buffer is empty; deferred,
-    the error surfaces at the NEXT library call -- it must say which call it belongs to, and the updates that could not be issued
-    stay pending (they are issued once the cause is gone), as do other objects' pending updates behind it."""
+    """the reference raises `ValueError: high <= 0` from `_update_network()` itself when the buffer is empty and
+    stays usable.  Deferred, the error surfaces at the NEXT library call -- ONCE: it says which call it belongs to, the updates
+    that could not be issued stay owed but parked (no later call retries them behind the caller's back, so `store_episode` goes
+    through), other objects' pending updates behind it are not lost, and once the cause is gone the owed updates are issued by
+    the next `_update_network()` / `retry_pending_updates()` -- or dropped by `discard_pending_updates()`."""
     torch.manual_seed(0)
     agent, rng = make_agent(batch=64, n_eps=8, seed=3, n_batches=8)
     other, _ = make_agent(batch=64, n_eps=8, seed=4, n_batches=8)
@@ -770,13 +772,28 @@ def test_a_failing_deferred_update_names_itself_and_stays_owed():
     agent._update_network()                              # empty buffer: the reference would raise here
     agent._update_network()
     other._update_network()
-    assert agent._pending_updates == 2 and other._pending_updates == 1
+    assert agent.pending_updates == 2 and other.pending_updates == 1
     with pytest.raises(ValueError, match=r"high <= 0.*deferred _update_network\(\) x 2, first called at .*test_gpu_update\.py:\d+"):
         agent.o_norm.mean                                # an unrelated library call triggers the flush
-    assert agent._pending_updates == 2                   # still owed, not dropped
-    assert other._pending_updates in (0, 1)              # issued, or still registered -- never lost
-    agent._pending_updates = 0                           # give up on them explicitly (what a caller that catches the error may do)
-    _lib.unregister_pending(agent)
-    _lib.flush_pending()
-    assert other._pending_updates == 0
-    assert other.last_losses(1).shape == (1, 2)
+    assert agent.pending_updates == 2                    # still owed, not dropped
+    assert other.pending_updates in (0, 1)               # issued, or still registered -- never lost
+    assert agent.o_norm.mean.shape == (27,)              # raised once: the library is usable again, nothing retried behind our back
+    assert other.pending_updates == 0 and other.last_losses(1).shape == (1, 2)
+    assert agent.pending_updates == 2
+    with pytest.raises(ValueError, match="high <= 0"):   # an explicit retry with the cause still there fails the same way ...
+        agent.retry_pending_updates()
+    assert agent.pending_updates == 2
+    agent.buffer.store_episode(make_episodes(4, seed=10, mode="walk"))     # ... the docstring's recovery: remove the cause ...
+    agent._update_network()                              # ... and the next update call takes the owed ones along
+    assert agent.pending_updates == 3
+    losses = agent.last_losses(3)                        # (a library call: flushes)
+    assert agent.pending_updates == 0 and np.isfinite(losses).all()
+    # and the other way out: drop them
+    empty, _ = make_agent(batch=64, n_eps=8, seed=5, n_batches=8)
+    empty._update_network()
+    with pytest.raises(ValueError, match="high <= 0"):
+        empty.o_norm.mean
+    assert empty.discard_pending_updates() == 1 and empty.pending_updates == 0
+    empty.buffer.store_episode(make_episodes(2, seed=11, mode="walk"))
+    empty._update_network(2)
+    assert np.isfinite(empty.last_losses(2)).all()

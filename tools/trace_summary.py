@@ -14,6 +14,13 @@ tot = sum(r[5] for r in rows)
 cmd = sys.argv[2] if len(sys.argv) > 2 else "python bench.py --steps 2000 --warmup 400 --no-cpu-baseline --no-profile"
 print(f"# rocprofv3 --kernel-trace --stats -d <dir> -o trace -- {cmd}   (kernel durations from trace_results.db, "
       "tools/trace_summary.py)")
+try:   # fingerprint of the kernel sources this trace was taken on (bench.py: roofline.duration_stale)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pmc_summary import csrc_sha16
+    print("# csrc_sha16", csrc_sha16())
+except Exception:   # noqa: BLE001
+    pass
 print(f"{'kernel':44s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'share':>6s}")
 for r in rows:
     nm = r[0] if "[prologue" not in r[0] else r[0].split("(")[0] + "[prologue]"
