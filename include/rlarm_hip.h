@@ -371,8 +371,8 @@ int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *
  * the chain launch) + the actor's weight-gradient launch; 2 the split launch holds the actor's tiles too (one launch per update). */
 int hp_agent_update_form(hp_agent *ag, int32_t n_updates, int32_t *form);
 /* Sticky health word of the learner, free for the host (pinned memory, no synchronisation): 0 = healthy.  Bit 0: a bounded
- * in-launch hand-off gave up (bits 4-7: which -- 1 critic chains -> weight-gradient tiles, 2 actor chains -> critic optimizer
- * step, 3 cycle-opening launch); the launches since skipped work, every later hp_agent_train_cycle* /
+ * in-launch hand-off gave up; one bit per source beside it (several may be set): bit 4 critic chains -> weight-gradient tiles,
+ * bit 5 actor chains -> critic optimizer step, bit 6 cycle-opening launch; the launches since skipped work, every later hp_agent_train_cycle* /
  * hp_agent_sample_and_update / hp_agent_get_losses fails with HP_ERR_STATE, the agent must be recreated. */
 int hp_agent_status(hp_agent *ag, uint32_t *fault);
 int hp_agent_profile(hp_agent *ag, int32_t enable);

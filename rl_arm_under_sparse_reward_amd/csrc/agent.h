@@ -104,10 +104,12 @@ __device__ __forceinline__ void adam_prepare(AgentDevState *st, const AdamCfg c)
 #define SPLIT_FAULT (2 * SPLIT_SET_WORDS)
 #define SPLIT_SYNC_WORDS (SPLIT_FAULT + 4)
 
-// sticky fault word of in-launch hand-offs: bit 0 = a poll gave up, bits 4-7 = which (1 critic chains published, 2 actor
-// chains past the critic, 3 cycle-opening launch), mirrored into pinned host memory so that the next host call fails loudly
+// sticky fault word of in-launch hand-offs: bit 0 = a poll gave up, and ONE BIT PER SOURCE above it (the words of several
+// give-ups are OR-ed together, so the sources must not share bits): bit 4 = source 1, critic chains -> weight-gradient tiles;
+// bit 5 = source 2, actor chains -> critic optimizer step; bit 6 = source 3, cycle-opening launch.  Mirrored into pinned host
+// memory so that the next host call fails loudly.
 __device__ __forceinline__ void handoff_fault(unsigned *fault, unsigned *fault_host, unsigned which) {
-    const unsigned word = 1u | (which << 4);
+    const unsigned word = 1u | (1u << (3u + which));   // which in 1..3
     __hip_atomic_fetch_or(fault, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fault_host) __hip_atomic_fetch_or(fault_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -15,10 +15,9 @@ static void drop_graph(hp_agent *a);
 int agent_check_fault(const hp_agent *a, const char *who) {
     const unsigned w = a->fault_host ? *(volatile const unsigned *)a->fault_host : 0u;
     if (w == 0u) return HP_OK;
-    const unsigned which = (w >> 4) & 15u;
     hp_set_error("%s: an in-launch hand-off gave up earlier (%s%s%s; word 0x%x): the launches since skipped work and the "
-                 "learner's state is not valid -- recreate the agent", who, (which & 1u) ? "critic chains -> weight-gradient tiles " : "",
-                 (which & 2u) ? "actor chains -> critic optimizer step " : "", which == 3u ? "/ cycle-opening launch" : "", w);
+                 "learner's state is not valid -- recreate the agent", who, (w & 0x10u) ? "critic chains -> weight-gradient tiles; " : "",
+                 (w & 0x20u) ? "actor chains -> critic optimizer step; " : "", (w & 0x40u) ? "cycle-opening launch; " : "", w);
     return HP_ERR_STATE;
 }
 
