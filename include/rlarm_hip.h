@@ -335,7 +335,7 @@ int hp_peer_status(hp_peer *peer, uint32_t *error);
  * of its own in front of the kernel that consumes the peers' data, instead of inside that kernel's hundreds of workgroups.
  * Needed when ranks share one physical device (rehearsals of an N-GPU job on one GPU): there a rank's progress depends on
  * its kernels being co-resident with the other ranks' WAITING kernels, and workgroups spinning by the hundred can starve
- * them of registers / LDS.  Costs one kernel boundary per wait; default off (RLARM_PEER_GATE=0|1 overrides). */
+ * them of registers / LDS.  Costs one kernel boundary per wait; default off. */
 int hp_peer_set_gate(hp_peer *peer, int32_t on);
 /* 1: one-shot exchange (every rank reads every peer's whole gradient vector), 2: reduce-scatter + all-gather over the same
  * peer memory (default from 4 ranks; RLARM_PEER_PHASES=1|2).  Both sum in rank order: bit-identical results. */

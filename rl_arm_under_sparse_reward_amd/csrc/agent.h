@@ -177,15 +177,13 @@ struct hp_agent {
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
     // A/B switches, read once in hp_agent_create: RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD, RLARM_FB_PREFETCH (-1 = by size,
     // 0 = off, 1 = on)
-    bool gemm_xcd = true;
-    int fb_xcd = -1, fb_prefetch = -1;
     // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
     bool dw64 = false;                   // RLARM_DW64: default from batch 1536
-    int dw_S = 3;                        // RLARM_DW_SPLIT
+    int dw_S = 3;                        // (RLARM_DW64=s<n>)
     DevBuf dw_part, dw_ticket;           // partial tiles / arrival counters
     bool keep_grads_dbg = false;   // RLARM_KEEP_GRADS=1 (parity tests): the peer optimizer kernels also write the summed gradients out
     bool upd_graph_ok = true;   // hp_agent_sample_and_update replays cached graphs (RLARM_UPDATE_GRAPH=0: eager launches, for A/B)
-    bool gather_ahead = true;   // merged kernel: gather update u+1's inputs during update u (RLARM_AHEAD=0: off, for A/B)
+    bool gather_ahead = true;   // merged kernel: spare workgroups gather update u+1's inputs during update u (while CUs are free)
     DevBuf plan, norm_plan;
     int plan_batches = 0;
     DevBuf fwd_ws;          // actor_forward scratch
@@ -200,9 +198,6 @@ struct hp_agent {
     int snap_cur = -1, snap_pending = -1;
     // index plans of later updates drawn on a second stream, concurrently with the chain kernel, when the launch has no
     // spare CU for a ride-along plan workgroup (enqueue_updates)
-    hipStream_t plan_stream = nullptr;
-    hipEvent_t plan_fork = nullptr, plan_join = nullptr;
-    int plan_side = -1;                  // RLARM_PLAN_SIDE: -1 by occupancy, 0 never, 1 always
     hipStream_t act_stream = nullptr;
     hipEvent_t act_done = nullptr;
     bool act_recorded = false;
@@ -229,8 +224,6 @@ struct hp_agent {
     // cycle graph cache
     hipGraphExec_t graph = nullptr;
     unsigned *open_sync = nullptr;       // k_cycle_open's flags (cycle_open.hip)
-    int adam_wt = -1;                    // RLARM_ADAM_WT=0|1 overrides write-through optimizer stores (default: up to 768 batch rows)
-    int gl_uni = -1;                     // RLARM_GEMM_UNI=0|1 overrides the choice by reduction length (gemm_lds.h)
     int loss_wg = 1;                     // the loss log is written by a workgroup of its own behind the weight-gradient tiles (gemm_lds.h gemm_loss_wg)
     int dw_ksplit = 0;                   // reduction slices of the narrow weight-gradient problems (RLARM_DW_KSPLIT; 0/1: none)
     float *gl_part = nullptr;            // their partial tiles and arrival counters (gemm_lds.h)
@@ -238,8 +231,7 @@ struct hp_agent {
     // split launch (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
     // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
-    int split_mode = -1, split_place = 2;
-    int split_one = -1;                  // RLARM_SPLIT_ONE=1: the actor's tiles inside the split launch too (ONE launch per update): built, parity-green, 45.7 vs 39.2 us -- opt-in
+    int split_mode = -1;                 // RLARM_SPLIT=0|1: never / also for short sequences (default: from SPLIT_MIN_UPDATES updates)
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
     unsigned *fault_host_dev = nullptr;

@@ -53,6 +53,14 @@ struct CycleOpts {
     std::function<int()> between;    // what follows the draws and precedes the first update
     bool polyak_folded = false;
 };
+// Does a sequence of n_updates sampled updates on this agent take the split form (slab8_split.h)?  ONE predicate for the
+// launch logic (enqueue_updates) and for what hp_agent_update_form reports.
+static bool update_takes_split_form(const hp_agent *a, int n_updates) {
+    const bool full = a->slab8 && chain_wgs(a) + 1 + S8_AHEAD_WGS > a->ctx->cu_count;   // no CU left for the chain kernel's spare workgroups
+    return a->slab8 && a->gather_ahead && !full && split_fits(a) &&
+           (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
+}
+
 static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq,
                            int n_updates, bool with_adam, CycleOpts *cyc = nullptr) {
     // slab engine: only the first minibatch's indices are drawn up front; update u draws the plan of update u+1 in
@@ -64,25 +72,19 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     const int chains = chain_wgs(a);
     // ... and when the launch is full (no CU for spare workgroups) both jobs move out of the chain kernel
     const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
-    // slab8 engine, full launch: both jobs ride in the weight-gradient launch (k_gemm_lds_adam_ride); RLARM_PLAN_SIDE=2
-    // keeps the second-stream variant for A/B (its cross-queue graph edges cost ~4 us each: 65.5 vs 71.4 us at batch 1024)
+    // slab8 engine, full launch: both jobs ride in the weight-gradient launch (k_gemm_lds_adam_ride).  (A second stream beside
+    // the chain kernel was the alternative until round 4: its cross-queue graph edges cost ~4 us each, 65.5 vs 71.4 us at batch
+    // 1024, and at batch 4096 k_draw_plan took 83 us instead of 3.4 next to the chain kernel; removed in round 5.)
     // slab32 engine: its chain kernel never gathers and its launches fill the CUs from batch 4096, so both jobs ride in the
-    // weight-gradient launch by default (measured at batch 4096: beside the chain kernel on a second stream k_draw_plan
-    // took 83 us instead of 3.4 and the chain kernel 97 us); RLARM_PLAN_SIDE=2 keeps the second stream, 0 runs the gather in
-    // front of every launch.  Profiling brackets every launch with events on the main stream: serial as well.
-    const bool s32_ride = ride && a->slab32 && !a->prof && a->plan_side != 0 && a->plan_side != 2;
-    const bool s32_side = ride && a->slab32 && !a->prof && a->plan_side == 2;
-    const bool s32_serial = a->slab32 && !s32_side && !s32_ride;
-    const bool want_offload = s32_ride || (ride && a->slab8 && a->plan_side != 0 && (a->plan_side >= 1 || full) &&
-                                           (getenv("RLARM_AHEAD") ? a->gather_ahead : true));
-    const bool side_gather = (want_offload && a->slab8 && a->plan_side == 2 && !a->prof) || s32_side;
-    const bool dw_ride = want_offload && !side_gather;
-    const bool ahead = ride && ((a->slab8 && (a->gather_ahead || side_gather || dw_ride)) || s32_side || s32_ride);
+    // weight-gradient launch as well.  Profiling brackets every launch with events: the gather then runs in front of every launch.
+    const bool s32_ride = ride && a->slab32 && !a->prof;
+    const bool s32_serial = a->slab32 && !s32_ride;
+    const bool dw_ride = s32_ride || (ride && a->slab8 && full);
+    const bool ahead = ride && ((a->slab8 && (a->gather_ahead || dw_ride)) || s32_ride);
     const int lead = ahead ? 2 : 1;
     // split form (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the chain
     // launch.  Needs the chain kernel's own look-ahead (plans two updates ahead, gather workgroups) and the fused optimizer.
-    const bool split = ride && ahead && !dw_ride && !side_gather && a->slab8 && a->gather_ahead && split_fits(a) &&
-                       (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
+    const bool split = ride && ahead && !dw_ride && update_takes_split_form(a, n_updates);
     {
         ProfScope ps(a, PROF_PLAN);
         const int first = ride ? (n_updates < lead ? n_updates : lead) : n_updates;
@@ -97,27 +99,11 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     if (cyc && cyc->between) HP_TRY(cyc->between());
     const bool fold = cyc && with_adam && polyak_foldable(a);
     if (cyc) cyc->polyak_folded = fold;
-    // Where the plan of update u + lead is drawn: by a spare workgroup of update u's own launch while that launch leaves
-    // a CU free -- or, when the chains occupy every CU (batch 1024: 256 chain workgroups; the 16-row engine beyond), by
-    // k_draw_plan on a second stream next to the chain kernel.  A workgroup appended to a full launch only starts when
-    // the first chain ends and then runs its sequential MT19937 draw alone: measured 51.5 vs 37.8 us for k_fb_slab8 at
-    // batch 1024 and 96 vs 51 us for k_bwd_slab at batch 4096 (profiles/r02_large_batch_traces.txt).
-    const int spare_cus = a->ctx->cu_count - (a->slab8 ? chains + (ahead && !side_gather ? S8_AHEAD_WGS : 0)
-                                                       : 2 * (a->Mp / S32_ROWS));
-    const bool side = side_gather || (ride && !dw_ride && !a->prof && (a->plan_side >= 0 ? a->plan_side >= 1 : spare_cus < 1));
-    if (side && !a->plan_stream) {
-        HP_CHECK_HIP(hipStreamCreateWithFlags(&a->plan_stream, hipStreamNonBlocking));
-        HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_fork, hipEventDisableTiming));
-        HP_CHECK_HIP(hipEventCreateWithFlags(&a->plan_join, hipEventDisableTiming));
-    }
-    bool join_pending = false;
     // split form: Q' of the FIRST update's minibatch comes from a prologue launch of target chains (every later one from the
     // launch before).  Round 4 also built the alternative -- the first update's critic chains run k_fb_slab8's whole critic side
     // and hand off to the tiles at their end, no prologue: 37.90 vs 37.92 us/update over cycles, 40.97 vs 41.14 in the driver's
     // 20-step form, and an intermittent optimizer mismatch in the teacher-forced test that the prologue form never showed;
     // removed.
-    if (split && a->split_one == 1)   // (opt-in one-launch form: no tile launch behind it that clears the counters)
-        HP_CHECK_HIP(hipMemsetAsync(a->k1_sync, 0, 2 * SPLIT_SET_WORDS * sizeof(unsigned), a->ctx->stream));
     if (split) {
         GatherCtx g0{b, on, gn, a->plan.as<PlanRec>(), sq};
         HP_TRY(enqueue_split_prologue(a, &g0));
@@ -127,31 +113,10 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         gc.split = split;
         gc.qset = u & 1;
         gc.t_plan = (split && u + 1 < n_updates) ? a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B : nullptr;
-        hipStream_t ms = a->ctx->stream;
-        if (join_pending) {   // the plan drawn beside the previous update is what this launch gathers from
-            HP_CHECK_HIP(hipStreamWaitEvent(ms, a->plan_join, 0));
-            join_pending = false;
-        }
-        const bool gather_beside = side_gather && u + 1 < n_updates;
-        if (side && (gather_beside || (ride && u + lead < n_updates))) {
-            // fork: ordered behind everything enqueued so far (the previous draws included), concurrent with update u
-            HP_CHECK_HIP(hipEventRecord(a->plan_fork, ms));
-            HP_CHECK_HIP(hipStreamWaitEvent(a->plan_stream, a->plan_fork, 0));
-            if (gather_beside)   // inputs of update u + 1 into the other input set, from the plan an earlier draw finished
-                HP_TRY(enqueue_gather(a, b, on, gn, a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B, sq, (u + 1) & 1,
-                                      a->plan_stream));
-            if (ride && u + lead < n_updates)
-                HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, 1, future_p,
-                                       a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B, a->plan_stream));
-            HP_CHECK_HIP(hipEventRecord(a->plan_join, a->plan_stream));
-            join_pending = true;
-        }
         if (ride && u + lead < n_updates) {
             PlanRec *next = a->plan.as<PlanRec>() + (size_t)(u + lead) * a->B;
-            if (side) {
-                (void)next;
-            } else if (a->slab32 && s32_serial && 2 * (a->Mp / S32_ROWS) >= a->ctx->cu_count) {
-                // serial mode (profiling, RLARM_PLAN_SIDE=0) of a launch that fills the CUs: a spare workgroup would only start
+            if (a->slab32 && s32_serial && 2 * (a->Mp / S32_ROWS) >= a->ctx->cu_count) {
+                // serial mode (profiling) of a launch that fills the CUs: a spare workgroup would only start
                 // when the first chain ends (137 instead of 87 us per launch at batch 4096) -- draw in front of the launch
                 HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, a->B, 1, future_p, next));
             } else {
@@ -165,7 +130,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
         if (ahead) {
             gc.xset = u & 1;
             gc.pregathered = u > 0;
-            if (u + 1 < n_updates && !side_gather) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
+            if (u + 1 < n_updates) gc.ahead_plan = a->plan.as<PlanRec>() + (size_t)(u + 1) * a->B;
         }
         gc.ride_in_dw = dw_ride;
         const bool last_fold = fold && u == n_updates - 1;
@@ -190,7 +155,6 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             if (!fused) HP_TRY(enqueue_adam(a, last_fold));
         }
     }
-    if (join_pending) HP_CHECK_HIP(hipStreamWaitEvent(a->ctx->stream, a->plan_join, 0));
     if (with_adam && a->peer) HP_TRY(peer_enqueue_seq_end(a->peer, n_updates));
     return HP_OK;
 }
@@ -337,28 +301,20 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         }
         const char *fa = getenv("RLARM_FUSE_ADAM");
         a->fuse_adam_ok = !(fa && fa[0] == '0');
-        a->gemm_xcd = tri("RLARM_GEMM_XCD") != 0;
-        a->fb_xcd = tri("RLARM_FB_XCD");
-        a->fb_prefetch = tri("RLARM_FB_PREFETCH");
         a->upd_graph_ok = tri("RLARM_UPDATE_GRAPH") != 0;
         a->keep_grads_dbg = tri("RLARM_KEEP_GRADS") == 1;
         a->cycle_open = tri("RLARM_CYCLE_OPEN") != 0;
         a->split_mode = tri("RLARM_SPLIT");
-        a->split_one = tri("RLARM_SPLIT_ONE");
-        if (const char *sp = getenv("RLARM_SPLIT_PLACE")) a->split_place = atoi(sp);
-        a->gl_uni = tri("RLARM_GEMM_UNI");
-        a->adam_wt = tri("RLARM_ADAM_WT");
-        if (const char *ps = getenv("RLARM_PLAN_SIDE")) a->plan_side = atoi(ps);   // -1 auto, 0 off, 1 on, 2 on via a second stream
         // weight gradients: 64 x 64 tiles with split batch rows (dw64.h) where the 32 x 32 tiles are L2-bound
         // (us/update, 32 x 32 tiles vs dw64: 56.6 / 58.9 at batch 1024, 85.8 / 85.1 at 1536, 93.9 / 92.2 at 2048, 146 / 128 at 4096)
+        // RLARM_DW64 = 0 | 1 | s<n>: never / always (3 slices of the batch rows per tile) / always with n slices (1..16)
         a->dw64 = a->slab && (tri("RLARM_DW64") >= 0 ? tri("RLARM_DW64") == 1 : a->Mp >= 1536);
-        if (const char *ds = getenv("RLARM_DW_SPLIT")) a->dw_S = atoi(ds) > 0 && atoi(ds) <= 16 ? atoi(ds) : a->dw_S;
-        const char *ah = getenv("RLARM_AHEAD");
-        a->gather_ahead = !(ah && ah[0] == '0');
-        // ... and the spare workgroups of the gather-ahead only pay while they find free CUs next to the chains: at batch
-        // 1024 (256 chains) they ran after them, 87.6 vs 76.1 us/update
-        const int chains = chain_wgs(a);
-        if (!ah && chains + 1 + S8_AHEAD_WGS > cus) a->gather_ahead = false;
+        if (const char *ds = getenv("RLARM_DW64"))
+            if (ds[0] == 's' && atoi(ds + 1) > 0 && atoi(ds + 1) <= 16) a->dw_S = atoi(ds + 1);
+        // the chain kernel's spare workgroups (index plan two updates ahead, gather of the next minibatch) only pay while they find
+        // free CUs next to the chains: at batch 1024 (256 chains) they ran after them, 87.6 vs 76.1 us/update -- both jobs then
+        // ride in the weight-gradient launch (agent.hip: enqueue_updates)
+        a->gather_ahead = chain_wgs(a) + 1 + S8_AHEAD_WGS <= cus;
     }
     if (st == HP_OK) st = dev_alloc(a, &a->d_state, 1);
     if (st == HP_OK) st = dev_alloc(a, &a->open_sync, 4);
@@ -841,11 +797,7 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 // + the actor's tile launch, 2 = split launch holding the actor's tiles as well (one launch per update)
 int hp_agent_update_form(hp_agent *a, int32_t n_updates, int32_t *form) {
     HP_REQUIRE(a && form, HP_ERR_INVALID, "hp_agent_update_form: null argument");
-    const int chains = chain_wgs(a);
-    const bool full = a->slab8 && chains + 1 + S8_AHEAD_WGS > a->ctx->cu_count;
-    const bool split = a->slab8 && a->gather_ahead && !full && a->plan_side <= 0 && split_fits(a) &&
-                       (a->split_mode >= 0 ? a->split_mode == 1 : n_updates >= SPLIT_MIN_UPDATES);
-    *form = split ? (a->split_one == 1 ? 2 : 1) : 0;
+    *form = update_takes_split_form(a, n_updates) ? 1 : 0;
     return HP_OK;
 }
 
@@ -885,12 +837,6 @@ void hp_agent_destroy(hp_agent *a) {
     drop_graph(a);
     (void)hipStreamSynchronize(a->ctx->stream);
     for (void *p : a->owned) (void)hipFree(p);
-    if (a->plan_stream) {
-        (void)hipStreamSynchronize(a->plan_stream);
-        (void)hipEventDestroy(a->plan_fork);
-        (void)hipEventDestroy(a->plan_join);
-        (void)hipStreamDestroy(a->plan_stream);
-    }
     if (a->act_stream) {
         (void)hipStreamSynchronize(a->act_stream);
         for (auto &ps : a->snap) {

@@ -411,8 +411,8 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
     if (ks > 1) L.split_last(ks);
     L.g.part = a->gl_part;
     L.g.ticket = a->gl_ticket;
-    L.g.uni = a->gl_uni >= 0 ? a->gl_uni : (Mp > 256 && Mp <= 640 ? 1 : 0);   // gemm_lds.h, note at `wave`
-    if (a->gemm_xcd) L.place_on_xcds();
+    L.g.uni = (Mp > 256 && Mp <= 640) ? 1 : 0;   // gemm_lds.h, note at `wave`
+    L.place_on_xcds();
     return L;
 }
 
@@ -460,12 +460,11 @@ bool split_fits(const hp_agent *a) {
 }
 
 // Who runs where.  Workgroup b of the launch lands on XCD b % 8, and within an XCD in index order: chains first, then the spare
-// workgroups, the weight-gradient tiles last (they wait for chains).  RLARM_SPLIT_PLACE (us/update at batch 256, same box,
-// alternating runs): 0 = every kind of chain spread evenly over the XCDs (every L2 then streams all six fragment sets): 39.8;
-// 1 = actor-side chains on XCDs 0-3 with the warmers and spare workgroups, target chains on XCDs 4-7, critic chains on both
-// halves: 39.2; 2 (default) = the actor-side chains ALONE on XCDs 0-3 -- the launch's critical path keeps an L2 to itself, 16
-// streams per XCD like in k_fb_slab8 -- and every short chain on XCDs 4-7, whose 32 streams per XCD saturate their L2s
-// (the short chains end 1.5 us later: they have 10 us of slack): 38.3.
+// workgroups, the weight-gradient tiles last (they wait for chains).  The actor-side chains run ALONE on XCDs 0-3 -- the launch's
+// critical path keeps an L2 to itself, 16 streams per XCD like in k_fb_slab8 -- and every short chain on XCDs 4-7, whose 32
+// streams per XCD saturate their L2s (the short chains end 1.5 us later: they have 10 us of slack): 38.3 us/update at batch 256
+// against 39.8 with every kind of chain spread evenly over the XCDs and 39.2 with the critic chains on both halves (round 4,
+// profiles/r04_ab_split_place_b256.txt; those placements are gone).  Shapes whose chains do not divide that way are spread evenly.
 static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains_ac, bool chains_t, int n_plan, int n_ahead,
                                   int n_tiles) {
     const int nslab = a->Mp / a->s8_rows, per_xcd = a->ctx->cu_count / 8;
@@ -474,14 +473,10 @@ static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains
     auto spread = [&](int role, int count, int x0, int nx) {   // evenly over XCDs x0 .. x0 + nx - 1, remainder to the first ones
         for (int i = 0; i < nx; ++i) n[x0 + i][role] += count / nx + (i < count % nx ? 1 : 0);
     };
-    const bool half = (a->split_place == 1 || a->split_place == 2) && nslab % 8 == 0 && chains_ac && 3 * (nslab / 8) + 2 <= per_xcd;
-    if (half && a->split_place == 2 && 2 * (nslab / 4) <= per_xcd) {
-        // place 2: the actor-side chains alone on XCDs 0-3 (as in k_fb_slab8), every short chain on XCDs 4-7
+    const bool half = nslab % 8 == 0 && chains_ac && 3 * (nslab / 8) + 2 <= per_xcd && 2 * (nslab / 4) <= per_xcd;
+    if (half) {   // the actor-side chains alone on XCDs 0-3 (as in k_fb_slab8), every short chain on XCDs 4-7
         spread(SR_A, nslab, 0, 4);
         spread(SR_C, nslab, 4, 4);
-        if (chains_t) spread(SR_T, nslab, 4, 4);
-    } else if (half) {
-        if (chains_ac) { spread(SR_A, nslab, 0, 4); spread(SR_C, nslab, 0, 8); }
         if (chains_t) spread(SR_T, nslab, 4, 4);
     } else {
         if (chains_ac) { spread(SR_A, nslab, 0, 8); spread(SR_C, nslab, 0, 8); }
@@ -489,7 +484,7 @@ static unsigned build_split_roles(const hp_agent *a, FbSplitArgs &Q, bool chains
     }
     for (int i = 0; i < n_plan; ++i) n[i % (half ? 4 : 8)][SR_PLAN] += 1;
     for (int i = 0; i < n_ahead; ++i) n[(n_plan + i) % (half ? 4 : 8)][SR_AHEAD] += 1;
-    int warm = a->fb_prefetch == 0 ? 0 : split_warmers(a);
+    const int warm = split_warmers(a);
     Q.warm_side = 0u;
     for (int x = 0; x < 8; ++x) {
         int used = 0;
@@ -555,10 +550,10 @@ static Launch build_dw_half(const hp_agent *a, bool critic, const float *sX, flo
         add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
         add_dw(L, a->dK1, H, H, sX, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
         // two 256 x 256 problems: four XCDs each (gemm_tile: placed2)
-        if (a->gemm_xcd && L.g.p[0].tiles_n == 8 && L.g.p[0].M == 256 && L.g.p[1].tile0 == 64 && L.g.p[1].tiles_n == 8 && L.g.p[1].M == 256)
+        if (L.g.p[0].tiles_n == 8 && L.g.p[0].M == 256 && L.g.p[1].tile0 == 64 && L.g.p[1].tiles_n == 8 && L.g.p[1].M == 256)
             L.g.xcd = 2;
     }
-    L.g.uni = a->gl_uni >= 0 ? a->gl_uni : (Mp > 256 && Mp <= 640 ? 1 : 0);
+    L.g.uni = (Mp > 256 && Mp <= 640) ? 1 : 0;
     return L;
 }
 
@@ -633,11 +628,8 @@ static void build_fb_args(hp_agent *a, const GatherCtx *gc, FbBuilt &O) {
 }
 
 // bias gradients + their optimizer step in workgroups of their own behind the tiles (gemm_lds.h: gemm_bias_tile; the ring path's
-// summation order only).  RLARM_SEP_BIAS=0: inside the tn == 0 tiles (same bits either way)
-static bool sep_bias_on(const hp_agent *a) {
-    static const bool env = !(getenv("RLARM_SEP_BIAS") && getenv("RLARM_SEP_BIAS")[0] == '0');
-    return env && a->Mp >= GL_RING_MIN_K && !a->dw64;
-}
+// summation order only; inside the tn == 0 tiles otherwise, and in the launches that exchange tile-wise between ranks: same bits)
+static bool sep_bias_on(const hp_agent *a) { return a->Mp >= GL_RING_MIN_K && !a->dw64; }
 
 static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only);
 int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_adam, int only) {
@@ -659,7 +651,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         // chains split across XCD halves: measured (us/update, split vs not) 42.0 vs 43.5 at batch 128, 44.0 vs 45.2 at 256,
         // 46.6 vs 46.6 at 384, 48.0 vs 47.8 at 448, 77.3 vs 74.6 at 1024 -- it pays while the chains leave half of the CUs free
         const int n_chain = chain_wgs(a);
-        P.xcd_split = (nslab % 4 == 0) && (a->fb_xcd >= 0 ? a->fb_xcd == 1 : 4 * nslab <= a->ctx->cu_count);
+        P.xcd_split = (nslab % 4 == 0) && 4 * nslab <= a->ctx->cu_count;
         P.ahead = P.f.gs;
         P.aXT = P.aXA = P.aXP = nullptr;
         if (gc && gc->ahead_plan && !ride_dw) {   // next update's inputs into the other set
@@ -676,7 +668,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         {
             const int fit = a->ctx->cu_count - (n_chain + P.n_plan + P.n_ahead);
             const int want = fit >= 16 ? 16 : (fit >= 8 ? 8 : 0);
-            P.n_pref = a->fb_prefetch >= 0 ? (a->fb_prefetch == 1 ? (want ? want : 8) : 0) : want;
+            P.n_pref = want;
         }
         const unsigned grid = n_chain + P.n_plan + P.n_ahead + P.n_pref;
         if (a->s8_rows == 4)
@@ -794,7 +786,6 @@ static void split_common(hp_agent *a, FbSplitArgs &Q, int set) {
     Q.fault_host = a->fault_host_dev;
     Q.wait_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock: three orders of magnitude beyond a launch
 }
-static bool split_one_launch(const hp_agent *a) { return a->split_one == 1; }
 
 static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only) {
     HP_REQUIRE(only == 0 && fuse_adam && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine / call");
@@ -825,32 +816,17 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     Q.qt_in = gc->qset ? a->QT2 : a->QT;
     Q.qt_out = gc->qset ? a->QT : a->QT2;
     split_common(a, Q, gc->qset);
-    const bool one = split_one_launch(a);
-    // tile problems in the order their operands are published: the critic's W3, W4 (stage 0), W2 (stage 1), W1 (stage 2), then
-    // the actor's (counter 6: every actor-side chain has ended).  Gates of the optimizer steps: W3c after the actor-side chains'
-    // first critic dX layer (counter 4), W4c / W1c after their critic forward (3), W2c after the second dX layer (5); the
-    // actor's parameters are read by the actor-side chains only, which have ended when its tiles start.
+    // tile problems in the order their operands are published: the critic's W3, W4 (stage 0), W2 (stage 1), W1 (stage 2).  Gates
+    // of the optimizer steps: W3c after the actor-side chains' first critic dX layer (counter 4), W4c / W1c after their critic
+    // forward (3), W2c after the second dX layer (5).  The actor's tiles are the launch behind this one (the form that held them
+    // in this launch too, behind an "actor-side chains done" counter, measured 45.7 vs 38.0 us/update in round 4 and is gone).
     Launch L = build_dw_half(a, true, built.sXA, nullptr);
     Q.tile_stage = 0u | (0u << 4) | (1u << 8) | (2u << 12);
-    unsigned gate_sel = 4u | (3u << 4) | (5u << 8) | (3u << 12);
-    Q.loss_prob = -1;
-    if (one) {
-        const Launch La = build_dw_half(a, false, built.sXP, nullptr);
-        for (int i = 0; i < La.g.n; ++i) {
-            GemmProb p = La.g.p[i];
-            p.tile0 += L.tiles;
-            L.g.p[L.g.n + i] = p;
-            Q.tile_stage |= 6u << (4 * (L.g.n + i));
-            gate_sel |= SPLIT_CTR_NONE << (4 * (L.g.n + i));
-        }
-        Q.loss_prob = L.g.n;
-        L.g.n += La.g.n;
-        L.tiles += La.tiles;
-    }
+    const unsigned gate_sel = 4u | (3u << 4) | (5u << 8) | (3u << 12);
     Q.tiles = L.g;
     Q.need_c = (unsigned)nslab;
-    // time-line builds: the last launch with target chains AND a plan workgroup stamps (RLARM_TL_LAST: the last with target chains)
-    Q.tl_mark = (gc->t_plan != nullptr && (P.n_plan > 0 || getenv("RLARM_TL_LAST"))) ? 1 : 0;
+    // time-line builds: the last launch with target chains AND a plan workgroup stamps
+    Q.tl_mark = (gc->t_plan != nullptr && P.n_plan > 0) ? 1 : 0;
     AdamFuse F = adam_fuse(a);
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;
     if (gc->polyak_after) fold_polyak(a, F);
@@ -869,7 +845,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
         launch_split(grid, s, Q);
         HP_CHECK_HIP(hipGetLastError());
     }
-    if (!one) {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
+    {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
         ProfScope ps(a, PROF_DW);
         Launch La = build_dw_half(a, false, built.sXP, nullptr);
         AdamFuse Fa = adam_fuse(a);
@@ -908,7 +884,6 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     split_common(a, Q, 1);        // sync_other = set 0, the first update's
     Q.need_c = 0u;
     Q.reset_sync = 1;
-    Q.loss_prob = -1;
     Q.adam = adam_fuse(a);
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
@@ -930,7 +905,7 @@ static AdamFuse adam_fuse(hp_agent *a) {
     F.part = a->part; F.nslab = a->Mp / (a->slab8 ? a->s8_rows : S32_ROWS); F.B = a->B;
     F.act_dim = a->cfg.act_dim;
     F.action_l2 = (float)a->cfg.action_l2; F.loss_log = a->loss_log;
-    F.wt = a->adam_wt >= 0 ? a->adam_wt : (a->Mp <= 768 ? 1 : 0);   // us/update without / with: 40.9 / 40.3 at 256, 44.9 / 44.4 at 384, 46.9 / 46.1 at 512 k8, 53.1 / 52.9 at 768, 55.6 / 55.8 at 1024
+    F.wt = a->Mp <= 768 ? 1 : 0;   // us/update without / with: 40.9 / 40.3 at 256, 44.9 / 44.4 at 384, 46.9 / 46.1 at 512 k8, 53.1 / 52.9 at 768, 55.6 / 55.8 at 1024
     return F;
 }
 

@@ -239,7 +239,6 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
     p->n_grad = (size_t)n_grad_floats;
     p->phases = world >= 4 ? 2 : 1;
     if (const char *ph = getenv("RLARM_PEER_PHASES")) p->phases = atoi(ph) == 2 ? 2 : (atoi(ph) == 1 ? 1 : p->phases);
-    if (const char *g = getenv("RLARM_PEER_GATE")) p->gate = g[0] != '0';
     if (const char *t = getenv("RLARM_PEER_TILES")) p->tiles = t[0] != '0';
     const PeerLayout L(p->n_grad);
     p->bytes = L.total;
@@ -354,7 +353,6 @@ int hp_peer_status(hp_peer *p, uint32_t *error) {
 int hp_peer_set_gate(hp_peer *p, int32_t on) {
     HP_REQUIRE(p, HP_ERR_INVALID, "hp_peer_set_gate: null handle");
     p->gate = on != 0;
-    if (const char *g = getenv("RLARM_PEER_GATE")) p->gate = g[0] != '0';
     return HP_OK;
 }
 

@@ -20,14 +20,18 @@
 // Every counter exists once per XCD (SPLIT_CTR_STRIDE words apart: a producer bumps all eight, a consumer polls its XCD's): a
 // hundred workgroups polling ONE address saturate its memory channel and slow every weight stream that crosses it (measured:
 // the actor-side chains went from 26.3 to 28.6 us with a single counter polled every 0.1 us).
-// Workgroups are dispatched in index order and a waiting workgroup only ever waits for workgroups with a SMALLER index (chains
-// come first on every XCD), so the waits cannot starve what they wait for, also when ranks share a device.  Every poll is
-// bounded (FbSplitArgs::wait_ticks): a give-up skips the work, sets the sticky fault word and its pinned host mirror, and the
-// next host call fails (agent.hip: agent_check_fault).
-// The ACTOR's tiles: either the launch behind this one (144 tiles, one per CU), or -- the default -- further tile workgroups of
-// THIS launch that start when every actor-side chain has published (counter 6): one launch per update, the kernel boundary
-// between chains and tiles (the chain launch's drain, a gap, the tile launch's ramp and cold start: ~3 us) is replaced by one
-// hand-off (~1 us).  The first actor tile also finishes the loss log.
+// Forward progress of the waits: workgroup b runs on XCD b % 8, an XCD dispatches ITS workgroups in index order, chains come
+// first on every XCD and tiles last -- but a tile may wait for chains of ANOTHER XCD with a larger index (the actor-side chains
+// on XCDs 0-3 gate tiles everywhere; the critic chains on XCDs 4-7 feed tiles on XCDs 0-3).  What makes that safe is that every
+// XCD's chains fit its CUs at once (split_fits_rows: they are all resident before any tile of that XCD is dispatched) and that
+// the whole launch fits the device; with ranks sharing a device the split launch is not used at all (split_fits: no peer).
+// Every poll is bounded all the same (FbSplitArgs::wait_ticks): a give-up skips the work, sets the sticky fault word and its
+// pinned host mirror, and the next host call fails (agent.hip: agent_check_fault).
+// The ACTOR's tiles are the launch behind this one (144 tiles, one per CU, k_gemm_lds_adam).  Holding them in this launch as well
+// -- behind an "every actor-side chain has published" counter, one launch per update -- was built in round 4 and measured
+// 45.7 vs 38.0 us/update (the tiles cannot start before the last chain ends, an in-launch tile takes 6-8 us against 5 in a
+// fresh launch, and half of them queue behind critic tiles): removed in round 5, as was the form that carried them at the
+// head of the NEXT launch (40.9 vs 38.6).  profiles/r05_ab_staged_actor_tiles.txt has the stage-by-stage arithmetic.
 // Same device functions, same operands, same summation order as k_fb_slab8 + k_gemm_lds_adam: bit-identical results
 // (tests/test_gpu_update.py::test_split_launch_is_bit_identical).
 
@@ -167,19 +171,16 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
                 if (xx < x && nt > in_xcd) tile += 1;
             }
         }
-        int pi = 0, first_tile = 0;
+        int pi = 0;
 #pragma unroll
         for (int i = 1; i < MAX_PROBS; ++i)
-            if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) {
-                pi = i;
-                first_tile = Q.tiles.p[i].tile0;
-            }
+            if (i < Q.tiles.n && tile >= Q.tiles.p[i].tile0) pi = i;
         const int stage = (int)((Q.tile_stage >> (4 * pi)) & 15u);
         if (!handoff_wait(split_ctr(Q.sync, stage, (int)(blockIdx.x & 7)), Q.need_c, Q.wait_ticks, Q.fault, Q.fault_host,
                           1u, reinterpret_cast<int *>(dq)))
             return;
         SPLIT_STAMP(1);
-        gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, pi == Q.loss_prob && tile == first_tile);
+        gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, false);
         SPLIT_STAMP(3);
     } else if (role == SR_T) {
         // ------------------------------------------------------------------ target side, one update ahead
@@ -347,7 +348,6 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
 #undef S8_AFTER_CRITIC_FWD
 #undef S8_AFTER_CRITIC_DX1
 #undef S8_AFTER_CRITIC_DX
-        if (Q.loss_prob >= 0) split_publish(Q.sync, 6);   // one-launch form: dZ, dK3..dK1, the actor's activations and loss partials are out
         SPLIT_STAMP(3);
     }
 }

@@ -29,10 +29,9 @@ struct FbSplitArgs {
     unsigned long long wait_ticks;   // bound of every poll (100 MHz)
     unsigned need_c;                 // C chains of this launch (0: no tiles)
     unsigned tile_stage;             // 4 bits per problem of `tiles`: the counter that says its operands are published
-    int loss_prob;                   // the first tile of this problem finishes the loss log (-1: the launch behind this one does)
     int reset_sync;                  // prologue launch of a sequence (target chains only): clear the counters
     int tl_mark;                     // time-line builds: this launch records its per-workgroup stamps (the last one WITH target chains)
-    GemmGroup tiles;                 // weight-gradient problems: the critic's four, then (one-launch form) the actor's four
+    GemmGroup tiles;                 // weight-gradient problems: the critic's four
     AdamFuse adam;                   // their optimizer epilogue
 };
 static_assert(sizeof(FbSplitArgs) <= 4096, "kernel arguments of k_fb_split8 exceed the 4 KB kernarg segment");

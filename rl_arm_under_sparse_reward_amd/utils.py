@@ -27,7 +27,7 @@ from . import _lib
 class Communicator:
     """Thin view of the default torch.distributed process group (or a single rank)."""
 
-    def __init__(self, device_id=None, force=False):
+    def __init__(self, device_id=None, force=False, gate=None):
         import torch.distributed as dist
 
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -37,6 +37,7 @@ class Communicator:
         self._native_lib = None
         self.peer = None          # library-side peer-memory exchange (hp_peer *), see attach_peer
         self.shared_device = False   # two or more ranks on one physical device (set by attach_peer)
+        self.gate = gate             # peer exchange: waits in gate kernels (hp_peer_set_gate); None = exactly when ranks share a device
 
     def agree(self, flag, ctx=None):
         """True iff `flag` is true on EVERY rank (collective).  Transport decisions must be taken by all ranks together."""
@@ -126,7 +127,7 @@ class Communicator:
         ids = [torch.zeros(32, dtype=torch.uint8, device=dev) for _ in range(self.world_size)]
         dist.all_gather(ids, mine_id)
         self.shared_device = len({bytes(t.cpu().tolist()) for t in ids}) < self.world_size
-        _lib.check(lib.hp_peer_set_gate(h, 1 if self.shared_device else 0))
+        _lib.check(lib.hp_peer_set_gate(h, 1 if (self.shared_device if self.gate is None else self.gate) else 0))
         ok = lib.hp_peer_connect(h, raw) == 0
         if not agree(ok):      # before any collective kernel: a rank that could not map its peers must not leave the others waiting
             lib.hp_peer_destroy(h)

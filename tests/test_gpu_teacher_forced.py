@@ -239,15 +239,14 @@ def test_every_update_meets_the_north_star_bar_single_rank(batch, k, monkeypatch
           f"grad / max|g| {worst[1]:.2e} (error vs float64 = {worst[4]:.2f} x torch float32's), optimizer vs torch.optim.Adam {worst[2]:.2f} x (1 ulp + 5e-10), well-conditioned param {worst[3]:.2e}, ReLU ties {worst[5]}")
 
 
-@pytest.mark.parametrize("batch,k,n_eps,one", [(256, 4, 64, 1), (256, 4, 5000, 1), (64, 4, 64, 1), (256, 4, 64, 0)],
-                         ids=["b256", "b256_full_shard", "b64", "b256_two_launches"])
-def test_every_update_meets_the_bar_through_the_split_launch(batch, k, n_eps, one, monkeypatch):
+@pytest.mark.parametrize("batch,k,n_eps", [(256, 4, 64), (256, 4, 5000), (64, 4, 64), (320, 8, 64)],
+                         ids=["b256", "b256_full_shard", "b64", "b320_k8"])
+def test_every_update_meets_the_bar_through_the_split_launch(batch, k, n_eps, monkeypatch):
     """Round 4: the same bars through slab8_split.h (RLARM_SPLIT=1 forces it for single updates too): target chains in a
     prologue launch, critic chains + the critic's weight-gradient tiles and optimizer step inside the chain launch behind the
     two in-launch counters, the actor's tiles behind it -- on the 64-episode buffer and on the full 5000-episode shard."""
     monkeypatch.setenv("RLARM_KEEP_GRADS", "1")
     monkeypatch.setenv("RLARM_SPLIT", "1")
-    monkeypatch.setenv("RLARM_SPLIT_ONE", str(one))   # 1 (default): the actor's tiles inside the split launch as well
     worst, agent = _run(batch, k, n_eps=n_eps, n_steps=N_STEPS if n_eps <= 64 else 20)
     print(f"teacher-forced (split launch) batch {batch} k {k} episodes {n_eps}: worst: loss rel {worst[0]:.2e}, grad / max|g| {worst[1]:.2e} "
           f"(vs float64 = {worst[4]:.2f} x torch float32's), optimizer {worst[2]:.2f} x (1 ulp + 5e-10), param {worst[3]:.2e}, ReLU ties {worst[5]}")

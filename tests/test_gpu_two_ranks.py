@@ -48,7 +48,6 @@ def _worker(rank, world, port, out_dir, transport="torch"):
         # the test after 5 s instead of hanging the box.
         os.environ["RLARM_COMM"] = "peer"
         os.environ["RLARM_PEER_PHASES"] = "1"
-        os.environ["RLARM_PEER_GATE"] = "0"
         os.environ["RLARM_PEER_TIMEOUT_S"] = "5"
     if transport == "peertilesks":
         # with a SPLIT reduction of the narrow problems (default from batch 768) the workgroup that reaches the
@@ -73,7 +72,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     from rl_arm_under_sparse_reward_amd.utils import Communicator
 
     torch.set_num_threads(2)
-    comm = Communicator(0)
+    comm = Communicator(0, gate=False if transport.startswith("peertiles") else None)
     assert comm.active and comm.world_size == world
     n_eps, batch, seed = 32, {"peertiles": 64, "peertilesks": 128}.get(transport, 256), 125 + rank
     eps = make_episodes(n_eps, seed=40 + rank, mode="walk")

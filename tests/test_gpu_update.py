@@ -193,8 +193,7 @@ def test_split_weight_gradient_kernel_tracks_oracle(batch, split, monkeypatch):
     `split` workgroups that meet through write-through partial tiles and a ticket -- forced here onto every engine and
     onto ragged slices (1281 rows -> slices of 224/.../161 padded rows), odd splits (no XCD placement) and split 1 (no
     exchange at all)."""
-    monkeypatch.setenv("RLARM_DW64", "1")
-    monkeypatch.setenv("RLARM_DW_SPLIT", str(split))
+    monkeypatch.setenv("RLARM_DW64", f"s{split}")
     test_updates_track_oracle_over_a_cycle(batch, 4)
 
 
@@ -437,8 +436,7 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         monkeypatch.setenv("RLARM_PEER_TILES", "0")
     if transport.endswith("+dw64"):   # the split weight-gradient kernel without its optimizer epilogue (k_dw64 -> exchange -> Adam)
         transport = transport[:-5]
-        monkeypatch.setenv("RLARM_DW64", "1")
-        monkeypatch.setenv("RLARM_DW_SPLIT", "3")
+        monkeypatch.setenv("RLARM_DW64", "s3")
     from rl_arm_under_sparse_reward_amd import _lib
 
     monkeypatch.setenv("RLARM_COMM", transport)
@@ -473,36 +471,24 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
 
-@pytest.mark.parametrize("switch,batch", [("RLARM_AHEAD=0", 256), ("RLARM_FUSE_ADAM=0", 256), ("RLARM_AHEAD=1", 1024),
-                                          ("RLARM_GEMM_XCD=0", 256), ("RLARM_GEMM_XCD=0", 1024), ("RLARM_FB_XCD=0", 256),
-                                          ("RLARM_FB_XCD=1", 512), ("RLARM_FB_PREFETCH=0", 256), ("RLARM_FB_PREFETCH=1", 1024),
-                                          ("RLARM_PLAN_SIDE=1", 256), ("RLARM_PLAN_SIDE=0", 1024), ("RLARM_PLAN_SIDE=0", 2048),
-                                          ("RLARM_PLAN_SIDE=1", 449), ("RLARM_PLAN_SIDE=2", 1024), ("RLARM_PLAN_SIDE=2", 256),
-                                          # 32-row engine + split weight-gradient tiles: look-ahead on a second stream / in front of
-                                          # every launch
-                                          ("RLARM_PLAN_SIDE=2", 3072), ("RLARM_PLAN_SIDE=0", 2560),
-                                          # round 3: the cycle's opening work as four launches instead of k_cycle_open; the other
-                                          # loop-control form of the weight-gradient tiles; optimizer stores plain / write-through
-                                          ("RLARM_CYCLE_OPEN=0", 256), ("RLARM_CYCLE_OPEN=0", 1024), ("RLARM_GEMM_UNI=1", 256),
-                                          ("RLARM_GEMM_UNI=0", 512), ("RLARM_GEMM_UNI=1", 1024), ("RLARM_ADAM_WT=0", 256),
-                                          ("RLARM_ADAM_WT=1", 1024), ("RLARM_ADAM_WT=1", 3072),
-                                          # round 4: the split launch (target chains one update ahead, critic tiles + optimizer
-                                          # inside the chain launch; default where it fits) against the two-launch form, its other
-                                          # placement, and forced on for the single-update tail of a sequence
-                                          # (the 4-update sequences of this test take the two-launch form by default: the split
-                                          # launch is forced on, alone and with its other placements / the one-launch form)
-                                          ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT=1", 128), ("RLARM_SPLIT=1", 288), ("RLARM_SPLIT=1", 64),
-                                          ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=0", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_PLACE=1", 256),
-                                          ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 256), ("RLARM_SPLIT=1,RLARM_SPLIT_ONE=1", 128),
-                                          # bias gradients + their optimizer step inside the tn = 0 tiles instead of in workgroups of
-                                          # their own (gemm_bias_tile): two-launch form, split launch, ride kernels, split narrow
-                                          # tiles (4 slices from 768 rows: the panel adds the slices' sums in slice order)
-                                          ("RLARM_SEP_BIAS=0", 256), ("RLARM_SEP_BIAS=0,RLARM_SPLIT=1", 256), ("RLARM_SEP_BIAS=0", 449),
-                                          ("RLARM_SEP_BIAS=0", 512), ("RLARM_SEP_BIAS=0", 768), ("RLARM_SEP_BIAS=0", 1024),
-                                          ("RLARM_SEP_BIAS=0", 100)])
+# Round 5: the switches of forms that were measured and lost are gone with their code; what is left that
+# changes the launch structure of an update is listed here, each against the default at the shapes where it bites.
+@pytest.mark.parametrize("switch,batch", [
+    ("RLARM_FUSE_ADAM=0", 256), ("RLARM_FUSE_ADAM=0", 1024), ("RLARM_FUSE_ADAM=0", 3072),      # optimizer as a launch of its own
+    ("RLARM_CYCLE_OPEN=0", 256), ("RLARM_CYCLE_OPEN=0", 1024),                                   # the cycle's opening work as four launches
+    ("RLARM_UPDATE_GRAPH=0", 256), ("RLARM_UPDATE_GRAPH=0", 2048),                               # eager launches instead of cached graphs
+    # the split launch (target chains one update ahead, critic tiles + optimizer inside the chain launch; default where it fits
+    # from 12 updates per sequence) against the two-launch form: the 4-update sequences of this test take the two-launch form by
+    # default, so the split launch is forced on; and off for whole cycles in test_split_launch_is_bit_identical
+    ("RLARM_SPLIT=1", 256), ("RLARM_SPLIT=1", 128), ("RLARM_SPLIT=1", 288), ("RLARM_SPLIT=1", 64), ("RLARM_SPLIT=0", 256),
+    ("RLARM_SLAB_ROWS=8", 256), ("RLARM_SLAB_ROWS=16", 1024), ("RLARM_SLAB_ROWS=4", 449),       # other slab heights of the thin-slab engine
+    ("RLARM_DW64=1", 256), ("RLARM_DW64=s2", 1024), ("RLARM_DW64=0", 2048),                      # 64 x 64 split weight-gradient tiles on / off
+    ("RLARM_DW_KSPLIT=2", 256), ("RLARM_DW_KSPLIT=1", 1024), ("RLARM_DW_KSPLIT=8", 768),         # reduction slices of the narrow problems
+    ("RLARM_KEEP_GRADS=1", 256), ("RLARM_KEEP_GRADS=1", 1024)])                                  # gradients also written out
 def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
-    """The default path (next minibatch gathered one launch ahead while spare CUs exist, Adam in the weight-gradient
-    epilogue, its big problems placed on XCD pairs) against the same engine with one of those switched: same arithmetic, same summation order, same RNG stream -> identical bits after 3 cycles."""
+    """The default path against the same learner with ONE structural switch changed: same arithmetic, same summation order, same
+    RNG stream -> identical bits after 3 cycles.  (RLARM_SLAB_ROWS / RLARM_DW64 / RLARM_DW_KSPLIT change the summation order
+    of the weight gradients' batch reduction: those are held to the oracle's bar instead, see below.)"""
     torch.manual_seed(0)
     ref_agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     want = _run_cycles(ref_agent, graph=True)
@@ -512,8 +498,13 @@ def test_engine_variants_are_bit_identical(switch, batch, monkeypatch):
     torch.manual_seed(0)
     agent, _ = make_agent(batch=batch, n_eps=32, seed=21)
     got = _run_cycles(agent, graph=True)
+    reorders = switch.split("=")[0] in ("RLARM_SLAB_ROWS", "RLARM_DW64", "RLARM_DW_KSPLIT")
     for a, b in zip(want, got):
-        assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+        a, b = np.asarray(a), np.asarray(b)
+        if not reorders or a.dtype.kind in "iu":
+            assert np.array_equal(bits(a), bits(b))
+        else:       # another order of the same float32 sums: close, not identical (the teacher-forced tests hold each form to 1e-5)
+            assert np.allclose(a, b, rtol=2e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("batch,n_updates", [(256, 40), (256, 7), (320, 5), (100, 40)])
@@ -541,12 +532,7 @@ def test_split_launch_is_bit_identical(batch, n_updates, monkeypatch):
     got = run()
     monkeypatch.setenv("RLARM_SPLIT", "1")
     forced = run()
-    monkeypatch.setenv("RLARM_SPLIT_ONE", "1")       # opt-in: the actor's tiles inside the split launch too (one launch per update)
-    one = run()
-    monkeypatch.setenv("RLARM_SPLIT_PLACE", "1")
-    monkeypatch.delenv("RLARM_SPLIT_ONE")
-    placed = run()
-    for other in (got, forced, one, placed):
+    for other in (got, forced):
         for a, b in zip(want, other):
             assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
@@ -554,7 +540,7 @@ def test_split_launch_is_bit_identical(batch, n_updates, monkeypatch):
 @pytest.mark.parametrize("batch", [256, 1024, 2048, 3072])
 def test_repeated_runs_are_bit_identical(batch, monkeypatch):
     """Race check for the concurrent pieces of a cycle (index plans drawn two updates ahead, next minibatch gathered by
-    spare workgroups, input sets ping-ponging): 60 cycles = 2400 updates twice, then once with gather-ahead off --
+    spare workgroups, input sets ping-ponging): 60 cycles = 2400 updates twice, then once in the two-launch form --
     identical parameters and sampler state every time.  Batch 256 runs 4-row slabs, 1024 8-row slabs, 3072 the 32-row
     engine whose weight-gradient workgroups meet through tickets (dw64.h: the sum order must not depend on who arrives last)."""
     def run():
@@ -568,7 +554,7 @@ def test_repeated_runs_are_bit_identical(batch, monkeypatch):
                 np.asarray(st[1]), np.asarray([st[2]]))
     first = run()
     second = run()
-    monkeypatch.setenv("RLARM_AHEAD", "0")
+    monkeypatch.setenv("RLARM_SPLIT", "0")           # ... and once in the other launch structure (a no-op beyond batch 320)
     third = run()
     for other in (second, third):
         for a, b in zip(first, other):

@@ -21,4 +21,4 @@ ns = dict(T.__dict__); ns["worst"] = worst; ns["trace"] = trace
 exec(body, ns)
 ns["run"](batch, int(os.environ.get("REPLAY_K", "4")))
 if os.environ.get("TRACE"): print(" ".join(f"{v:.1e}" for v in trace))
-print("batch", batch, os.environ.get("RLARM_DW64"), os.environ.get("RLARM_DW_SPLIT"), os.environ.get("RLARM_ENGINE"), "worst rel dev actor/critic", worst)
+print("batch", batch, os.environ.get("RLARM_DW64"), os.environ.get("RLARM_ENGINE"), "worst rel dev actor/critic", worst)

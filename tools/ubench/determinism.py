@@ -33,8 +33,8 @@ def run(cycles, batch):
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for batch in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("256", "1024"))]:
     a = run(cycles, batch); b = run(cycles, batch)
-    os.environ["RLARM_AHEAD"] = "0"; c = run(cycles, batch); del os.environ["RLARM_AHEAD"]
+    os.environ["RLARM_UPDATE_GRAPH"] = "0"; c = run(cycles, batch); del os.environ["RLARM_UPDATE_GRAPH"]
     # the split launch (in-launch counters between chains and tiles, slab8_split.h) against the two-launch form
     os.environ["RLARM_SPLIT"] = "0"; d = run(cycles, batch); del os.environ["RLARM_SPLIT"]
-    print(f"batch {batch}: {cycles} cycles = {40 * cycles} updates  run1 {a[0][:16]} run2 {b[0][:16]} no-ahead {c[0][:16]} "
+    print(f"batch {batch}: {cycles} cycles = {40 * cycles} updates  run1 {a[0][:16]} run2 {b[0][:16]} eager {c[0][:16]} "
           f"two-launch form {d[0][:16]}  losses {a[1]}", "OK" if a[0] == b[0] == c[0] == d[0] else "MISMATCH")
