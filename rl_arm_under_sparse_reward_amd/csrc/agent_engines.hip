@@ -127,6 +127,9 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
         return;
     }
     const int extra = (int)blockIdx.x - tiles;
+#ifdef SLAB_TIMELINE   // riders stamp start / end like the tiles (slot 7: 1 = index plan, 2 = gather)
+    if (threadIdx.x == 0 && blockIdx.x < 512) { g_gemm_tl_wg[blockIdx.x][0] = wall_clock64(); g_gemm_tl_wg[blockIdx.x][7] = extra < R.n_plan ? 1 : 2; }
+#endif
     if (extra < R.n_plan) {
         if (threadIdx.x >= MT_THREADS) return;   // ended waves take no part in the barriers of the draw
         // the sequential draw is the longest single job of this launch at batch 1024 (as long as the tiles): let its waves
@@ -138,6 +141,9 @@ __device__ __forceinline__ void gemm_ride_body(const GemmGroup &grp, const AdamF
         s8r4::s8_gather_ahead(R.ahead, R.aXT, R.aXA, R.aXP, R.ldx, R.act_off, R.act_dim, R.max_action, extra - R.n_plan,
                               R.n_ahead);
     }
+#ifdef SLAB_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_gemm_tl_wg[blockIdx.x][5] = wall_clock64();
+#endif
 }
 __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_ride(const GemmGroup grp, const RideArgs R, int tiles) {
     gemm_ride_body<false>(grp, nullptr, R, tiles);

@@ -118,6 +118,7 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
     int idx, in_xcd, n_in_xcd;
     const int role = split_role(R, idx, in_xcd, n_in_xcd);
     if (role == SR_N) return;
+
 #ifdef SLAB_TIMELINE
     if (Q.tl_mark && threadIdx.x == 0 && blockIdx.x < 1024) {
         g_split_entry[blockIdx.x] = t_entry;

@@ -30,7 +30,7 @@ for _ in range(20):
 ctx.synchronize()
 fn = lib._cdll.hp_debug_gemm_wg_timeline
 wg = (C.c_uint64 * 4096)(); fn.restype = C.c_int; fn(wg)
-rows = [(b, [wg[8 * b + k] for k in range(6)]) for b in range(512) if wg[8 * b] and wg[8 * b + 5]]
+rows = [(b, [wg[8 * b + k] for k in range(8)]) for b in range(512) if wg[8 * b] and wg[8 * b + 5]]
 last = max(r[1][0] for r in rows)
 rows = [r for r in rows if r[1][0] > last - 3000]        # the last launch only (stamps of earlier, larger launches may linger)
 b0 = min(r[1][0] for r in rows)
@@ -44,3 +44,13 @@ slow = sorted(((r[1][5] - b0) / 100, (r[1][0] - b0) / 100, r[0]) for r in rows)[
 print("  last to end (end, start, block):", " ".join(f"{e:.2f}<-{s:.2f}@{b}" for e, s, b in slow))
 late = sorted(((r[1][0] - b0) / 100, r[0]) for r in rows)[-8:]
 print("  last to start (start, block):", " ".join(f"{s:.2f}@{b}" for s, b in late))
+riders = [r for r in rows if r[1][7] in (1, 2) and not r[1][1]]
+for kind, nm in ((1, "index-plan rider"), (2, "gather riders")):
+    v = [r for r in riders if r[1][7] == kind]
+    if v: print(f"  {nm}: n={len(v)} start {min((r[1][0] - b0) / 100 for r in v):.2f} .. end {max((r[1][5] - b0) / 100 for r in v):.2f} (longest {max((r[1][5] - r[1][0]) / 100 for r in v):.2f} us)")
+tiles = [r for r in rows if r[1][1]]
+print("  tiles only: end", stat([(r[1][5] - b0) / 100 for r in tiles]))
+if os.environ.get("TL_ROWS"):
+    print("  slowest 30 workgroups (block: start | products, loop left, LDS sums, gate + bias, end since own start | end):")
+    for r in sorted(tiles, key=lambda r: r[1][5])[-30:]:
+        print(f"   wg {r[0]:3d} xcd {r[0] % 8}: start {(r[1][0] - b0) / 100:5.2f} | " + " ".join(f"{(r[1][k] - r[1][0]) / 100:6.2f}" if r[1][k] else "   -  " for k in (1, 2, 3, 4, 5)) + f" | end {(r[1][5] - b0) / 100:5.2f}")
