@@ -124,3 +124,62 @@ def test_reference_learner_on_the_mirror_data_path_is_bitwise_the_oracle_run(bat
         assert np.array_equal(bits(got.flat(which)), bits(want.flat(which))), which
     assert state_equal(rng, *rs.get_state()[1:3])
     assert buf.current_size == store.current_size and buf.n_transitions_stored == store.n_transitions_stored
+
+
+def test_torch_learner_on_the_gpu_fed_by_the_device_output_sampler():
+    """INTEGRATION.md section 1 with `args.cuda` (ddpg_agent.py:244-248): the reference's torch learner runs ON THE GPU and its
+    four input tensors come straight out of `replay_buffer.sample_device()` (hp_buffer_sample_dev: gather + relabel + reward + clip +
+    normalise -> float32 in device memory) -- nothing of a minibatch crosses PCIe.  Every minibatch must be BITWISE what the
+    all-oracle CPU run feeds its learner (same draws, same float64 arithmetic, same float32 rounding), the random stream must end
+    on the same word; the losses follow within the north-star 1e-5 on the first update and a drift bound after (the GPU's
+    matrix products sum in another order than the CPU's)."""
+    torch.set_num_threads(4)
+    seed, n_eps, n_batches, batch, k = 125, 40, 40, 256, 4
+    a0 = oupd.init_actor(27, 3, 4, seed=1)
+    c0 = oupd.init_critic(27, 3, 4, seed=2)
+    fp = future_probability("future", k)
+    first = make_episodes(n_eps, seed=3, mode="walk")
+    eps = make_episodes(2, seed=50, mode="walk")
+    # ---- all-oracle run (CPU)
+    rs = np.random.RandomState(seed)
+    store = EpisodeStore(100, 27, 3, 4, n_eps * 100 + 300)
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    want = oupd.DDPGLearner(a0, c0)
+    store.store_episode(first, rs)
+    store.store_episode(eps, rs)
+    update_normalizers(on, gn, eps, fp, rs)
+    want_x, want_log = [], []
+    for _ in range(n_batches):
+        tr, _ = store.sample(batch, fp, rs)
+        mb = oupd.minibatch_tensors(tr, on, gn)
+        res = want.update(*mb)
+        want_x.append(mb)
+        want_log.append((res["actor_loss"], res["critic_loss"]))
+    # ---- torch learner on cuda:0, mirror data path with device outputs
+    dev = torch.device("cuda", ctx().device_id)
+    rng = fresh_rng(seed)
+    her = her_sampler("future", k, None, rng=rng)
+    buf = replay_buffer(dict(ENV_PARAMS), n_eps * 100 + 300, her.sample_her_transitions, rng=rng, ctx=ctx())
+    o_norm = normalizer(size=27, default_clip_range=5, ctx=ctx())
+    g_norm = normalizer(size=3, default_clip_range=5, ctx=ctx())
+    got = oupd.DDPGLearner({kk: v.to(dev) for kk, v in a0.items()}, {kk: v.to(dev) for kk, v in c0.items()})
+    buf.store_episode(first)
+    buf.store_episode(eps)
+    mb_obs, mb_ag, mb_g, mb_actions = eps
+    transitions = her.sample_her_transitions({'obs': mb_obs, 'ag': mb_ag, 'g': mb_g, 'actions': mb_actions,
+                                              'obs_next': mb_obs[:, 1:, :], 'ag_next': mb_ag[:, 1:, :]}, mb_actions.shape[1])
+    obs, g = preproc_og(transitions['obs'], transitions['g'], 200)
+    o_norm.update(obs); g_norm.update(g)
+    o_norm.recompute_stats(); g_norm.recompute_stats()
+    assert np.array_equal(bits(o_norm.mean), bits(on.mean)) and np.array_equal(bits(g_norm.std), bits(gn.std))
+    for i in range(n_batches):
+        mb = buf.sample_device(batch, o_norm, g_norm, clip_obs=200)                      # ddpg_agent.py:227-243 in one kernel
+        assert all(t.is_cuda and t.dtype == torch.float32 for t in mb.values())
+        for key, ref in zip(("x", "x_next", "actions", "r"), want_x[i]):
+            assert np.array_equal(bits(mb[key].cpu().numpy()), bits(ref.numpy())), ("minibatch", i, key)
+        res = got.update(mb["x"], mb["x_next"], mb["actions"], mb["r"])                  # :250-277 on the GPU
+        for j, name in enumerate(("actor_loss", "critic_loss")):
+            tol = 1e-5 if i == 0 else 1e-5 * 1.3 ** min(i, 20)
+            assert abs(res[name] - want_log[i][j]) <= tol * max(abs(want_log[i][j]), 1e-2), (i, name, res[name], want_log[i][j])
+    assert state_equal(rng, *rs.get_state()[1:3])
+    ctx().set_stream(None)      # back on the context's own stream for whatever test runs next
