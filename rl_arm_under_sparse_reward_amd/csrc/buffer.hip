@@ -70,7 +70,6 @@ __global__ __launch_bounds__(256) void k_gather_dict(const double *__restrict__ 
 // [obs t | obs t+1 | ag t+1 | g' | action] = 2 od + 2 gd + ad doubles -- exactly 64 for the bmirobot shapes (27, 3, 4), i.e.
 // ONE 8-byte load per lane, of which the first 54 lanes read one contiguous 432-byte run.  HBM-bound: 67 doubles read,
 // 65 floats written per transition.
-#define FS_FLIGHT 4
 struct FusedSampleArgs {
     const double *obs, *ag, *g, *act;
     const PlanRec *plan;
@@ -83,38 +82,53 @@ struct FusedSampleArgs {
     unsigned char *o_her;
 };
 
+// FLIGHT transitions per wavefront and pass: 1 for small batches (one minibatch = two dependent memory latencies, as many
+// wavefronts as transitions), 4 from 16 Ki transitions on (more bytes in flight per wavefront, grid-stride).  Every load of a
+// pass -- the lanes' source elements AND the reward's operands -- is issued before the first value is used.
+template <int FLIGHT>
 __global__ __launch_bounds__(256) void k_gather_fused(const FusedSampleArgs A) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const int od = A.od, gd = A.gd, ad = A.ad, ldx = od + gd, Q = 2 * od + 2 * gd + ad;
-    for (long long base = wave * FS_FLIGHT; base < A.batch; base += n_waves * FS_FLIGHT) {
-        PlanRec rec[FS_FLIGHT];
+    // what this lane's source element is in the first strip of 64 (the only one for the bmirobot shapes): 0 obs t, 1 obs t+1,
+    // 2 ag t+1 (reward only), 3 g', 4 action, 5 nothing
+    auto kind_of = [&](int q) { return q < od ? 0 : q < 2 * od ? 1 : q < 2 * od + gd ? 2 : q < 2 * od + 2 * gd ? 3 : q < Q ? 4 : 5; };
+    auto col_of = [&](int q, int kind) { return kind == 0 ? q : kind == 1 ? q - od : kind == 2 ? q - 2 * od : kind == 3 ? q - 2 * od - gd : q - 2 * od - 2 * gd; };
+    const int rc = lane < gd ? lane : gd - 1;      // reward operands: lanes < gd, one goal component each
+    for (long long base = wave * FLIGHT; base < A.batch; base += n_waves * FLIGHT) {
+        PlanRec rec[FLIGHT];
 #pragma unroll
-        for (int k = 0; k < FS_FLIGHT; ++k) rec[k] = A.plan[base + k < A.batch ? base + k : A.batch - 1];
+        for (int k = 0; k < FLIGHT; ++k) rec[k] = A.plan[base + k < A.batch ? base + k : A.batch - 1];
+        const double *obs0[FLIGHT], *g_src[FLIGHT];
+        double ra[FLIGHT], rg[FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {
+            const long long e = rec[k].e;
+            const int t = rec[k].t;
+            obs0[k] = A.obs + (e * (A.T + 1) + t) * od;
+            g_src[k] = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;   // her.py:35-36
+            ra[k] = A.ag[(e * (A.T + 1) + t + 1) * gd + rc];
+            rg[k] = g_src[k][rc];
+        }
         for (int q0 = 0; q0 < Q; q0 += 64) {   // one pass for the bmirobot shapes
-            const int q = q0 + lane;
-            // what this lane's source element is: 0 obs t, 1 obs t+1, 2 ag t+1 (reward only), 3 g', 4 action, 5 nothing
-            const int kind = q < od ? 0 : q < 2 * od ? 1 : q < 2 * od + gd ? 2 : q < 2 * od + 2 * gd ? 3 : q < Q ? 4 : 5;
-            const int j = kind == 0 ? q : kind == 1 ? q - od : kind == 2 ? q - 2 * od : kind == 3 ? q - 2 * od - gd : q - 2 * od - 2 * gd;
+            const int q = q0 + lane, kind = kind_of(q), j = col_of(q, kind);
             float mu = 0.f;
             double sd = 1.0, clip = 0.0;
             if (kind <= 1) { mu = A.onz->mean[j]; sd = A.onz->std[j]; clip = A.clip_o; }
             if (kind == 3) { mu = A.gnz->mean[j]; sd = A.gnz->std[j]; clip = A.clip_g; }
-            double v[FS_FLIGHT];
+            double v[FLIGHT];
 #pragma unroll
-            for (int k = 0; k < FS_FLIGHT; ++k) {
+            for (int k = 0; k < FLIGHT; ++k) {
                 const long long e = rec[k].e;
                 const int t = rec[k].t;
-                const double *obs0 = A.obs + (e * (A.T + 1) + t) * od;
-                const double *g_src = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;
                 // address-selected, unconditional load (idle lanes re-read element 0 of the observation row)
-                const double *p = kind <= 1 ? obs0 + q : kind == 2 ? A.ag + (e * (A.T + 1) + t + 1) * gd + j
-                                : kind == 3 ? g_src + j : kind == 4 ? A.act + (e * A.T + t) * ad + j : obs0;
+                const double *p = kind <= 1 ? obs0[k] + q : kind == 2 ? A.ag + (e * (A.T + 1) + t + 1) * gd + j
+                                : kind == 3 ? g_src[k] + j : kind == 4 ? A.act + (e * A.T + t) * ad + j : obs0[k];
                 v[k] = *p;
             }
 #pragma unroll
-            for (int k = 0; k < FS_FLIGHT; ++k) {
+            for (int k = 0; k < FLIGHT; ++k) {
                 const long long m = base + k;
                 if (m >= A.batch) continue;
                 if (kind <= 1 || kind == 3) {
@@ -134,21 +148,14 @@ __global__ __launch_bounds__(256) void k_gather_fused(const FusedSampleArgs A) {
         }
         // reward: lanes < gd hold (ag_next - g')^2 of their component, lane 0 adds them in index order (numpy's add.reduce
         // over < 8 contiguous elements is a left-to-right sum)
-        double sq[FS_FLIGHT];
 #pragma unroll
-        for (int k = 0; k < FS_FLIGHT; ++k) {
-            const long long e = rec[k].e;
-            const int t = rec[k].t, c = lane < gd ? lane : gd - 1;
-            const double *g_src = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;
-            const double d = __dsub_rn(A.ag[(e * (A.T + 1) + t + 1) * gd + c], g_src[c]);
-            sq[k] = __dmul_rn(d, d);
-        }
-#pragma unroll
-        for (int k = 0; k < FS_FLIGHT; ++k) {
+        for (int k = 0; k < FLIGHT; ++k) {
             const long long m = base + k;
+            const double d = __dsub_rn(ra[k], rg[k]);
+            const double sq = __dmul_rn(d, d);
             double s = 0.0;
             for (int c = 0; c < gd; ++c) {
-                const double sc = __shfl(sq[k], c);
+                const double sc = __shfl(sq, c);
                 s = (c == 0) ? sc : __dadd_rn(s, sc);
             }
             if (m < A.batch && lane == 0) {
@@ -546,9 +553,13 @@ static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_no
     A.o_e = reinterpret_cast<long long *>(o->e); A.o_t = reinterpret_cast<long long *>(o->t);
     A.o_fut = reinterpret_cast<long long *>(o->future_t);
     A.o_her = o->her;
-    const int64_t waves = (batch + FS_FLIGHT - 1) / FS_FLIGHT, wgs = (waves + 3) / 4;
-    const int64_t cap = (int64_t)b->ctx->cu_count * 8;            // grid-stride beyond 8 workgroups per compute unit
-    hipLaunchKernelGGL(k_gather_fused, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+    // (us per 262144 transitions of a 5000-episode shard: 4 in flight, grid capped at 8 / 32 workgroups per CU 126.8 / 121.0; 8 in
+    // flight 133.6; 2 in flight, cap 16: 130.5; 1 in flight, cap 64: 124.0 -- ~2.1 G transitions/s whatever the shape of the launch)
+    const int flight = batch >= 16384 ? 4 : 1;
+    const int64_t waves = (batch + flight - 1) / flight, wgs = (waves + 3) / 4;
+    const int64_t cap = (int64_t)b->ctx->cu_count * 32;           // grid-stride beyond 32 workgroups per compute unit
+    if (flight == 4) hipLaunchKernelGGL(k_gather_fused<4>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+    else hipLaunchKernelGGL(k_gather_fused<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
