@@ -175,8 +175,6 @@ struct hp_agent {
     bool slab32 = false;   // 32-row slabs on the 32x32x2 MFMA, forward + backward in one kernel (slab32.h: large batches)
     int s8_rows = 4;       // slab height of that engine: 4 rows up to batch 448, 8 up to 1280, 16 beyond (RLARM_SLAB_ROWS overrides)
     bool fuse_adam_ok = true;   // Adam in the weight-gradient GEMM's epilogue (RLARM_FUSE_ADAM=0: separate launch, for A/B)
-    // A/B switches, read once in hp_agent_create: RLARM_GEMM_XCD (0 = off), RLARM_FB_XCD, RLARM_FB_PREFETCH (-1 = by size,
-    // 0 = off, 1 = on)
     // large-minibatch weight gradients (dw64.h): 64 x 64 tiles, batch rows split over dw_S workgroups per tile
     bool dw64 = false;                   // RLARM_DW64: default from batch 1536
     int dw_S = 3;                        // (RLARM_DW64=s<n>)
@@ -230,7 +228,7 @@ struct hp_agent {
     unsigned long long *gl_ticket = nullptr;
     // split launch (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
-    // 1 = wherever it fits (single updates too: parity tests), RLARM_SPLIT_PLACE = placement variant (agent_engines.hip)
+    // 1 = wherever it fits (single updates too: parity tests)
     int split_mode = -1;                 // RLARM_SPLIT=0|1: never / also for short sequences (default: from SPLIT_MIN_UPDATES updates)
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
