@@ -228,7 +228,8 @@ __device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring,
 // instead of the 8 gate values in e[].
 __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
                                           int ld_out, const s8_mask_t *mask_in = nullptr,
-                                          s8_mask_t *mask_out = nullptr, float *gout = nullptr) {
+                                          s8_mask_t *mask_out = nullptr, float *gout = nullptr,
+                                          unsigned long long *wtl = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
     if (kh == 1) {
@@ -238,6 +239,7 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
             for (int r = 0; r < 4; ++r) pbuf[(4 * g + r) * 256 + col] = c[g][r];
     }
     s8_sync();
+    S8_WSTAMP(wtl, 16);
     if (kh == 0) {
         unsigned bits = mask_in ? (unsigned)mask_in[col] : 0u, outbits = 0u;
 #pragma unroll
@@ -283,13 +285,15 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
                                              const float *__restrict__ aux, int ldaux, float *pbuf, float *lout,
                                              int ld_out, const s8_mask_t *mask_in = nullptr,
                                              s8_mask_t *mask_out = nullptr, unsigned long long *tl2 = nullptr,
-                                             int k2 = 0, float *gout = nullptr, const float *pre_e = nullptr) {
+                                             int k2 = 0, float *gout = nullptr, const float *pre_e = nullptr,
+                                             unsigned long long *wtl = nullptr) {   // wtl: per-wave stamps (time-line build)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cg = wave & 3, b0 = (wave >> 2) * 32;
     float e[8];
     if (pre_e) e[0] = *pre_e;   // bias loaded at the trunk's start (s8_trunk)
     else if (!mask_in) s8_epi_load(e, epi, aux, ldaux);
     __builtin_amdgcn_sched_barrier(0);
     S8_TSTAMP(tl2, k2);
+    S8_WSTAMP(wtl, 0);
     f32x4 c[S8_NRG];
 #pragma unroll
     for (int g = 0; g < S8_NRG; ++g) c[g] = f32x4{0, 0, 0, 0};
@@ -302,7 +306,8 @@ __device__ __forceinline__ void s8_big_layer(const float *lin, int ld_in, RingSl
     rbase = (rbase + 32) % S8_RING;
     __builtin_amdgcn_sched_barrier(0);
     S8_TSTAMP(tl2, k2 + 1);
-    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout);
+    S8_WSTAMP(wtl, 8);
+    s8_finish(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout, wtl);
     S8_TSTAMP(tl2, k2 + 2);
 }
 

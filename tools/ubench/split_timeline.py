@@ -72,6 +72,13 @@ tl = (C.c_uint64 * 192)(); _lib.check(lib.hp_agent_debug_timeline(h, tl))
 for ch, nm in ((0, "A chain slab 0"), (3, "A chain, first slab of the next XCD"), (1, "C chain slab 0"), (2, "T chain slab 0")):
     v = [tl[ch * 32 + k] for k in range(32)]
     if v[0]: print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(32) if v[k]))
+# per-wave stamps of ONE 256 x 256 layer (the critic's first dX layer in the actor-side chain above; slab8.h: S8_WSTAMP)
+wv = [[tl[128 + 8 * k + w] for w in range(8)] for k in range(4)]
+if all(wv[0]):
+    w0 = min(wv[0])
+    print("[one layer, per wave] wave = (column group, reduction half); us since the first wave entered the layer")
+    for k, kn in enumerate(("layer entered", "products done", "merge barrier passed", "closing barrier passed")):
+        print(f"   {kn:24s}", " ".join(f"w{w}({w & 3},{w >> 2}):{(wv[k][w] - w0) / 100:5.2f}" for w in range(8) if wv[k][w]))
 try:
     fn = lib._cdll.hp_debug_gemm_wg_timeline
     wg = (C.c_uint64 * 4096)(); fn.restype = C.c_int; fn(wg)
