@@ -595,7 +595,7 @@ __device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamF
 // uses it; the first workgroups of a launch to reach a field take the round trip to memory for it, in every stage (time line of
 // the actor's tile launch: the first five workgroups per XCD ended 0.5-2 us after the others).  Every workgroup therefore
 // touches the whole block with ONE vector load per 128-byte line at entry, so that the lines are on their way into the XCD's L2
-// before the scalar loads ask for them: -0.2 us/update at batch 256 (profiles/r05_ab_kernarg_prefetch.txt).  The same trick on
+// before the scalar loads ask for them: -0.2 us/update at batch 256 (profiles/r05_ab_actor_tile_launch_tail.txt).  The same trick on
 // the kernel's CODE (s_getpc, 36 KB) changed nothing and is not kept.  The destination register must stay reserved until the load
 // has returned: the kernel keeps it alive to its end (kernarg_prefetch_keep).
 #ifndef GL_KERNARG_PREFETCH
