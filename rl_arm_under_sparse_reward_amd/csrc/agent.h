@@ -56,6 +56,7 @@ struct GemmProb {
 #define MAX_PROBS 8
 #define GL_PART (32 * 32 + 32)   // floats of one partial tile in the split-reduction exchange (gemm_lds.h): the tile, then its column sums
 #define GL_MAX_SPLIT_TILES 64
+#define GL_MAX_KS 8            // most reduction slices per split tile (RLARM_DW_KSPLIT; hp_agent_create allocates GL_MAX_SPLIT_TILES * 8 partials)
 struct GemmGroup {
     int n;
     int xcd;    // problems 0..3 have 8 x 8 tiles each and own one pair of XCDs (Launch::place_on_xcds)

@@ -335,11 +335,11 @@ int hp_agent_create(hp_ctx *ctx, const hp_agent_cfg *cfg, hp_agent **out) {
         // 1 vs 4 slices: 54.2 / 53.1 at 768, 55.6 / 54.1 at 896, 82.1 / 78.9 at 1152, 83.6 / 79.2 at 1280)
         const char *e = getenv("RLARM_DW_KSPLIT");
         a->dw_ksplit = e ? atoi(e) : (a->Mp >= 768 ? 4 : 1);
-        if (a->dw_ksplit < 1 || a->dw_ksplit > 8) a->dw_ksplit = 1;
+        if (a->dw_ksplit < 1 || a->dw_ksplit > GL_MAX_KS) a->dw_ksplit = 1;
         const int H = a->H;
         const int narrow = 2 * ((H + 31) / 32) + ((H + 31) / 32) * (((a->lc.K1 + 31) / 32) + ((a->la.K1 + 31) / 32));
         if (narrow <= GL_MAX_SPLIT_TILES) {
-            st = dev_alloc(a, &a->gl_part, (size_t)GL_MAX_SPLIT_TILES * 8 * GL_PART);
+            st = dev_alloc(a, &a->gl_part, (size_t)GL_MAX_SPLIT_TILES * GL_MAX_KS * GL_PART);
             if (st == HP_OK) st = dev_alloc(a, &a->gl_ticket, GL_MAX_SPLIT_TILES);
         }
     }
