@@ -111,3 +111,22 @@ def test_pending_updates_are_issued_in_front_of_any_other_library_call():
     _lib.unregister_pending(p)
     lib.hp_ctx_create(10 ** 6, C.byref(h))
     assert calls == ["flush"]
+
+
+def test_switch_list_is_the_documented_one():
+    """Every RLARM_* switch the product reads is in DESIGN.md section 4's list, the list names nothing else, and it stays at 15
+    (the forms measured and lost go with their switches)."""
+    read = set()
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                src = open(os.path.join(root, f), encoding="utf-8").read()
+                if f.endswith(".py"):
+                    read |= set(re.findall(r"""environ(?:\.get|\.pop|\.setdefault)?[\(\[]\s*["'](RLARM_[A-Z0-9_]+)""", src))
+                else:
+                    read |= set(re.findall(r"""(?:getenv|tri)\(\s*"(RLARM_[A-Z0-9_]+)""", src))
+    design = open(os.path.join(os.path.dirname(PKG), "DESIGN.md"), encoding="utf-8").read()
+    sec = design[design.index("Switches (A/B and debugging"):design.index("## 5. Parity")]
+    documented = set(re.findall(r"`(RLARM_[A-Z0-9_]+)", sec))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+    assert len(documented) <= 15, sorted(documented)
