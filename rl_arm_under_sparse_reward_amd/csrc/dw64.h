@@ -132,8 +132,8 @@ __device__ __forceinline__ void dw64_tile(const GemmGroup &grp, const AdamFuse *
         }
     }
     DW_STAMP(1);
-    as0 += __shfl_xor(as0, 32);
-    as1 += __shfl_xor(as1, 32);
+    as0 = gl_fold32(as0);
+    as1 = gl_fold32(as1);
     // ---- the 8 partial tiles meet in LDS, fixed tree: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
     float *bs = lds + DW_RING * DW_BLK * 8;   // [4][64] column sums, behind the rings
     // (slot layout of the intermediate turns = the accumulators' own: float4 number (16 a + q) * 64 + lane holds registers

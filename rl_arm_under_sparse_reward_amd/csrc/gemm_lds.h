@@ -147,6 +147,16 @@ __device__ __forceinline__ void gl_products(const float *ldsA, const float *ldsB
 // PEER (data-parallel ranks, one-shot form inside this launch): the tile's gradient sums go out through the rank's exchange
 // vector, the workgroup signals its slot of the per-tile flags on every peer, waits for the peers' same tile, adds the
 // ranks' tiles in rank order (utils.sync_grads: SUM, utils.py:43-48) and steps -- no separate exchange + optimizer launch.
+// s + (s of the lane 32 / 16 away), in every lane: gfx950's lane-swap VALU instructions instead of a trip through the LDS crossbar
+// (__shfl_xor); swap(a, a) leaves {lo, lo} and {hi, hi} (or the even / odd rows), the two addends of every lane are the old pair
+__device__ __forceinline__ float gl_fold32(float s) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ float gl_fold16(float s) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
 struct PeerTile {
     const PeerDev *D;
     int u, mean;
@@ -315,7 +325,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
 #pragma unroll
         for (int r = 0; r < 16; ++r) my[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + l] = cr[r];
         if (want_bias_grad) {
-            asr += __shfl_xor(asr, 32);
+            asr = gl_fold32(asr);
             if (h == 0) bsum[wave][l] = asr;
         }
     } else {
@@ -329,10 +339,10 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     }
     }
     if (want_bias_grad && !ring_path) {
-        as0 += __shfl_xor(as0, 16);
-        as0 += __shfl_xor(as0, 32);
-        as1 += __shfl_xor(as1, 16);
-        as1 += __shfl_xor(as1, 32);
+        as0 = gl_fold16(as0);
+        as0 = gl_fold32(as0);
+        as1 = gl_fold16(as1);
+        as1 = gl_fold32(as1);
         if (q == 0) {
             bsum[wave][i] = as0;
             bsum[wave][16 + i] = as1;
@@ -584,7 +594,7 @@ __device__ __forceinline__ void gemm_bias_tile(const GemmGroup &grp, const AdamF
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) asr += blk[kp * 64];
         }
-        asr += __shfl_xor(asr, 32);
+        asr = gl_fold32(asr);
         if (slice) __syncthreads();   // the sums of the slice before have been read
         if (h == 0) bsum[wave][l] = asr;
         __syncthreads();

@@ -366,9 +366,33 @@ __device__ __forceinline__ float s8_row_shl_add(float s) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x100 + O, 0xf, 0xf, true);   // row_shl:O, zero fill
     return s + __int_as_float(moved);
 }
+// sum over the S8_ROWS first lanes of a wavefront into lane 0 (the per-slab loss partials): the pairs of __shfl_down(s, o, S8_ROWS) for
+// o = S8_ROWS / 2 .. 1, as DPP row shifts (S8_ROWS <= 16: one DPP row)
+__device__ __forceinline__ float s8_rows_sum_to_lane0(float s) {
+    if (S8_ROWS >= 16) s = s8_row_shl_add<8>(s);
+    if (S8_ROWS >= 8) s = s8_row_shl_add<4>(s);
+    s = s8_row_shl_add<2>(s);
+    s = s8_row_shl_add<1>(s);
+    return s;
+}
+// lanes 32-63 onto lanes 0-31 and rows 1 / 3 onto rows 0 / 2 with gfx950's lane-swap VALU instructions instead of two trips through the
+// LDS crossbar (ds_bpermute): v_permlane32_swap(a, a) leaves {lo, lo} and {hi, hi}, so lane i of the sum holds s[i % 32] + s[i % 32 + 32]
+// -- for i < 32 exactly what s += __shfl_down(s, 32) left there (same two addends) -- and likewise one row further down.
+__device__ __forceinline__ float s8_fold_halves(float s) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ float s8_fold_rows(float s) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+// lane 0's value to every lane: callers run with all 64 lanes active, so the first active lane IS lane 0 (one SALU move, no crossbar)
+__device__ __forceinline__ float s8_lane0(float s) {
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s)));
+}
 __device__ __forceinline__ float s8_wave_sum_to_lane0(float s) {
-    s += __shfl_down(s, 32);
-    s += __shfl_down(s, 16);
+    s = s8_fold_halves(s);
+    s = s8_fold_rows(s);
     s = s8_row_shl_add<8>(s);
     s = s8_row_shl_add<4>(s);
     s = s8_row_shl_add<2>(s);
@@ -381,7 +405,7 @@ __device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int row
     const float4 h = *reinterpret_cast<const float4 *>(lin + row * ld_in + 4 * p);
     if (nout == 1) {
         const float s = s8_wave_sum_to_lane0((h.x * wv[0].x + h.y * wv[0].y) + (h.z * wv[0].z + h.w * wv[0].w));
-        return __shfl(s, 0);
+        return s8_lane0(s);
     }
     // several outputs: the reduction trees advance TOGETHER (independent cross-lane moves in flight per level instead
     // of one dependent chain per output; same tree per output, so the same bits).  wv[j] for j >= nout holds a valid
@@ -390,15 +414,15 @@ __device__ __forceinline__ float s8_rowdots(const float *lin, int ld_in, int row
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = (h.x * wv[j].x + h.y * wv[j].y) + (h.z * wv[j].z + h.w * wv[j].w);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] += __shfl_down(s[j], 32);
+    for (int j = 0; j < 4; ++j) s[j] = s8_fold_halves(s[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] += __shfl_down(s[j], 16);
+    for (int j = 0; j < 4; ++j) s[j] = s8_fold_rows(s[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = s8_row_shl_add<1>(s8_row_shl_add<2>(s8_row_shl_add<4>(s8_row_shl_add<8>(s[j]))));
     float mine = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float tot = __shfl(s[j], 0);
+        const float tot = s8_lane0(s[j]);
         if (p == j && j < nout) mine = tot;
     }
     return mine;
@@ -817,7 +841,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 g = -2.f * d * invB;
             }
             dq[tid] = g;
-            for (int o = S8_ROWS / 2; o > 0; o >>= 1) sq += __shfl_down(sq, o, S8_ROWS);
+            sq = s8_rows_sum_to_lane0(sq);
             keep_g = g;
             keep_a = sq;
         }

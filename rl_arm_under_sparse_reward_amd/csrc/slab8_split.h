@@ -305,7 +305,7 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
                 g = -2.f * d * invB;
             }
             dq[tid] = g;
-            for (int o = S8_ROWS / 2; o > 0; o >>= 1) sq += __shfl_down(sq, o, S8_ROWS);
+            sq = s8_rows_sum_to_lane0(sq);
             keep_g = g;
             keep_a = sq;
         }
