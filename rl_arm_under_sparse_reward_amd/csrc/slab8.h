@@ -242,12 +242,19 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
     S8_WSTAMP(wtl, 16);
     if (kh == 0) {
         unsigned bits = mask_in ? (unsigned)mask_in[col] : 0u, outbits = 0u;
+        // the other half's partial sums are all asked for before the first output is written: pbuf and lout are both LDS pointers the
+        // compiler cannot tell apart, so a read behind a write waited for it -- S8_ROWS dependent LDS round trips per layer
+        float pv[4][S8_NRG];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < S8_NRG; ++g) pv[r][g] = pbuf[(4 * g + r) * 256 + col];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int g = 0; g < S8_NRG; ++g) {
                 const int row = 4 * g + r;
-                const float v = c[g][r] + pbuf[row * 256 + col];
+                const float v = c[g][r] + pv[r][g];
                 float o;
                 if (epi == SE_BIAS_RELU) {
                     o = fmaxf(v + e[0], 0.f);
@@ -622,12 +629,14 @@ __device__ __forceinline__ void s8_gather_ahead(const GatherSrc &G, float *XT, f
 
 __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
     const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;   // H == 256: a thread owns column c of rows r0, r0 + 2, ...
+    float h[S8_ROWS / 2], d[S8_ROWS / 2];   // every read before the first write (buf and dq_rows are both LDS: a read behind a write waits for it)
 #pragma unroll
     for (int i = 0; i < S8_ROWS / 2; ++i) {
-        const int r = r0 + 2 * i;
-        const float h = buf[r * S8_LD + c];
-        buf[r * S8_LD + c] = (h > 0.f) ? dq_rows[r] * w4c : 0.f;
+        h[i] = buf[(r0 + 2 * i) * S8_LD + c];
+        d[i] = dq_rows[r0 + 2 * i];
     }
+#pragma unroll
+    for (int i = 0; i < S8_ROWS / 2; ++i) buf[(r0 + 2 * i) * S8_LD + c] = (h[i] > 0.f) ? d[i] * w4c : 0.f;
 }
 
 // L2 warmer `widx` (of P.n_pref: a multiple of 8, the same number on every XCD) of this workgroup's XCD: touches the weight
