@@ -639,6 +639,19 @@ __device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float 
     for (int i = 0; i < S8_ROWS / 2; ++i) buf[(r0 + 2 * i) * S8_LD + c] = (h[i] > 0.f) ? d[i] * w4c : 0.f;
 }
 
+// the same with dq_rows[r] = (row0 + r < B) ? d_live : 0 (the actor loss: every live row's dQ is -1 / B)
+__device__ __forceinline__ void s8_head_bwd_inplace_rows(float d_live, int row0, int B, float w4c, float *buf) {
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+    float h[S8_ROWS / 2];
+#pragma unroll
+    for (int i = 0; i < S8_ROWS / 2; ++i) h[i] = buf[(r0 + 2 * i) * S8_LD + c];
+#pragma unroll
+    for (int i = 0; i < S8_ROWS / 2; ++i) {
+        const float d = (row0 + r0 + 2 * i < B) ? d_live : 0.f;
+        buf[(r0 + 2 * i) * S8_LD + c] = (h[i] > 0.f) ? d * w4c : 0.f;
+    }
+}
+
 // L2 warmer `widx` (of P.n_pref: a multiple of 8, the same number on every XCD) of this workgroup's XCD: touches the weight
 // fragments the XCD's chains will stream, in the order they use them, one dword per 128-byte line, so that the chains find them
 // in their L2 instead of behind the fabric
