@@ -116,11 +116,13 @@ struct PolicyArgs {
 #define S8_RING2 12   // ring depth of the 8-row build
 #endif
 #define S8_RING (S8_NRG >= 4 ? 10 : (S8_NRG == 1 ? S8_RING1 : S8_RING2))   // 16-row slabs need the LDS for their activation buffers
+#undef S8_BOTH_HALVES
+#define S8_BOTH_HALVES (S8_NRG >= 2)   // both reduction halves finish rows (s8_finish); 4-row slabs: the kh 0 waves finish all four
 #undef S8_RPW
 #define S8_RPW ((S8_ROWS + S8_WAVES - 1) / S8_WAVES)   // rows per wavefront in the one-wavefront-per-row stages
 namespace S8_NS {
 
-typedef unsigned short s8_mask_t;   // ReLU mask of one column: bit r = row r of the slab
+typedef unsigned short s8_mask_t;   // ReLU mask of one column: one byte per reduction half, bit i = the i-th row that half finishes (s8_finish)
 
 __device__ __forceinline__ void s8_sync() {   // barrier that leaves global loads / DMA in flight (__syncthreads() would also drain them: s_waitcnt vmcnt(0))
     __builtin_amdgcn_sched_barrier(0);
@@ -221,17 +223,70 @@ __device__ __forceinline__ void s8_ring_step(f32x4 (&c)[S8_NRG], RingSlot *ring,
     if constexpr (T + 1 < 32) s8_ring_step<T + 1, HAS_NEXT>(c, ring, rbase, wlayer, nxt, cg, b0, a, bnext);
 }
 
-// combine the two reduction halves and run the epilogue.  c0: this wave's partial [row][col = lane]
+// combine the two reduction halves and run the epilogue.  c: this wave's partial [row][col = lane]
 // gout (may be null): global [rows][256] copy of the output.
-// mask_out (SE_BIAS_RELU, may be null): LDS word per column, bit r = (output row r > 0) -- the ReLU mask the backward
-// stages of the SAME workgroup need (merged forward+backward kernel); mask_in (SE_MASK, may be null): use such a byte
-// instead of the 8 gate values in e[].
+// mask_out (SE_BIAS_RELU, may be null): LDS word per column = the ReLU mask the backward stages of the SAME workgroup need;
+// mask_in (SE_MASK, may be null): use such a word instead of the gate values in e[].
+// BOTH halves finish: the kh-th wave of a column group owns half of the slab's rows (row groups [kh NRG/2, (kh + 1) NRG/2); with
+// one row group its rows 2 kh, 2 kh + 1), hands the partial sums of the OTHER rows to its partner through pbuf and, behind the
+// barrier, adds the partner's sums to its own rows (kh 0: c + partner, kh 1: partner + c -- the same two addends, the sum is kh 0's
+// + kh 1's either way), applies the epilogue and writes them out.  Until round 5 the kh 0 waves did all of it while the kh 1 waves
+// waited: at 8 rows the layer's tail was 1.2 us (profiles/r05_ab_chain_small_levers.txt).  A mask word keeps one BYTE per half
+// (bit 8 kh + index of the row among the half's rows), so the two waves of a column write different bytes.
+template <int HH>
+__device__ __forceinline__ void s8_finish_half(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
+                                               int ld_out, const s8_mask_t *mask_in, s8_mask_t *mask_out, float *gout, int col,
+                                               unsigned long long *wtl) {
+    constexpr int NOWN = 2 * S8_NRG;                     // rows a half owns
+    auto own_g = [](int i) { return S8_NRG == 1 ? 0 : HH * (S8_NRG / 2) + i / 4; };        // i-th owned row -> row group, row in group
+    auto own_r = [](int i) { return S8_NRG == 1 ? 2 * HH + i : i % 4; };
+    auto oth_g = [](int i) { return S8_NRG == 1 ? 0 : (1 - HH) * (S8_NRG / 2) + i / 4; };
+    auto oth_r = [](int i) { return S8_NRG == 1 ? 2 * (1 - HH) + i : i % 4; };
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) pbuf[(4 * oth_g(i) + oth_r(i)) * 256 + col] = c[oth_g(i)][oth_r(i)];
+    s8_sync();
+    S8_WSTAMP(wtl, 16);
+    const unsigned bits = mask_in ? ((unsigned)mask_in[col] >> (8 * HH)) & 0xffu : 0u;
+    unsigned outbits = 0u;
+    // the partner's sums are all asked for before the first output is written: pbuf and lout are both LDS pointers the compiler
+    // cannot tell apart, so a read behind a write would wait for it
+    float pv[NOWN];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) pv[i] = pbuf[(4 * own_g(i) + own_r(i)) * 256 + col];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+        const int g = own_g(i), r = own_r(i), row = 4 * g + r;
+        const float v = HH == 0 ? c[g][r] + pv[i] : pv[i] + c[g][r];
+        float o;
+        if (epi == SE_BIAS_RELU) {
+            o = fmaxf(v + e[0], 0.f);
+            outbits |= (o > 0.f ? 1u : 0u) << i;
+        } else if (mask_in) {
+            o = ((bits >> i) & 1u) ? v : 0.f;
+        } else {
+            o = (e[row & 7] > 0.f) ? v : 0.f;
+        }
+        lout[row * ld_out + col] = o;
+        // global copy for the weight-gradient GEMM straight from the register (a wavefront writes 64
+        // consecutive floats of one row): no second pass over the LDS slab before the next layer can start
+        if (gout) wt_store(gout + (size_t)row * 256 + col, o);   // operand of the weight-gradient tiles
+    }
+    if (mask_out) reinterpret_cast<unsigned char *>(mask_out)[2 * col + HH] = (unsigned char)outbits;
+}
 __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, const float *e, float *pbuf, float *lout,
                                           int ld_out, const s8_mask_t *mask_in = nullptr,
                                           s8_mask_t *mask_out = nullptr, float *gout = nullptr,
                                           unsigned long long *wtl = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, cg = wave & 3, kh = wave >> 2;
     const int col = 64 * cg + lane;
+    static_assert(2 * S8_NRG <= 8 && sizeof(s8_mask_t) == 2, "a half's rows fit one byte of a mask word");
+#if S8_BOTH_HALVES
+    if (kh == 0) s8_finish_half<0>(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout, col, wtl);
+    else s8_finish_half<1>(c, epi, e, pbuf, lout, ld_out, mask_in, mask_out, gout, col, wtl);
+#else
+    // 4-row slabs: the kh 0 waves finish all four rows (measured with both halves finishing two each: 37.16 vs 37.13 us/update at batch
+    // 256, 45.03 vs 44.42 at 512 k8 -- the layer is bound by its weight transfers there and four more waves issuing stores only add to
+    // them; 8 rows: 51.9 vs 52.4 at batch 1024, 16 rows: 85.7 vs 88.8 at 2048)
     if (kh == 1) {
 #pragma unroll
         for (int g = 0; g < S8_NRG; ++g)
@@ -271,12 +326,13 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
             }
         if (mask_out) mask_out[col] = (s8_mask_t)outbits;
     }
+#endif
 }
 
-// epilogue operands of this wave's column (only the kh == 0 waves use them): bias, or the 8 gate values
+// epilogue operands of this wave's column (both reduction halves finish rows): bias, or the 8 gate values
 __device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float *__restrict__ aux, int ldaux) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = 64 * (wave & 3) + (threadIdx.x & 63);
-    if ((wave >> 2) != 0) return;
+    if (!S8_BOTH_HALVES && (wave >> 2) != 0) return;
     if (epi == SE_BIAS_RELU) {
         e[0] = aux[col];
     } else {
@@ -529,7 +585,7 @@ __device__ __forceinline__ void s8_trunk(const float *xin, const NetLayout &l, c
         eb3 = pre3[2];
     } else {
         const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col_ = 64 * (w_ & 3) + (threadIdx.x & 63);
-        if ((w_ >> 2) == 0) { eb2 = canon[l.b2 + col_]; eb3 = canon[l.b3 + col_]; }
+        if (S8_BOTH_HALVES || (w_ >> 2) == 0) { eb2 = canon[l.b2 + col_]; eb3 = canon[l.b3 + col_]; }
     }
     const float *pe2 = &eb2, *pe3 = &eb3;
     s8_small_layer(xin, S8_LDX, l.K1, wb1, SE_BIAS_RELU, canon + l.b1, 0, pbuf, bufA, S8_LD, nullptr, m1,
@@ -765,7 +821,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // with its weights, the rest behind the inputs -- a trunk's start then waits for nothing from global memory
         float ebT[3] = {0.f, 0.f, 0.f}, ebC[3] = {0.f, 0.f, 0.f}, ebA[3] = {0.f, 0.f, 0.f};
         const int ecol_ = 64 * (wave & 3) + lane;
-        const bool ekh0_ = wave < 4;
+        const bool ekh0_ = S8_BOTH_HALVES || wave < 4;   // (8- / 16-row slabs: both reduction halves run epilogues)
         if (ekh0_) ebT[0] = tn.canon[la.b1 + ecol_];
 #endif
         __builtin_amdgcn_sched_barrier(0);

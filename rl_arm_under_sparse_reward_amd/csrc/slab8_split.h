@@ -198,7 +198,7 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
         s8_small_prefetch(tn.wf + la.w1, la.K1, wbaT);
         float ebT[3] = {0.f, 0.f, 0.f}, ebC[3] = {0.f, 0.f, 0.f};
         const int ecol_ = 64 * (wave & 3) + lane;
-        const bool ekh0_ = wave < 4;
+        const bool ekh0_ = S8_BOTH_HALVES || wave < 4;   // (8- / 16-row slabs: both reduction halves run epilogues)
         if (ekh0_) ebT[0] = tn.canon[la.b1 + ecol_];
         __builtin_amdgcn_sched_barrier(0);
         s8_gather(xin, G, rec, 0, row0, A.ldx, A.act_off, ad, A.max_action, nullptr);
@@ -255,7 +255,7 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
         s8_small_prefetch(on.wf + ca + lc.w1, lc.K1, wbcA);
         float ebA[3] = {0.f, 0.f, 0.f};
         const int ecol_ = 64 * (wave & 3) + lane;
-        const bool ekh0_ = wave < 4;
+        const bool ekh0_ = S8_BOTH_HALVES || wave < 4;   // (8- / 16-row slabs: both reduction halves run epilogues)
         if (ekh0_) ebA[0] = on.canon[ca + lc.b1 + ecol_];
         __builtin_amdgcn_sched_barrier(0);
         if (A.gs.plan) {
