@@ -28,6 +28,7 @@
 #define GL_KC 256
 #define GL_ROWK_LD (GL_KC + 4)
 #define GL_KMAJ_LD 36
+#define GL_TS 36   // row length of a wave's partial 32 x 32 tile in the LDS (floats)
 #ifndef GL_RING_MIN_K
 #define GL_RING_MIN_K 64   // k-major x k-major reductions of at least this length take the per-wave ring path (gemm_tile)
 #endif
@@ -318,12 +319,14 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     }
     GL_STAMP(2);
     __syncthreads();  // operand images are dead: reuse the LDS for the partial tiles
-    float *my = lds + wave * (32 * 33);
+    // partial tiles in rows of GL_TS = 36 floats: a thread's 4 columns of a row are one aligned float4, so the reduction over the 8 waves
+    // is 8 LDS reads per thread instead of 32 (the count of reads in flight per wave is capped at 15: 32 went in three round trips)
+    float *my = lds + wave * (32 * GL_TS);
     const bool want_bias_grad = p.bias_grad != nullptr && tn == 0 && grp.bias0 == 0;   // (bias0 > 0: gemm_bias_tile does it)
     if (ring_path) {   // 32 x 32 accumulator layout: register r -> row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
         const int h = lane >> 5, l = lane & 31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) my[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + l] = cr[r];
+        for (int r = 0; r < 16; ++r) my[(8 * (r >> 2) + 4 * h + (r & 3)) * GL_TS + l] = cr[r];
         if (want_bias_grad) {
             asr = gl_fold32(asr);
             if (h == 0) bsum[wave][l] = asr;
@@ -332,10 +335,10 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * q + r;
-        my[row * 33 + i] = c00[r];
-        my[row * 33 + 16 + i] = c01[r];
-        my[(16 + row) * 33 + i] = c10[r];
-        my[(16 + row) * 33 + 16 + i] = c11[r];
+        my[row * GL_TS + i] = c00[r];
+        my[row * GL_TS + 16 + i] = c01[r];
+        my[(16 + row) * GL_TS + i] = c10[r];
+        my[(16 + row) * GL_TS + 16 + i] = c11[r];
     }
     }
     if (want_bias_grad && !ring_path) {
@@ -357,13 +360,12 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     }
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (etile) {
+        float4 pw[GL_WAVES];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = erow * 33 + ecol + j;
-            float s = 0.f;
+        for (int w = 0; w < GL_WAVES; ++w) pw[w] = *reinterpret_cast<const float4 *>(lds + w * (32 * GL_TS) + erow * GL_TS + ecol);
 #pragma unroll
-            for (int w = 0; w < GL_WAVES; ++w) s += lds[w * (32 * 33) + o];
-            v[j] = s;
+        for (int w = 0; w < GL_WAVES; ++w) {   // wave order, as before: s = ((0 + w0) + w1) + ...
+            v[0] += pw[w].x; v[1] += pw[w].y; v[2] += pw[w].z; v[3] += pw[w].w;
         }
     }
     if (ring_path && p.ks > 1) {
