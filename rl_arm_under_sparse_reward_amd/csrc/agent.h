@@ -51,6 +51,8 @@ struct GemmProb {
     int ks, part0;       // ks > 1: the reduction of every tile is split over ks workgroups (slice-major behind tile0) that meet
                          // through GemmGroup::part / ticket, entries part0 + tile (gemm_lds.h, ring path only)
     float max_action;    // EPI_BIAS_TANH
+    int frag_layer;      // weight gradients: layer 1-4 of the network C belongs to (its fragment copies' offsets follow from the tile's
+                         // coordinates, gemm_lds.h); 0 = unknown, look them up from the arena index
 };
 
 #define MAX_PROBS 8
@@ -380,8 +382,9 @@ static inline void add_dx(Launch &L, const float *dY, int ldy, int Nout, const f
 
 // dW = dY^T X, db = column sums of dY
 static inline void add_dw(Launch &L, const float *dY, int ldy, int Nout, const float *X, int ldx, int Kin, float *dW,
-                   float *db, int Mrows) {
+                   float *db, int Mrows, int layer = 0) {
     GemmProb &p = L.add(Nout, Kin, Mrows);
+    p.frag_layer = layer;
     p.A = dY; p.a_si = 1; p.a_sk = ldy;
     p.B = X; p.b_sj = 1; p.b_sk = ldx;
     p.C = dW; p.ldc = Kin;

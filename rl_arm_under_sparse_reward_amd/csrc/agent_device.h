@@ -5,6 +5,8 @@
 
 // canonical arena index -> (offset of the forward-fragment copy, offset of the dX-fragment copy); -1 for biases
 __host__ __device__ __forceinline__ void frag8_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
+__host__ __device__ __forceinline__ int frag8_fwd_index(int n, int k, int K);   // (slab8.h)
+__host__ __device__ __forceinline__ int frag8_dx_index(int n, int k, int N);
 __host__ __device__ __forceinline__ void frag32_offsets(const ArenaMap &am, int idx, int &off_f, int &off_d);
 
 __host__ __device__ __forceinline__ void frag_offsets_any(const ArenaMap &am, int idx, int &off_f, int &off_d) {
@@ -148,15 +150,25 @@ __device__ __forceinline__ void adam_fetch4(AdamState4 &S, const AdamFuse &F, in
     S.m = *reinterpret_cast<const float4 *>(F.m + idx0);
     S.v = *reinterpret_cast<const float4 *>(F.v + idx0);
 }
-__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S);
+#ifdef ADAM_TL   // (agent_engines.hip, time-line build): stamps of workgroup 0's optimizer step in g_gemm_tl[8..11] (timeline slots 168-171)
+extern __device__ unsigned long long g_gemm_tl[32];
+#define ADAM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_gemm_tl[8 + (k)] = wall_clock64(); } while (0)
+#else
+#define ADAM_STAMP(k) do { } while (0)
+#endif
+#define ADAM_FRAG_LOOKUP (-2)   // of_known: find the fragment offsets from the arena index (frag8_offsets: a walk over the layout + a division)
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S,
+                                            int of_known = ADAM_FRAG_LOOKUP, int od_known = -1);
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
     AdamState4 S;
     adam_fetch4(S, F, idx0);
     adam_apply4(F, idx0, g, S);
 }
-__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S) {
+__device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S, int of_known,
+                                            int od_known) {
     const float neg_step_size = S.neg_step_size;
     const float bc2_sqrt = S.bc2_sqrt;
+    ADAM_STAMP(0);
     const float4 p4 = S.p, m4 = S.m, v4 = S.v;
     float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -167,6 +179,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         const float denom = __fadd_rn(__fdiv_rn(sq, bc2_sqrt), F.eps);
         pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(neg_step_size, mm[j]), denom));
     }
+    ADAM_STAMP(1);
     // F.wt (small minibatches): write-through stores.  The optimizer leaves 5.6 MB dirty in the L2s, which the end of the kernel
     // has to write back before the next launch may start; written through while other workgroups still multiply, that tail is
     // gone: 40.7 -> 40.1 us/update at batch 256.  At batch 1024 / 4096 the launch is long enough to hide the write-back itself
@@ -181,6 +194,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
+    ADAM_STAMP(2);
     float tt[4] = {0.f, 0.f, 0.f, 0.f};
     if (F.tgt) {   // same expression as k_polyak_frag, on the parameters just stepped
         const float4 t4 = *reinterpret_cast<const float4 *>(F.tgt + idx0);
@@ -193,7 +207,8 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
         // slab8 / slab32 fragment orders: 4 consecutive reduction indices of one output row (idx0 % 4 == 0, every tensor's
         // row length is a multiple of 4) are ONE float4 of the forward copy and 4 dwords 16 B apart in the dX copy
         int of, od;
-        if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
+        if (F.am.mode == 1 && of_known != ADAM_FRAG_LOOKUP) { of = of_known; od = od_known; }   // (the caller knows its tensor: gemm_tile)
+        else if (F.am.mode == 1) frag8_offsets(F.am, idx0, of, od);
         else frag32_offsets(F.am, idx0, of, od);
         if (of >= 0) {
             if (F.wt) wt_store4(F.fragF + of, make_float4(pp[0], pp[1], pp[2], pp[3]));
@@ -217,6 +232,7 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
             if (of >= 0 && F.tgt) F.fragFT[of] = tt[j];
         }
     }
+    ADAM_STAMP(3);
 }
 
 // loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic)

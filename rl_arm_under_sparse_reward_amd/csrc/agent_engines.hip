@@ -9,6 +9,9 @@
 // is the number of dependent launches and the per-CU weight stream, not math.  Every product is fp32 MFMA (no TF32 on
 // gfx950; the 1e-5 loss parity needs fp32); all state is device resident and every kernel argument is constant across
 // updates, so a whole training cycle is one cached hipGraph (agent.hip).
+#ifdef SLAB_TIMELINE
+#define ADAM_TL 1
+#endif
 #include "agent_device.h"
 #include "gemm_lds.h"
 
@@ -399,21 +402,21 @@ Launch build_dw_group(const hp_agent *a, const float *sXA, const float *sXP, flo
     float *Ga = grads, *Gc = grads + la.total;
     Launch L;
     // the four 256 x 256 problems first: Launch::place_on_xcds gives each of them one pair of XCDs
-    add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
-    add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
-    add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
-    add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
+    add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp, 3);
+    add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp, 2);
+    add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp, 3);
+    add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp, 2);
     // the narrow problems (heads, first layers: 40 tiles at the reference shapes) follow as second workgroups on CUs that
     // already hold a 256 x 256 tile; with a long reduction their batch rows are split over ks workgroups each, so that no CU
     // carries two full tiles (gemm_lds.h)
     const int ks = (!a->dw64 && a->gl_part && a->dw_ksplit > 1 && Mp >= GL_RING_MIN_K) ? a->dw_ksplit : 1;   // ring path only
-    add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
+    add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp, 4);
     if (ks > 1) L.split_last(ks);
-    add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+    add_dw(L, a->dA1, H, H, sXA, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp, 1);
     if (ks > 1) L.split_last(ks);
-    add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
+    add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp, 4);
     if (ks > 1) L.split_last(ks);
-    add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+    add_dw(L, a->dK1, H, H, sXP, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp, 1);
     if (ks > 1) L.split_last(ks);
     L.g.part = a->gl_part;
     L.g.ticket = a->gl_ticket;
@@ -546,15 +549,15 @@ static Launch build_dw_half(const hp_agent *a, bool critic, const float *sX, flo
     Launch L;
     if (critic) {
         // in the order the critic chains publish the operands (slab8_split.h: stages 0, 0, 1, 2)
-        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp);
-        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp);
-        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp);
-        add_dw(L, a->dA1, H, H, sX, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp);
+        add_dw(L, a->dA3, H, H, a->CA.h2, H, H, Gc + lc.w3, Gc + lc.b3, Mp, 3);
+        add_dw(L, a->dQA, 16, 16, a->CA.h3, H, H, Gc + lc.w4, Gc + lc.b4, Mp, 4);
+        add_dw(L, a->dA2, H, H, a->CA.h1, H, H, Gc + lc.w2, Gc + lc.b2, Mp, 2);
+        add_dw(L, a->dA1, H, H, sX, ldx, lc.K1, Gc + lc.w1, Gc + lc.b1, Mp, 1);
     } else {
-        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp);
-        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp);
-        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp);
-        add_dw(L, a->dK1, H, H, sX, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp);
+        add_dw(L, a->dK3, H, H, a->AP.h2, H, H, Ga + la.w3, Ga + la.b3, Mp, 3);
+        add_dw(L, a->dK2, H, H, a->AP.h1, H, H, Ga + la.w2, Ga + la.b2, Mp, 2);
+        add_dw(L, a->dZ, 16, 16, a->AP.h3, H, H, Ga + la.w4, Ga + la.b4, Mp, 4);
+        add_dw(L, a->dK1, H, H, sX, ldx, la.K1, Ga + la.w1, Ga + la.b1, Mp, 1);
         // two 256 x 256 problems: four XCDs each (gemm_tile: placed2)
         if (L.g.p[0].tiles_n == 8 && L.g.p[0].M == 256 && L.g.p[1].tile0 == 64 && L.g.p[1].tiles_n == 8 && L.g.p[1].M == 256)
             L.g.xcd = 2;

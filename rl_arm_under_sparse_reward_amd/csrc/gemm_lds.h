@@ -526,8 +526,17 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
     }
     if (ADAM) {
         const int base = (int)(p.C - F->grads_base) + em * p.ldc + en;
+        GL_STAMP(7);
         if (adam_vec) {
-            adam_apply4(*F, base, v, ast);
+            // the fragment copies' offsets from the tile's own coordinates (row em, column en of layer frag_layer's weight matrix): the
+            // generic look-up walks the arena layout and divides by the row length, per thread, at the launch's very end
+            int of = ADAM_FRAG_LOOKUP, od = -1;
+            if (F->am.mode == 1 && p.frag_layer > 0) {
+                const int tw0 = (int)(p.C - F->grads_base);
+                of = p.frag_layer <= 3 ? tw0 + frag8_fwd_index(em, en, p.ldc) : -1;
+                od = p.frag_layer >= 2 ? tw0 + frag8_dx_index(em, en, p.M) : -1;
+            }
+            adam_apply4(*F, base, v, ast, of, od);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

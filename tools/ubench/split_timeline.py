@@ -72,6 +72,8 @@ tl = (C.c_uint64 * 192)(); _lib.check(lib.hp_agent_debug_timeline(h, tl))
 for ch, nm in ((0, "A chain slab 0"), (3, "A chain, first slab of the next XCD"), (1, "C chain slab 0"), (2, "T chain slab 0")):
     v = [tl[ch * 32 + k] for k in range(32)]
     if v[0]: print(f"[timeline {nm}]", " ".join(f"{k}:{(v[k]-v[0])/100:.1f}" for k in range(32) if v[k]))
+ad = [tl[168 + k] for k in range(4)]
+if all(ad): print('[actor tile launch, workgroup 0] optimizer step: entered 0.00, math done %.2f, p / m / v stored %.2f, end (fragment copies stored) %.2f us' % tuple((ad[k] - ad[0]) / 100 for k in (1, 2, 3)))
 # per-wave stamps of ONE 256 x 256 layer (the critic's first dX layer in the actor-side chain above; slab8.h: S8_WSTAMP)
 wv = [[tl[128 + 8 * k + w] for w in range(8)] for k in range(4)]
 if all(wv[0]):
@@ -93,7 +95,7 @@ try:
             if c: print(f"[{nm}] since the launch's first start: {kn:10s} {stat(c)}")
         slow = sorted(((wg[8 * b + 5] - b0) / 100, b) for b in sel if wg[8 * b + 5] and wg[8 * b])[-6:]
         print(f"[{nm}] last to end (us since first start, workgroup):", " ".join(f"{t:.2f}@{b}" for t, b in slow))
-        for k, kn in ((0, "start"), (1, "products done"), (3, "LDS sums ready"), (4, "gate + bias step done"), (5, "end")):
+        for k, kn in ((0, "start"), (1, "products done"), (3, "LDS sums ready"), (4, "gate + bias step done"), (7, "optimizer step entered"), (5, "end")):
             c = [(wg[8 * b + k] - wg[8 * b]) / 100 for b in sel if wg[8 * b + k] and wg[8 * b]]
             if c: print(f"[{nm}] since own start: {kn:22s} {stat(c)}")
         if nm.startswith("actor") and os.environ.get("TL_ROWS", "1") != "0":
