@@ -708,6 +708,32 @@ __device__ __forceinline__ void s8_head_bwd_inplace_rows(float d_live, int row0,
     }
 }
 
+// the same for the critic loss (ddpg_agent.py:255-263): every thread derives dL/dQ of its rows from the per-row scalars already in the LDS
+// (Q', Q, reward: written before the barrier in front of this stage) with the expression the loss block uses, instead of waiting behind
+// a barrier for that block to hand it over
+__device__ __forceinline__ void s8_head_bwd_inplace_td(const float (*rows)[S8_ROWS], int row0, int B, float gamma, float clip_ret,
+                                                       float invB, float w4c, float *buf) {
+    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
+    float h[S8_ROWS / 2], qt[S8_ROWS / 2], qa[S8_ROWS / 2], rw[S8_ROWS / 2];
+#pragma unroll
+    for (int i = 0; i < S8_ROWS / 2; ++i) {
+        const int r = r0 + 2 * i;
+        h[i] = buf[r * S8_LD + c];
+        qt[i] = rows[0][r]; qa[i] = rows[1][r]; rw[i] = rows[2][r];
+    }
+#pragma unroll
+    for (int i = 0; i < S8_ROWS / 2; ++i) {
+        float g = 0.f;
+        if (row0 + r0 + 2 * i < B) {
+            float y = rw[i] + gamma * qt[i];
+            y = fminf(fmaxf(y, -clip_ret), 0.f);
+            const float d = y - qa[i];
+            g = -2.f * d * invB;
+        }
+        buf[(r0 + 2 * i) * S8_LD + c] = (h[i] > 0.f) ? g * w4c : 0.f;
+    }
+}
+
 // L2 warmer `widx` (of P.n_pref: a multiple of 8, the same number on every XCD) of this workgroup's XCD: touches the weight
 // fragments the XCD's chains will stream, in the order they use them, one dword per 128-byte line, so that the chains find them
 // in their L2 instead of behind the fabric
@@ -918,13 +944,11 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 sq = d * d;
                 g = -2.f * d * invB;
             }
-            dq[tid] = g;
             sq = s8_rows_sum_to_lane0(sq);
             keep_g = g;
             keep_a = sq;
         }
-        s8_sync();
-        s8_head_bwd_inplace(dq, w4c, bufA);   // bufA holds h3 of critic(x, a)
+        s8_head_bwd_inplace_td(rows, (int)row0, Bk.B, Bk.gamma, Bk.clip_ret, invB, w4c, bufA);   // bufA holds h3 of critic(x, a)
         s8_sync();
         S8_TSTAMP(tl, 19);
         s8_store(bufA, S8_LD, H, Bk.dA3 + row0 * H, H);

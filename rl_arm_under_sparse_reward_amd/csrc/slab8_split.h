@@ -304,13 +304,11 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
                 sq = d * d;
                 g = -2.f * d * invB;
             }
-            dq[tid] = g;
             sq = s8_rows_sum_to_lane0(sq);
             keep_g = g;
             keep_a = sq;
         }
-        s8_sync();
-        s8_head_bwd_inplace(dq, w4c, bufA);   // bufA holds h3 of critic(x, a)
+        s8_head_bwd_inplace_td(rows, (int)row0, Bk.B, Bk.gamma, Bk.clip_ret, invB, w4c, bufA);   // bufA holds h3 of critic(x, a)
         s8_sync();
         S8_TSTAMP(tl, 19);
         s8_store(bufA, S8_LD, H, Bk.dA3 + row0 * H, H);
