@@ -683,19 +683,9 @@ __device__ __forceinline__ void s8_gather_ahead(const GatherSrc &G, float *XT, f
     }
 }
 
-__device__ __forceinline__ void s8_head_bwd_inplace(const float *dq_rows, float w4c, float *buf) {
-    const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;   // H == 256: a thread owns column c of rows r0, r0 + 2, ...
-    float h[S8_ROWS / 2], d[S8_ROWS / 2];   // every read before the first write (buf and dq_rows are both LDS: a read behind a write waits for it)
-#pragma unroll
-    for (int i = 0; i < S8_ROWS / 2; ++i) {
-        h[i] = buf[(r0 + 2 * i) * S8_LD + c];
-        d[i] = dq_rows[r0 + 2 * i];
-    }
-#pragma unroll
-    for (int i = 0; i < S8_ROWS / 2; ++i) buf[(r0 + 2 * i) * S8_LD + c] = (h[i] > 0.f) ? d[i] * w4c : 0.f;
-}
-
-// the same with dq_rows[r] = (row0 + r < B) ? d_live : 0 (the actor loss: every live row's dQ is -1 / B)
+// Backward step of a 1-wide head in place: buf[r][c] = relu'(h) * dQ[r] * w4[c] (H == 256: a thread owns column c of rows r0, r0 + 2, ...),
+// every LDS read before the first write (a read behind a write to an LDS pointer the compiler cannot tell apart waits for it).
+// Actor loss (ddpg_agent.py:265): dQ of a live row is d_live = -1 / B, known without a trip through the LDS
 __device__ __forceinline__ void s8_head_bwd_inplace_rows(float d_live, int row0, int B, float w4c, float *buf) {
     const int c = threadIdx.x & 255, r0 = threadIdx.x >> 8;
     float h[S8_ROWS / 2];
