@@ -317,7 +317,7 @@ __device__ __forceinline__ void s8_finish(const f32x4 (&c)[S8_NRG], int epi, con
                 } else if (mask_in) {
                     o = ((bits >> row) & 1u) ? v : 0.f;
                 } else {
-                    o = (e[row] > 0.f) ? v : 0.f;
+                    o = (e[row & 7] > 0.f) ? v : 0.f;
                 }
                 lout[row * ld_out + col] = o;
                 // global copy for the weight-gradient GEMM straight from the register (a wavefront writes 64
@@ -336,8 +336,9 @@ __device__ __forceinline__ void s8_epi_load(float (&e)[8], int epi, const float 
     if (epi == SE_BIAS_RELU) {
         e[0] = aux[col];
     } else {
+        // (gate values instead of a mask word: slabs of at most 8 rows; every caller in this engine passes masks)
 #pragma unroll
-        for (int r = 0; r < S8_ROWS; ++r) e[r] = aux[(size_t)r * ldaux + col];
+        for (int r = 0; r < (S8_ROWS < 8 ? S8_ROWS : 8); ++r) e[r] = aux[(size_t)r * ldaux + col];
     }
 }
 
