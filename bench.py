@@ -347,7 +347,7 @@ def first_cycle_or_fallback(a, rank, world, force_dp, shared):
         order = order[order.index(forced):]
     elif forced:
         order = [forced]
-    last = None
+    last, failures = None, []
     for mode in order:
         if mode != "auto" or forced:
             os.environ["RLARM_COMM"] = mode
@@ -367,9 +367,21 @@ def first_cycle_or_fallback(a, rank, world, force_dp, shared):
             import torch.distributed as dist
             t = torch.tensor([ok], dtype=torch.int32, device="cpu" if shared else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
-        if ok:
+            all_ok = int(t.item())
+        else:
+            all_ok = ok
+        if all_ok:
+            # what was tried and dropped on the way to the transport that ran (rank 0's view): a peer exchange the ranks refused
+            # at attach time (IPC mapping, self-check), transports whose first cycle failed
+            refused = getattr(r.agent.comm, "peer_refused", None)
+            r.fallbacks = failures + ([{"exchange": "peer-memory", "refused_at_attach": refused}] if refused else [])
             return r
+        failures.append({"exchange": mode, "first_cycle_error": str(last) if not ok else "failed on another rank"})
+        if r is not None:               # free the exchange memory / communicator of the transport that is being dropped
+            try:
+                r.agent.close_comm()
+            except Exception:           # noqa: BLE001
+                pass
         if world == 1:
             break
     raise RuntimeError(f"no exchange transport completed the first cycle: {last}")
@@ -399,12 +411,15 @@ def replicas_identical(r, world, shared):
     return all(bool(torch.equal(e, every[0])) for e in every)
 
 
-def time_exchange_alternatives(a, rank, world, shared, ran, n_cycles=10):
+def time_exchange_alternatives(a, rank, world, shared, ran, done, deadline, n_cycles=10):
     """N > 1 only, after the timed region (there may be exactly one multi-GPU run): a short timed pass on
     each exchange transport that did NOT carry the headline -- library-side RCCL inside the cycle graph (what north_star names),
     the peer-memory exchange in its other form(s), torch.distributed from a host loop -- with us/update and whether the replicas
-    stayed bit-identical.  Every step is agreed on by all ranks; a transport that fails is recorded with its error and the next
-    one is tried, the JSON line is printed whatever happens here."""
+    stayed bit-identical.  Every step is agreed on by all ranks BEFORE any collective kernel of the pass is enqueued; a transport
+    that fails is recorded with its error and the next one is tried.  `done` collects the records as they finish (the watchdog in
+    main() prints the line with whatever is there if a pass hangs), `deadline` (time.monotonic) is the time box of the whole
+    pass: every transport gets an equal share of what is left, its number of cycles is cut to fit (at eight ranks on ONE device a
+    pass read 11-22 ms per update), and what does not fit at all is recorded as skipped."""
     import torch
     import torch.distributed as dist
 
@@ -416,31 +431,64 @@ def time_exchange_alternatives(a, rank, world, shared, ran, n_cycles=10):
     plain = argparse.Namespace(**{**vars(a), "feeder_episodes": 0, "feeder_envs": 0})   # the passes time the exchange, not a feeder
     keys = sorted({k for _, env in plans for k in env})
     saved = {k: os.environ.get(k) for k in keys}
-    out = []
     dev = "cpu" if shared else "cuda"
-    for name, env in plans:
+
+    def agree_min(v, dtype=torch.int32):
+        t = torch.tensor([v], dtype=dtype, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item()
+
+    def agree_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for n_plan, (name, env) in enumerate(plans):
+        left = len(plans) - n_plan
+        share = agree_min((deadline - time.monotonic()) / left, torch.float64)     # every rank works with the same budget
+        rec = {"exchange": name, "env": env}
+        if share < 4.0:
+            rec["skipped"] = f"time box: {share:.1f} s left for this pass (RLARM_BENCH_ALT_BUDGET_S)"
+            done.append(rec)
+            continue
+        t_pass = time.monotonic()
         for k in keys:
             os.environ.pop(k, None)
         os.environ.update(env)
-        rec, ok, r2, err = {"exchange": name, "env": env}, 1, None, None
+        ok, r2, err = 1, None, None
         try:
             r2 = Runner(plain, rank, world, False)
             if os.environ.get("RLARM_BENCH_FAIL_ALT") and name.startswith(os.environ["RLARM_BENCH_FAIL_ALT"]) and rank == 0:
                 raise RuntimeError("injected failure (RLARM_BENCH_FAIL_ALT)")     # test hook: one rank's pass "fails"
-            r2.run_steps(2 * N_BATCHES)
-            r2.sync()
-            r2.agent.check_exchange()
         except Exception as e:      # noqa: BLE001 -- every rank must reach the agreement below
             ok, err = 0, str(e)
-        t = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 1:
+        # agreed BEFORE the first collective kernel of this pass: a rank that could not build its state must not leave the
+        # others inside an RCCL / torch.distributed collective that never completes
+        if int(agree_min(ok)) == 1:
+            try:
+                t0 = time.perf_counter()
+                r2.run_steps(2 * N_BATCHES)
+                r2.sync()
+                r2.agent.check_exchange()
+                warm = time.perf_counter() - t0
+            except Exception as e:  # noqa: BLE001
+                ok, err, warm = 0, str(e), 0.0
+        if int(agree_min(ok)) == 1:
             got, phases = exchange_name(r2.agent)
             rec["ran_as"] = got + (f", phases {phases}" if phases else "") + (", gate kernels (ranks share a device)" if r2.agent._peer is not None and r2.agent.comm.shared_device else "")
             try:
+                rec["kernels_per_update"] = r2.agent.engine().get("kernels_per_update")
+            except Exception:   # noqa: BLE001
+                pass
+            # cycles that fit this pass's share of the time box (the two warm cycles above say what a cycle costs here)
+            per_cycle = agree_max(warm / 2.0)
+            room = share - (time.monotonic() - t_pass) - 2.0
+            n_cyc = int(max(1, min(n_cycles, room / max(per_cycle, 1e-6))))
+            n_cyc = int(agree_min(n_cyc))
+            try:
                 barrier(world)
                 t0 = time.perf_counter()
-                r2.run_steps(n_cycles * N_BATCHES)
+                r2.run_steps(n_cyc * N_BATCHES)
                 r2.sync()
                 barrier(world)
                 dt = time.perf_counter() - t0
@@ -448,14 +496,10 @@ def time_exchange_alternatives(a, rank, world, shared, ran, n_cycles=10):
             except Exception as e:  # noqa: BLE001
                 ok, err = 0, str(e)
                 dt = float("nan")
-            t = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 1:
-                td = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(td, op=dist.ReduceOp.MAX)
-                dt = float(td.item())
-                rec.update(us_per_update=round(1e6 * dt / (n_cycles * N_BATCHES), 3),
-                           value=round(world * a.batch * n_cycles * N_BATCHES / dt, 1), steps=n_cycles * N_BATCHES,
+            if int(agree_min(ok)) == 1:
+                dt = agree_max(dt)
+                rec.update(us_per_update=round(1e6 * dt / (n_cyc * N_BATCHES), 3),
+                           value=round(world * a.batch * n_cyc * N_BATCHES / dt, 1), steps=n_cyc * N_BATCHES,
                            replicas_bit_identical=replicas_identical(r2, world, shared),
                            same_as_headline=(got, phases) == ran and "RLARM_PEER_TILES" not in env)
             else:
@@ -468,13 +512,13 @@ def time_exchange_alternatives(a, rank, world, shared, ran, n_cycles=10):
             except Exception:       # noqa: BLE001
                 pass
             del r2
-        out.append(rec)
+        done.append(rec)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
-    return out
+    return done
 
 
 def main():
@@ -596,6 +640,7 @@ def main():
                            "note": "same process, measured right after the timed region over whole cycles; `value` above is the "
                                    "contract's K-step figure"}
     losses = r.agent.last_losses(1)[0]
+    dp = world > 1 or force_dp
     # data-parallel replicas must hold the SAME networks bit for bit (same summed gradients, same Adam): every rank
     # fingerprints its online + target parameters and rank 0 reports whether all fingerprints agree
     replicas_same = None
@@ -616,276 +661,372 @@ def main():
             rk, wd = _C0.c_int32(), _C0.c_int32()
             r.agent.lib.hp_comm_info(r.agent._native_comm, _C0.byref(rk), _C0.byref(wd))
             devices["rccl_communicator_ranks"] = wd.value
-    prof = None
-    if rank == 0 and world == 1 and not a.no_profile:   # N=1 only: the eager profile pass would issue collectives alone
-        prof = profile_kernels(r)
-    if world > 1:
-        barrier(world)
+    # What ran, asked WHILE the transport that carried the timed region is still attached (VERDICT r05 Weak 3: asked after
+    # close_comm() the agent is single-rank again and names kernels a data-parallel rank never launches): the engine, the
+    # kernels of one update read off the library's own launch logic (hp_agent_update_kernels), the exchange.
+    eng = r.agent.engine()
+    ran = exchange_name(r.agent) if dp else None
     dp_native = r.agent._native_comm is not None
     dp_peer = r.agent._peer is not None
-    peer_phases = None
-    if dp_peer:
-        import ctypes as _C
-        _ph = _C.c_int32()
-        r.agent.lib.hp_peer_phases(r.agent._peer, _C.byref(_ph))
-        peer_phases = _ph.value
+    peer_phases = ran[1] if (dp and dp_peer) else None
     import ctypes as _C
     mode = _C.c_int32()
     r.agent.lib.hp_agent_cycle_mode(r.agent.h, _C.byref(mode))
     cycle_mode = {0: "none", 1: "hipGraph", 2: "eager launches"}.get(mode.value, str(mode.value))
-    alternatives = None
-    ran = exchange_name(r.agent) if (world > 1 or force_dp) else None
-    if world > 1 or force_dp:
-        r.agent.close_comm()
-    if world > 1 and os.environ.get("RLARM_BENCH_ALTERNATIVES", "1") != "0":
+    # live per-launch durations (HIP event pairs on the launch stream).  At N > 1 every rank runs the pass -- its launches
+    # exchange with the peers' -- and rank 0 reports its own figures.
+    prof = None
+    if not a.no_profile:
         try:
-            alternatives = time_exchange_alternatives(a, rank, world, shared, ran)
-        except Exception as e:      # noqa: BLE001 -- the headline line must survive anything that happens in the extra passes
-            alternatives = [{"error": f"alternatives pass aborted: {e}"}]
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    import ctypes as C
-    from rl_arm_under_sparse_reward_amd import _lib as _l
-    mhz = C.c_double()
-    _l.check(r.ctx.lib.hp_ctx_clock_mhz(r.ctx.h, C.byref(mhz)))      # shader clock right after the timed region
-    cal = (C.c_double * 4)()
-    try:
-        _l.check(r.ctx.lib.hp_ctx_calibrate(r.ctx.h, cal))
-        calibration = {"launch_floor_us": round(cal[0], 3), "lds_dma_GBps_per_cu": round(cal[1], 1),
-                       "mfma4x4_dependent_cycles": round(cal[2], 2), "shader_clock_mhz": round(cal[3]),
-                       "typical": CALIBRATION_TYPICAL}
-    except Exception as e:        # noqa: BLE001 -- a diagnostic must not cost the run its line
-        calibration = {"error": str(e)}
+            prof = profile_kernels(r)
+            r.agent.check_exchange()
+        except Exception as e:      # noqa: BLE001 -- a diagnostic pass must not cost the run its line
+            prof = None
+            print(f"[bench rank {rank}] profile pass failed: {e}", file=sys.stderr, flush=True)
+    if world > 1:
+        barrier(world)
     ms_per_step = 1e3 * dt / a.steps
     value = world * a.batch * a.steps / dt
-    out = {
-        "metric": baseline_metric_name(a),
-        "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "init": "untimed before the warm-up: one training cycle (cycle hipGraph capture / exchange set-up) and one rehearsal "
-                "of the warm-up + timed step pattern (partial-cycle graph captures), ending on a cycle boundary",
-        "cycle_boundaries_in_timed_region": boundaries,
-        **({"cycle_inclusive_estimate": cycle_inclusive} if cycle_inclusive else {}),
-        **({"host_feeder": feeder_stats} if feeder_stats else {}),
-        **({"exchange_alternatives": alternatives} if alternatives is not None else {}),
-        "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
-                               f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
-                               "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
-                   "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
-                   **({"feeder_episodes_per_cycle": a.feeder_episodes} if a.feeder_episodes else {}),
-                   "parallelism": f"dp{world}" + (
-                       " (grad SUM per update [reference semantics, utils.py:47] + normalizer MEAN per cycle: " +
-                       ("one-shot all-reduce over peer memory fused with Adam, inside the cycle graph)" if dp_peer else
-                        "RCCL all-reduce issued by the library inside the cycle graph)" if dp_native
-                        else "torch.distributed, host-driven loop)") if (world > 1 or force_dp) else ""),
-                   "exchange": ("peer-memory" if dp_peer else "rccl" if dp_native else "torch.distributed") if (world > 1 or force_dp) else None,
-                   "peer_exchange_form": {1: "one-shot (every rank reads every peer's whole gradient vector)",
-                                          2: "two-phase (reduce-scatter + all-gather over peer memory)"}.get(peer_phases),
-                   "cycle_mode": cycle_mode,
-                   "peer_gate_kernels": bool(r.agent.comm.shared_device) if dp_peer else None,
-                   "replicas_bit_identical": replicas_same,
-                   "devices": devices,
-                   "devices_shared_by_ranks": bool(shared) if world > 1 else None,
-                   "engine": r.agent.engine(),
-                   "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
-                   "final_losses": [float(losses[0]), float(losses[1])],
-                   "shader_clock_mhz_after_run": round(mhz.value)},
-        # ~200 us of probes that characterise THIS box (rlarm_hip_debug.h: hp_ctx_calibrate), taken right after the timed region:
-        # about one box in seven of the pool ran every kernel of this path ~1.4 x slower at the same shader clock -- with these
-        # three rates in the line a slow box can be told from a regression
-        "calibration": calibration,
-    }
-    if prof:
-        # ---- roofline of the matrix kernels.  Algorithmic MACs per transition (minimal algorithm):
-        # 5 forward passes 699,648 + backward dX chains 395,776 run in the chain kernel(s); weight gradients 287,488.
-        # Durations: n = 200 launches of ONE kernel as a captured hipGraph between ONE HIP event pair on the launch stream
-        # (hp_agent_debug_chain kinds 11 / 12): kernel time + one graph kernel boundary (~1.5 us) per launch, no event
-        # overhead inside.  rocprofv3 kernel durations of the same command (profiles/) are that minus the boundary.
-        ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
-        eng = r.agent.engine()
-        split = eng.get("launches_per_update", "").startswith("split")
-        chain_kernel = {"slab8": "k_fb_split8" if split else "k_fb_slab8", "slab32": "k_fb_slab32"}.get(eng["engine"], "k_gemm_group")
-        dw_kernel = "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam"
-        # weight-gradient MACs per transition by network (SURVEY 8d's 287,488 split by the layer shapes: critic 34*256 + 2*256*256 +
-        # 256, actor 30*256 + 2*256*256 + 4*256)
-        dw_critic = round(287_488 * 140_032 / 279_808)
-        dw_actor = 287_488 - dw_critic
-        if split:   # slab8_split.h: the chain launch also holds the critic's weight gradients + Adam; the launch behind it the actor's
-            kinds = {"chain": (None, 699_648 + 395_776 + dw_critic, chain_kernel), "weight_grad": (None, dw_actor, dw_kernel)}
-        else:
-            kinds = {"chain": (11, 699_648 + 395_776, chain_kernel), "weight_grad": (12, 287_488, dw_kernel)}
-        # HBM traffic needs rocprofv3 --pmc passes around the process (tools/gpu_round3.sh), so it cannot be measured from
-        # inside this run: it is read from the newest committed counter summary of this shape, which records a fingerprint of
-        # the kernel sources it was taken on -- when the sources have changed since, the figure is reported as stale
-        pmc, pmc_file, pmc_sha = {}, None, None
-        for cand in (f"r05_pmc_traffic_b{a.batch}.json", f"r04_pmc_traffic_b{a.batch}.json", f"r03_pmc_traffic_b{a.batch}.json",
-                     f"r02_pmc_traffic_b{a.batch}.json"):
-            path = os.path.join(REPO, "profiles", cand)
-            if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
-                with open(path) as fh:
-                    doc = json.load(fh)
-                pmc = {k: v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items()}
-                pmc_file, pmc_sha = "profiles/" + cand, doc.get("csrc_sha16")
-                break
-        sys.path.insert(0, os.path.join(REPO, "tools"))
+    out = None
+    if rank == 0:
+        import ctypes as C
+        from rl_arm_under_sparse_reward_amd import _lib as _l
+        mhz = C.c_double()
+        _l.check(r.ctx.lib.hp_ctx_clock_mhz(r.ctx.h, C.byref(mhz)))      # shader clock right after the timed region
+        cal = (C.c_double * 4)()
         try:
-            from pmc_summary import csrc_sha16
-            sha_now = csrc_sha16()
-        except Exception:                      # noqa: BLE001
-            sha_now = None
-        traffic_stale = (pmc_sha is None or sha_now is None or pmc_sha != sha_now) if pmc_file else None
-        # committed rocprofv3 summary of this same configuration (tools/gpu_round3.sh): cross-check for the live numbers
-        prof_file = os.path.join(REPO, "profiles", f"r05_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
-        for older in ("r04", "r03", "r02"):
-            if not os.path.exists(prof_file):
-                prof_file = os.path.join(REPO, "profiles", f"{older}_kernel_trace_b{a.batch}_k{a.replay_k}.txt")
-        prof_avg, prof_sha = {}, None
-        if os.path.exists(prof_file):
-            for line in open(prof_file):
-                if line.startswith("# csrc_sha16"):      # tools/trace_summary.py: fingerprint of the kernel sources it was taken on
-                    prof_sha = line.split()[2]
-                parts = line.split()
-                if len(parts) >= 6 and parts[0][0] != "#" and parts[-1].endswith("%"):
-                    try:
-                        prof_avg.setdefault(parts[0].split("(")[0].split("::")[-1], float(parts[-4]))   # "s8r4::k_fb_split8(s8r4::FbSplitArgs)" -> k_fb_split8
-                    except ValueError:
-                        pass
-        per = {}
-        for name, (kind, macs, kernel) in kinds.items():
-            us = C.c_double(float("nan"))
-            if kind is not None:
-                _l.check(r.agent.lib.hp_agent_debug_chain(r.agent.h, kind, 200, C.byref(us)))
-            ev = prof.get({"chain": "forward", "weight_grad": "weight_grad"}[name], {})
-            ev2 = prof.get("backward_dx", {}) if name == "chain" else {}
-            # live, in situ: one HIP event pair around each eager launch of the training loop on the launch stream, minus what
-            # an event pair with nothing in between reads on this stack
-            live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
-            if name == "chain":
-                rp = sum(v for k, v in prof_avg.items() if k == chain_kernel)
-            else:   # the ride-along variant runs on all but the last updates of a cycle
-                rp = (prof_avg.get("k_dw64_adam") or prof_avg.get("k_gemm_lds_adam_ride") or prof_avg.get("k_gemm_lds_adam_ride_u")
-                      or prof_avg.get("k_gemm_lds_adam") or prof_avg.get("k_gemm_lds_adam_u", 0.0))   # _u: scalar wave index (batch 257..640)
-            used = max(live, rp)
-            tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
-            per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "duration_source": "live" if live >= rp else "committed",
-                         "live_event_pair_minus_empty_us": round(live, 3),
-                         "rocprofv3_avg_us_committed": round(rp, 3) if rp else None,
-                         "graph_replay_warm_us": round(us.value, 3) if us.value == us.value else None, "flop_per_launch": 2.0 * macs * a.batch,
-                         "achieved_tflops": round(tf, 3), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5),
-                         # the counters of THE variant that runs on all but the last update of a cycle (the ride-along one where it exists);
-                         # round 3 summed the variants' per-launch figures here (34.5 + 36.3 MB at batch 1024 read as 70.8)
-                         "traffic_hbm_bytes_per_launch": next((pmc[k] for k in sorted(pmc, key=len, reverse=True)
-                                                               if kernel in k), None)}
-        dom = max(per, key=lambda k: per[k]["avg_launch_us"])
-        out["roofline"] = {
-            "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
-            "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
-            "traffic_source": pmc_file, "traffic_stale": traffic_stale,
-            "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB per launch from separate rocprofv3 --pmc passes of this "
-                            "shape; traffic_stale = the kernel sources differ from the ones the counters were taken on "
-                            f"(csrc fingerprint then {pmc_sha}, now {sha_now})",
-            "flop_per_launch": per[dom]["flop_per_launch"],
-            "avg_launch_us": per[dom]["avg_launch_us"],
-            # which of the two durations decided `frac` in THIS run, and whether the committed file still describes these kernels
-            # (same fingerprint of the kernel sources as the PMC file's; a file without one reads as stale)
-            "duration_source": per[dom]["duration_source"],
-            "duration_stale": (prof_sha is None or sha_now is None or prof_sha != sha_now) if os.path.exists(prof_file) else None,
-            "duration_note": f"committed summary: profiles/{os.path.basename(prof_file)} (csrc fingerprint then {prof_sha}, now {sha_now}); "
-                             "with duration_source == 'committed' and duration_stale the fraction rests on an outdated file -- the live "
-                             "figure beside it is this run's",
-            "duration_method": "avg_launch_us = the LARGER of (a) live_event_pair_minus_empty_us: one HIP event pair around each "
-                               "eager launch of the training loop on the launch stream, minus event_pair_empty_us (what a pair with "
-                               "nothing in between reads), and (b) rocprofv3_avg_us_committed: the kernel's average in the "
-                               "committed rocprofv3 --kernel-trace --stats summary of this configuration "
-                               f"(profiles/{os.path.basename(prof_file)}).  graph_replay_warm_us = 200 back-to-back launches of the "
-                               "kernel alone as a hipGraph between one event pair (warm caches, no spare workgroups): a lower bound",
-            "event_pair_empty_us": round(ev_floor_us, 3),
-            "whole_update_tflops": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12, 3),
-            "whole_update_frac": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
-            "engine": eng,
-            "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup (4-row slabs on "
-                    "v_mfma_f32_4x4x1 up to batch 512, 8-row up to 1024, 16-row up to 2048; 32-row slabs on v_mfma_f32_32x32x2 "
-                    "beyond).  At batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at "
-                    "~2.4 us against 2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight "
-                    "stream, not by the matrix pipes.  At batch 4096 every CU streams the weights at the ~30 GB/s per CU the L2s "
-                    "deliver to 256 CUs at once (MI355X_MICROARCH.md ldsdma-fill): 16 flop per streamed byte caps the 32-row "
-                    "engine at ~70 % of the MFMA peak (DESIGN.md 3.1, 3.3)",
-            "all_matrix_kernels": per,
+            _l.check(r.ctx.lib.hp_ctx_calibrate(r.ctx.h, cal))
+            calibration = {"launch_floor_us": round(cal[0], 3), "lds_dma_GBps_per_cu": round(cal[1], 1),
+                           "mfma4x4_dependent_cycles": round(cal[2], 2), "shader_clock_mhz": round(cal[3]),
+                           "typical": CALIBRATION_TYPICAL}
+        except Exception as e:        # noqa: BLE001 -- a diagnostic must not cost the run its line
+            calibration = {"error": str(e)}
+        out = {
+            "metric": baseline_metric_name(a),
+            "value": round(value, 1), "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "init": "untimed before the warm-up: one training cycle (cycle hipGraph capture / exchange set-up) and one rehearsal "
+                    "of the warm-up + timed step pattern (partial-cycle graph captures), ending on a cycle boundary",
+            "cycle_boundaries_in_timed_region": boundaries,
+            **({"cycle_inclusive_estimate": cycle_inclusive} if cycle_inclusive else {}),
+            **({"host_feeder": feeder_stats} if feeder_stats else {}),
+            "config": {"workload": f"push task (obs 27, goal 3, action 4, T 100), buffer {a.episodes * 100} transitions "
+                                   f"({a.episodes} episodes) per GPU, batch {a.batch} per GPU, replay_k {a.replay_k}, "
+                                   "HIP HER sampler + FP32-MFMA DDPG update, 40 updates + store/normalizer/polyak per cycle",
+                       "global_batch": world * a.batch, "episodes_per_gpu": a.episodes,
+                       **({"feeder_episodes_per_cycle": a.feeder_episodes} if a.feeder_episodes else {}),
+                       "parallelism": f"dp{world}" + (
+                           " (grad SUM per update [reference semantics, utils.py:47] + normalizer MEAN per cycle: " +
+                           ("all-reduce over peer memory fused with Adam, inside the cycle graph)" if dp_peer else
+                            "RCCL all-reduce issued by the library inside the cycle graph)" if dp_native
+                            else "torch.distributed, host-driven loop)") if dp else ""),
+                       "exchange": ("peer-memory" if dp_peer else "rccl" if dp_native else "torch.distributed") if dp else None,
+                       "exchange_fallbacks": getattr(r, "fallbacks", None) or None,
+                       "peer_exchange_form": {1: "one-shot (every rank reads every peer's whole gradient vector)",
+                                              2: "two-phase (reduce-scatter + all-gather over peer memory)"}.get(peer_phases),
+                       "cycle_mode": cycle_mode,
+                       "peer_gate_kernels": bool(r.agent.comm.shared_device) if dp_peer else None,
+                       "replicas_bit_identical": replicas_same,
+                       "devices": devices,
+                       "devices_shared_by_ranks": bool(shared) if world > 1 else None,
+                       "engine": eng,
+                       "sampler_rng": "MT19937 numpy-legacy stream on device (bit-exact indices)",
+                       "final_losses": [float(losses[0]), float(losses[1])],
+                       "shader_clock_mhz_after_run": round(mhz.value)},
+            # ~200 us of probes that characterise THIS box (rlarm_hip_debug.h: hp_ctx_calibrate), taken right after the timed region:
+            # about one box in seven of the pool ran every kernel of this path ~1.4 x slower at the same shader clock -- with these
+            # three rates in the line a slow box can be told from a regression
+            "calibration": calibration,
         }
-        # the HBM-bound half of the path.  In the update loop the gather is fused into k_fb_slab8; the
-        # standalone sampler (replay_buffer.sample: k_draw_plan + k_gather_dict in the reference's float64 dict layout)
-        # is timed on its own, after the timed region (it advances the sampler stream)
-        dus, gus = C.c_double(), C.c_double()
-        buf = r.agent.buffer._dev
-        _l.check(r.ctx.lib.hp_buffer_sample_device_us(buf.h, r.rng.h, a.batch, float(r.agent.her_module.future_p),
-                                                      float(r.agent.her_module.sq_threshold), 200, C.byref(dus), C.byref(gus)))
-        row_doubles = 2 * 27 + 3 * 3 + 4
-        bytes_per_tr = row_doubles * 8 + 16 + row_doubles * 8 + 4      # rows read + plan record, dict rows + reward written
-        s_gbps = bytes_per_tr * a.batch / (gus.value * 1e-6) / 1e9
-        out["roofline_sample_kernel"] = {
-            "bound": "hbm", "kernel": "k_gather_dict (gather + relabel + reward, float64 dict layout)",
-            "achieved": round(s_gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(s_gbps / HBM_PEAK_GBPS, 6),
-            "avg_launch_us": round(gus.value, 3), "bytes_per_transition": bytes_per_tr, "traffic": None,
-            "index_draw_kernel_us": round(dus.value, 3),
-            "note": "256 random 0.5 KB rows of a 150 MB buffer per launch: two dependent memory latencies, nowhere near a "
-                    "bandwidth bound; averages over 200 back-to-back launches between one HIP event pair"}
-        # ... and the device-output fused sampler (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32
-        # x, x', a, r in device memory), SURVEY 8d's 528 B / transition kernel.  This build stores float64 rows, so what one launch
-        # actually moves is 67 x 8 B read + a 16 B index record + 65 x 4 B written = 812 B per transition; both figures are given.
-        # At the bench batch the launch is two dependent memory latencies; the large-batch figure shows the kernel against the roof.
-        fd, fg = C.c_double(), C.c_double()
-        fused = {}
-        for nb, reps in ((a.batch, 200), (1 << 18, 20)):
-            _l.check(r.ctx.lib.hp_buffer_sample_dev_us(buf.h, r.rng.h, r.agent.o_norm.h, r.agent.g_norm.h, nb,
-                                                       float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, reps,
-                                                       C.byref(fd), C.byref(fg)))
-            fused[nb] = {"batch": nb, "avg_launch_us": round(fg.value, 3), "index_draw_kernel_us": round(fd.value, 3),
-                         "achieved_GBps_528B": round(528 * nb / (fg.value * 1e-6) / 1e9, 2),
-                         "achieved_GBps_812B_this_build": round(812 * nb / (fg.value * 1e-6) / 1e9, 2),
-                         "transitions_per_s_kernel_only": round(nb / (fg.value * 1e-6), 1)}
-        big = fused[1 << 18]
-        out["roofline_sample_kernel_fused"] = {
-            "bound": "hbm", "kernel": "k_gather_fused (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 device tensors)",
-            "achieved": big["achieved_GBps_528B"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(big["achieved_GBps_528B"] / HBM_PEAK_GBPS, 5),
-            "bytes_per_transition": 528, "bytes_per_transition_this_build": 812,
-            "achieved_this_build_bytes": big["achieved_GBps_812B_this_build"],
-            "frac_this_build_bytes": round(big["achieved_GBps_812B_this_build"] / HBM_PEAK_GBPS, 5),
-            "avg_launch_us": big["avg_launch_us"], "batch": 1 << 18, "traffic": None,
-            "at_bench_batch": fused[a.batch],
-            "note": "achieved = SURVEY 8d's algorithmic 528 B / transition (float32 storage) x 2^18 transitions / the kernel's average "
-                    "launch time; this build keeps float64 rows (bit-identical rewards and inputs), so the bytes it really moves are "
-                    "812 B / transition (the *_this_build figures).  Random 432-byte row pairs out of a 150 MB shard: the shard is "
-                    "Infinity-Cache resident.  At the bench batch one launch is two dependent memory latencies"}
-        out["kernel_time_us_per_step_event_bracketed"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
-    if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
-        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        # the port timed next to the imported reference where both can run (the build container,
-        # tools/cpu_ratio.py) -- the factor that turns "x the port" into "x the reference CPU path"
-        ratio_file = os.path.join(REPO, "profiles", "r03_cpu_port_over_reference.json")
-        if os.path.exists(ratio_file):
-            with open(ratio_file) as fh:
-                rdoc = json.load(fh)
-            out["cpu_baseline"]["port_over_reference"] = rdoc["port_over_reference"]
-            out["cpu_baseline"]["port_over_reference_source"] = (
-                "profiles/r03_cpu_port_over_reference.json (tools/cpu_ratio.py on the build container: "
-                f"{rdoc.get('host_cpu', '?')}, by threads {({k: v['port_over_reference'] for k, v in rdoc['by_threads'].items()})})")
-            out["speedup_vs_reference_cpu_estimate"] = round(out["speedup_vs_cpu_baseline"] * rdoc["port_over_reference_min"], 1)
-    if world > 1 or force_dp:
-        dist.destroy_process_group()
-    # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER Python's output at exit:
-    # drain it first so that the JSON record is the last line on stdout
-    try:
-        import ctypes
+        if prof:
+            out.update(roofline_fields(a, r, eng, prof, ms_per_step, world, dp, ran))
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a, a.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+            # the port timed next to the imported reference where both can run (the build container,
+            # tools/cpu_ratio.py) -- the factor that turns "x the port" into "x the reference CPU path"
+            ratio_file = os.path.join(REPO, "profiles", "r03_cpu_port_over_reference.json")
+            if os.path.exists(ratio_file):
+                with open(ratio_file) as fh:
+                    rdoc = json.load(fh)
+                out["cpu_baseline"]["port_over_reference"] = rdoc["port_over_reference"]
+                out["cpu_baseline"]["port_over_reference_source"] = (
+                    "profiles/r03_cpu_port_over_reference.json (tools/cpu_ratio.py on the build container: "
+                    f"{rdoc.get('host_cpu', '?')}, by threads {({k: v['port_over_reference'] for k, v in rdoc['by_threads'].items()})})")
+                out["speedup_vs_reference_cpu_estimate"] = round(out["speedup_vs_cpu_baseline"] * rdoc["port_over_reference_min"], 1)
 
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    print(json.dumps(out), flush=True)
+    def emit(record):
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER Python's output at exit:
+        # drain it first so that the JSON record is the last line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(json.dumps(record), flush=True)
+
+    if dp:
+        r.agent.close_comm()
+    if world > 1 and os.environ.get("RLARM_BENCH_ALTERNATIVES", "1") != "0":
+        # The headline record is COMPLETE at this point.  The extra passes run against a time box, under a watchdog: if one of
+        # them hangs (a rank died inside a collective) the watchdog prints the line with the passes that finished and
+        # ends the process with status 0 -- on every rank, rank 0 first -- instead of losing what may be the only multi-GPU run.
+        import threading
+        budget = float(os.environ.get("RLARM_BENCH_ALT_BUDGET_S", "150"))
+        finished = []
+        printed = threading.Lock()
+
+        def watchdog():
+            if not printed.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["exchange_alternatives"] = list(finished) + [
+                    {"error": f"alternatives pass stopped by the watchdog {budget + 30:.0f} s after it began: a pass did not return "
+                              "(the records above are the passes that finished)"}]
+                emit(out)
+            os._exit(0)
+
+        timer = threading.Timer(budget + 30 + (0 if rank == 0 else 5), watchdog)
+        timer.daemon = True
+        timer.start()
+        try:
+            time_exchange_alternatives(a, rank, world, shared, ran, finished, time.monotonic() + budget)
+            alternatives = list(finished)
+        except Exception as e:      # noqa: BLE001 -- the headline line must survive anything that happens in the extra passes
+            alternatives = list(finished) + [{"error": f"alternatives pass aborted: {e}"}]
+        if not printed.acquire(blocking=False):     # the watchdog is printing: leave the exit to it
+            time.sleep(60)
+        timer.cancel()
+        if rank == 0:
+            out["exchange_alternatives"] = alternatives
+    if dp:
+        try:
+            dist.destroy_process_group()
+        except Exception:           # noqa: BLE001
+            pass
+    if rank == 0:
+        emit(out)
+
+
+def short_kernel(name):
+    """'void s8r4::k_fb_split8<0>(unsigned long long, ...)' / 's8r4::k_fb_split8(unsigned' -> 'k_fb_split8<0>' / 'k_fb_split8'
+    (tools/trace_summary.py prints this form; summaries committed before round 6 carry the long one)."""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("(")[0].split("::")[-1]
+
+
+def committed_kernel_averages(path):
+    """{short kernel name: avg_us}, csrc fingerprint of a committed tools/trace_summary.py file (prologue rows aside)."""
+    avg, sha = {}, None
+    if not os.path.exists(path):
+        return avg, sha
+    for line in open(path):
+        if line.startswith("# csrc_sha16"):
+            sha = line.split()[2]
+        cols = line.rstrip().rsplit(None, 5)
+        if len(cols) == 6 and not line.startswith("#") and cols[-1].endswith("%") and "[prologue" not in cols[0]:
+            try:
+                avg.setdefault(short_kernel(cols[0]), float(cols[2]))
+            except ValueError:
+                pass
+    return avg, sha
+
+
+def roofline_fields(a, r, eng, prof, ms_per_step, world, dp, ran):
+    """`roofline` (+ the sampler's two lines at N = 1) of the bench record.  The kernels are the ones the library's launch logic
+    names for THIS agent with its transport attached (eng["kernels_per_update"]); durations are this run's HIP event pairs, held
+    against the committed rocprofv3 summary of the same configuration where one exists."""
+    import ctypes as C
+
+    from rl_arm_under_sparse_reward_amd import _lib as _l
+    out = {}
+    # Algorithmic MACs per transition (SURVEY.md section 8d, minimal algorithm): 5 forward passes 699,648 + backward dX chains
+    # 395,776 run in the chain kernel(s); weight gradients 287,488 (critic 34*256 + 2*256*256 + 256, actor 30*256 + 2*256*256 + 4*256)
+    ev_floor_us = prof.pop("_event_pair_empty_us", 0.0)
+    kp = eng.get("kernels_per_update") or []
+    fallback_chain = {"slab8": "k_fb_slab8", "slab32": "k_fb_slab32"}.get(eng["engine"], "k_gemm_lds")
+    chain_kernel = kp[0] if kp else fallback_chain
+    dw_kernel = next((k for k in kp[1:] if k.startswith(("k_gemm_lds", "k_dw64"))),
+                     "k_dw64_adam" if eng["weight_grad"].startswith("dw64") else "k_gemm_lds_adam")
+    split = chain_kernel.startswith("k_fb_split8")
+    dw_critic = round(287_488 * 140_032 / 279_808)
+    dw_actor = 287_488 - dw_critic
+    single = not dp
+    if split:   # slab8_split.h: the chain launch also holds the critic's weight gradients (+ exchange + Adam); the launch behind it the actor's
+        kinds = {"chain": (None, 699_648 + 395_776 + dw_critic, chain_kernel), "weight_grad": (None, dw_actor, dw_kernel)}
+    else:
+        kinds = {"chain": (11 if single else None, 699_648 + 395_776, chain_kernel), "weight_grad": (12 if single else None, 287_488, dw_kernel)}
+    # HBM traffic needs rocprofv3 --pmc passes around the process (tools/gpu_round6.sh), so it cannot be measured from
+    # inside this run: it is read from the newest committed counter summary of this shape, which records a fingerprint of
+    # the kernel sources it was taken on -- when the sources have changed since, the figure is reported as stale
+    tag = "" if single else "_forced_dp_" + ("peer" if ran and ran[0] == "peer-memory" else "rccl" if ran and ran[0] == "rccl" else "torch")
+    pmc, pmc_file, pmc_sha = {}, None, None
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
+        cand = f"{rnd}_pmc_traffic_b{a.batch}{tag}.json"
+        path = os.path.join(REPO, "profiles", cand)
+        if os.path.exists(path) and os.environ.get("RLARM_ENGINE") is None and os.environ.get("RLARM_SLAB_ROWS") is None:
+            with open(path) as fh:
+                doc = json.load(fh)
+            pmc = {short_kernel(k): v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if "[prologue" not in k}
+            pmc_file, pmc_sha = "profiles/" + cand, doc.get("csrc_sha16")
+            break
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    try:
+        from pmc_summary import csrc_sha16
+        sha_now = csrc_sha16()
+    except Exception:                      # noqa: BLE001
+        sha_now = None
+    traffic_stale = (pmc_sha is None or sha_now is None or pmc_sha != sha_now) if pmc_file else None
+    # committed rocprofv3 summary of this same configuration (tools/gpu_round6.sh): cross-check for the live numbers.  A real
+    # multi-GPU run (world > 1) has no committed trace: its durations are this run's event pairs alone.
+    prof_file = None
+    if world == 1:
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
+            cand = os.path.join(REPO, "profiles", f"{rnd}_kernel_trace_b{a.batch}_k{a.replay_k}{tag}.txt")
+            if os.path.exists(cand):
+                prof_file = cand
+                break
+    prof_avg, prof_sha = committed_kernel_averages(prof_file) if prof_file else ({}, None)
+
+    def committed(kernel):     # summaries from before round 6 name the (then untemplated) split kernel without its <form>
+        return prof_avg.get(kernel) or prof_avg.get(kernel.split("<")[0]) or 0.0
+
+    def traffic_of(kernel):
+        return pmc.get(kernel) or pmc.get(kernel.split("<")[0])
+
+    per = {}
+    for name, (kind, macs, kernel) in kinds.items():
+        us = C.c_double(float("nan"))
+        if kind is not None:
+            _l.check(r.agent.lib.hp_agent_debug_chain(r.agent.h, kind, 200, C.byref(us)))
+        ev = prof.get({"chain": "forward", "weight_grad": "weight_grad"}[name], {})
+        ev2 = prof.get("backward_dx", {}) if name == "chain" else {}
+        # live, in situ: one HIP event pair around each eager launch of the training loop on the launch stream, minus what
+        # an event pair with nothing in between reads on this stack
+        live = ev.get("avg_us", 0.0) - ev_floor_us + (ev2.get("avg_us", 0.0) - ev_floor_us if ev2.get("avg_us") else 0.0)
+        rp = committed(kernel)
+        if name == "weight_grad" and not rp:   # the ride-along variant runs on all but the last updates of a cycle
+            rp = next((committed(k) for k in (kernel + "_ride", kernel.replace("_u", "") + "_ride_u") if committed(k)), 0.0)
+        used = max(live, rp)
+        tf = 2.0 * macs * a.batch / (used * 1e-6) / 1e12 if used > 0 else 0.0
+        per[name] = {"kernel": kernel, "avg_launch_us": round(used, 3), "duration_source": "live" if live >= rp else "committed",
+                     "live_event_pair_minus_empty_us": round(live, 3),
+                     "rocprofv3_avg_us_committed": round(rp, 3) if rp else None,
+                     "graph_replay_warm_us": round(us.value, 3) if us.value == us.value else None, "flop_per_launch": 2.0 * macs * a.batch,
+                     "achieved_tflops": round(tf, 3), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5),
+                     "traffic_hbm_bytes_per_launch": traffic_of(kernel)}
+    dom = max(per, key=lambda k: per[k]["avg_launch_us"])
+    pf = os.path.basename(prof_file) if prof_file else None
+    out["roofline"] = {
+        "bound": "mfma", "kernel": per[dom]["kernel"], "achieved": per[dom]["achieved_tflops"],
+        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per[dom]["frac"],
+        "traffic": per[dom]["traffic_hbm_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
+        "traffic_source": pmc_file, "traffic_stale": traffic_stale,
+        "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB per launch from separate rocprofv3 --pmc passes of this "
+                        "shape; traffic_stale = the kernel sources differ from the ones the counters were taken on "
+                        f"(csrc fingerprint then {pmc_sha}, now {sha_now})",
+        "flop_per_launch": per[dom]["flop_per_launch"],
+        "avg_launch_us": per[dom]["avg_launch_us"],
+        # which of the two durations decided `frac` in THIS run, and whether the committed file still describes these kernels
+        # (same fingerprint of the kernel sources as the PMC file's; a file without one reads as stale)
+        "duration_source": per[dom]["duration_source"],
+        "duration_stale": (prof_sha is None or sha_now is None or prof_sha != sha_now) if prof_file else None,
+        "duration_note": (f"committed summary: profiles/{pf} (csrc fingerprint then {prof_sha}, now {sha_now}); "
+                          "with duration_source == 'committed' and duration_stale the fraction rests on an outdated file -- the live "
+                          "figure beside it is this run's") if prof_file else
+                         "no committed rocprofv3 summary of this configuration: the durations are this run's event pairs",
+        "duration_method": "avg_launch_us = the LARGER of (a) live_event_pair_minus_empty_us: one HIP event pair around each "
+                           "eager launch of the training loop on the launch stream, minus event_pair_empty_us (what a pair with "
+                           "nothing in between reads), and (b) rocprofv3_avg_us_committed: the kernel's average in the "
+                           "committed rocprofv3 --kernel-trace --stats summary of this configuration"
+                           + (f" (profiles/{pf})" if pf else " (none)") +
+                           ".  graph_replay_warm_us = 200 back-to-back launches of the kernel alone as a hipGraph between one "
+                           "event pair (warm caches, no spare workgroups; single-rank two-launch form only): a lower bound",
+        "event_pair_empty_us": round(ev_floor_us, 3),
+        "whole_update_tflops": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12, 3),
+        "whole_update_frac": round(FLOP_PER_TRANSITION * a.batch / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
+        "kernels_per_update": kp,
+        "engine": eng,
+        "note": "dominant kernel by time: forward AND backward (dX) of a row slab in one workgroup (4-row slabs on "
+                "v_mfma_f32_4x4x1 up to batch 512, 8-row up to 1024, 16-row up to 2048; 32-row slabs on v_mfma_f32_32x32x2 "
+                "beyond).  At batch 256: 128 chain workgroups on 256 CUs, 16 dependent layers each, 8 of them 256x256 at "
+                "~2.4 us against 2.0 us of LDS-DMA weight streaming per CU: a latency chain bound by the per-CU weight "
+                "stream, not by the matrix pipes.  At batch 4096 every CU streams the weights at the ~30 GB/s per CU the L2s "
+                "deliver to 256 CUs at once (MI355X_MICROARCH.md ldsdma-fill): 16 flop per streamed byte caps the 32-row "
+                "engine at ~70 % of the MFMA peak (DESIGN.md 3.1, 3.3)",
+        "all_matrix_kernels": per,
+    }
+    out["kernel_time_us_per_step_event_bracketed"] = {k: round(1e3 * v["ms_per_step"], 3) for k, v in prof.items()}
+    if world > 1:
+        return out
+    # the HBM-bound half of the path (SURVEY 8d-i).  In the update loop the gather is fused into the chain kernels; the
+    # standalone sampler (replay_buffer.sample: k_draw_plan + k_gather_dict in the reference's float64 dict layout)
+    # is timed on its own, after the timed region (it advances the sampler stream)
+    dus, gus = C.c_double(), C.c_double()
+    buf = r.agent.buffer._dev
+    _l.check(r.ctx.lib.hp_buffer_sample_device_us(buf.h, r.rng.h, a.batch, float(r.agent.her_module.future_p),
+                                                  float(r.agent.her_module.sq_threshold), 200, C.byref(dus), C.byref(gus)))
+    row_doubles = 2 * 27 + 3 * 3 + 4
+    bytes_per_tr = row_doubles * 8 + 16 + row_doubles * 8 + 4      # rows read + plan record, dict rows + reward written
+    s_gbps = bytes_per_tr * a.batch / (gus.value * 1e-6) / 1e9
+    out["roofline_sample_kernel"] = {
+        "bound": "hbm", "kernel": "k_gather_dict (gather + relabel + reward, float64 dict layout)",
+        "achieved": round(s_gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(s_gbps / HBM_PEAK_GBPS, 6),
+        "avg_launch_us": round(gus.value, 3), "bytes_per_transition": bytes_per_tr, "traffic": None,
+        "index_draw_kernel_us": round(dus.value, 3),
+        "note": "256 random 0.5 KB rows of a 150 MB buffer per launch: two dependent memory latencies, nowhere near a "
+                "bandwidth bound; averages over 200 back-to-back launches between one HIP event pair"}
+    out["roofline_sample_kernel_fused"] = sample_kernel_fused_fields(a, r)
+    return out
+
+
+def sample_kernel_fused_fields(a, r):
+    """The device-output fused sampler (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 x, x', a, r
+    in device memory), SURVEY 8d's 528 B / transition kernel.  This build stores float64 rows, so what one launch actually moves
+    is 67 x 8 B read + a 16 B index record + 65 x 4 B written = 812 B per transition; both figures are given.  At the bench
+    batch the launch is two dependent memory latencies; the large-batch figure shows the kernel against the roof."""
+    import ctypes as C
+
+    from rl_arm_under_sparse_reward_amd import _lib as _l
+    buf = r.agent.buffer._dev
+    fd, fg = C.c_double(), C.c_double()
+    fused = {}
+    for nb, reps in ((a.batch, 200), (1 << 18, 20)):
+        _l.check(r.ctx.lib.hp_buffer_sample_dev_us(buf.h, r.rng.h, r.agent.o_norm.h, r.agent.g_norm.h, nb,
+                                                   float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, reps,
+                                                   C.byref(fd), C.byref(fg)))
+        fused[nb] = {"batch": nb, "avg_launch_us": round(fg.value, 3), "index_draw_kernel_us": round(fd.value, 3),
+                     "achieved_GBps_528B": round(528 * nb / (fg.value * 1e-6) / 1e9, 2),
+                     "achieved_GBps_812B_this_build": round(812 * nb / (fg.value * 1e-6) / 1e9, 2),
+                     "transitions_per_s_kernel_only": round(nb / (fg.value * 1e-6), 1)}
+    big = fused[1 << 18]
+    # PMC traffic of the kernel (separate rocprofv3 --pmc passes, tools/gpu_round6.sh): the committed summary of the 2^18 launch
+    traffic, tsrc = None, None
+    for rnd in ("r06",):
+        path = os.path.join(REPO, "profiles", f"{rnd}_pmc_traffic_sample_fused.json")
+        if os.path.exists(path):
+            with open(path) as fh:
+                doc = json.load(fh)
+            for k, v in doc.get("kernels", {}).items():
+                if short_kernel(k).startswith("k_gather_fused") and v.get("batch") == (1 << 18):
+                    traffic, tsrc = v["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
+    return {
+        "bound": "hbm", "kernel": "k_gather_fused (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 device tensors)",
+        "achieved": big["achieved_GBps_528B"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(big["achieved_GBps_528B"] / HBM_PEAK_GBPS, 5),
+        "bytes_per_transition": 528, "bytes_per_transition_this_build": 812,
+        "achieved_this_build_bytes": big["achieved_GBps_812B_this_build"],
+        "frac_this_build_bytes": round(big["achieved_GBps_812B_this_build"] / HBM_PEAK_GBPS, 5),
+        "avg_launch_us": big["avg_launch_us"], "batch": 1 << 18, "traffic": traffic, "traffic_source": tsrc,
+        "at_bench_batch": fused[a.batch],
+        "note": "achieved = SURVEY 8d's algorithmic 528 B / transition (float32 storage) x 2^18 transitions / the kernel's average "
+                "launch time; this build keeps float64 rows (bit-identical rewards and inputs), so the bytes it really moves are "
+                "812 B / transition (the *_this_build figures).  Random 432-byte row pairs out of this run's shard "
+                f"({a.episodes} episodes = {a.episodes * 29840 / 1e6:.0f} MB of float64 rows: Infinity-Cache resident below 256 MB; "
+                "profiles/r06_sample_kernel_shard_sweep.txt has the figure on a larger one).  At the bench batch one launch is "
+                "two dependent memory latencies"}
 
 
 if __name__ == "__main__":

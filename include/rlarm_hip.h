@@ -38,9 +38,10 @@ extern "C" {
 /* Version of the STABLE surface declared in this header.  2 (round 4): the diagnostic / test-hook entry points moved to
  * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
  * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  3 (round 5): hp_buffer_sample_dev (device-output fused
- * sampler) was added.  hp_abi_version() returns the library's value; a host
- * must refuse a library whose version differs from the header it was built against. */
-#define HP_ABI_VERSION 3
+ * sampler) was added.  4 (round 6): hp_ctx_get_stream was added (a host that hands device outputs to a framework orders the
+ * framework's stream with the context's through events instead of rebinding the context).  hp_abi_version() returns the
+ * library's value; a host must refuse a library whose version differs from the header it was built against. */
+#define HP_ABI_VERSION 4
 
 typedef enum {
     HP_OK = 0,
@@ -68,6 +69,8 @@ int hp_ctx_create(int device_id, hp_ctx **out);
  * with a framework that uses it) pass hipStreamLegacy, i.e. (void *)1.  A change of stream keeps the context's work in
  * order: the new stream waits (on the device, not the host) for what the context enqueued on the old one. */
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
+/* the stream the context enqueues on right now (its own one unless hp_ctx_set_stream changed it) */
+int hp_ctx_get_stream(hp_ctx *ctx, void **hip_stream);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
 int hp_ctx_pci_bus_id(hp_ctx *ctx, char *buf, size_t len);      /* "0000:05:00.0"; len >= 16 */

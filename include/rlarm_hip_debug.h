@@ -42,6 +42,14 @@ int hp_agent_set_adam(hp_agent *ag, int32_t net, const float *m_host, const floa
  * hipGraph (kind: 6 optimizer kernel, 8 polyak, 10 forward + backward of the active engine, 11 its chain kernel only,
  * 12 its weight-gradient launch + optimizer only) -- the per-stage numbers quoted in DESIGN.md / bench.py */
 int hp_agent_debug_chain(hp_agent *ag, int32_t kind, int32_t n, double *us_per_launch);
+/* diagnostic: the kernels a sequence of n_updates sampled updates (hp_agent_sample_and_update) enqueues on this agent as it is
+ * now -- engine, RLARM_* switches, attached communicator / peer exchange --, read off the launch logic itself (it runs under a
+ * stream capture that is discarded: nothing executes).  out = comma-separated names in launch order with markers "#open",
+ * "#prologue", "#update" (one per update), "#close"; "rccl:ncclAllReduce" stands for RCCL's own kernel.  caller_exchanges != 0:
+ * the host-driven form instead (hp_agent_forward_backward, the caller's all-reduce -- "host:all_reduce" --, hp_agent_apply), one
+ * update.  bench.py's `config.engine.kernels_per_update` and the kernel its roofline names come from here. */
+int hp_agent_update_kernels(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, hp_rng *rng, double future_p,
+                            double sq_threshold, int32_t n_updates, int32_t caller_exchanges, char *out, int32_t out_len);
 /* diagnostic: stage-boundary time stamps (100 MHz ticks) of the slab kernels; only a build with
  * -DSLAB_TIMELINE writes them (tools/ubench/), a production build returns zeros */
 int hp_agent_debug_timeline(hp_agent *ag, uint64_t *out192);

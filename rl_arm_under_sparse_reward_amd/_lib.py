@@ -45,12 +45,12 @@ class AgentCfg(C.Structure):
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
 
 
-ABI_VERSION = 3     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
+ABI_VERSION = 4     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
 
 # entry points declared in include/rlarm_hip_debug.h: diagnostics and test hooks, outside the stable surface
 DEBUG_SYMBOLS = {"hp_ctx_launch_floor", "hp_ctx_event_pair_us", "hp_ctx_clock_mhz", "hp_ctx_calibrate", "hp_buffer_sample_device_us",
                  "hp_buffer_sample_dev_us",
-                 "hp_agent_set_adam", "hp_agent_debug_chain", "hp_agent_debug_timeline"}
+                 "hp_agent_set_adam", "hp_agent_debug_chain", "hp_agent_debug_timeline", "hp_agent_update_kernels"}
 
 # name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h and include/rlarm_hip_debug.h
 PROTOTYPES = {
@@ -58,6 +58,7 @@ PROTOTYPES = {
     "hp_last_error": (C.c_char_p, []),
     "hp_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
     "hp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_ctx_get_stream": (C.c_int, [C.c_void_p, c_void_pp]),
     "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "hp_ctx_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -154,6 +155,8 @@ PROTOTYPES = {
                                               C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_uint64)]),
     "hp_agent_debug_chain": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f64p]),
     "hp_agent_debug_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "hp_agent_update_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                          C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
     "hp_agent_engine": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hp_agent_status": (C.c_int, [C.c_void_p, u32p]),
     "hp_agent_update_form": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
@@ -266,6 +269,11 @@ def load(path: str | None = None):
         return _lib
 
 
+def last_error(lib=None):
+    """hp_last_error() of the calling thread as text (for records of failures that are handled, not raised)."""
+    return ((lib or load()).hp_last_error() or b"").decode("utf-8", "replace")
+
+
 def check(status: int):
     """Translate an hp_status into the exception the reference would raise at the same spot."""
     if status == 0:
@@ -319,15 +327,38 @@ class Context:
         # legacy default stream explicitly (hipStreamLegacy == 1), or the two sides would run unordered
         self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream or 1)
 
-    def on_torch_stream(self):
-        """Bind the context to torch's current stream unless it already is (device outputs handed to torch, e.g.
-        replay_buffer.sample_device, must be written on the stream torch consumes them on)."""
+    def torch_bridge(self):
+        """Order ONE library call that writes torch-owned device memory with torch's current stream WITHOUT rebinding the
+        context (a rebind to torch's default stream = hipStreamLegacy costs a host synchronisation per hop and takes the cached
+        graphs of the fused learner off the table while it lasts): `with ctx.torch_bridge() as note: ...; note(tensors)` --
+        on entry the context's stream waits for what torch enqueued so far (its allocator may have handed out memory whose last
+        use is still in flight there), on exit torch's stream waits for what the call enqueued, and the tensors passed to
+        `note` are recorded on the context's stream for torch's caching allocator.  A context that already runs on torch's
+        current stream needs none of it."""
+        import contextlib
+
         import torch
 
-        want = torch.cuda.current_stream(self.device_id).cuda_stream or 1
-        if getattr(self, "_bound_stream", None) != want:
-            torch.cuda.set_device(self.device_id)
-            self.set_stream(want)
+        @contextlib.contextmanager
+        def bridge():
+            cur = torch.cuda.current_stream(self.device_id)
+            mine = C.c_void_p()
+            check(self.lib.hp_ctx_get_stream(self.h, C.byref(mine)))
+            m, c = (mine.value or 0), (cur.cuda_stream or 1)     # torch's default stream (handle 0) is hipStreamLegacy (1)
+            kept = []
+            if m == c:                                         # already on torch's stream (e.g. use_torch_stream): plain stream order
+                yield kept.extend
+                return
+            if m <= 2:
+                raise HpError("the context is bound to a special stream handle that is not torch's current stream: call "
+                              "Context.set_stream(None) first")
+            lib_stream = torch.cuda.ExternalStream(mine.value, device=torch.device("cuda", self.device_id))
+            lib_stream.wait_stream(cur)
+            yield kept.extend
+            cur.wait_stream(lib_stream)
+            for t in kept:
+                t.record_stream(lib_stream)
+        return bridge()
 
     def synchronize(self):
         check(self.lib.hp_ctx_synchronize(self.h))

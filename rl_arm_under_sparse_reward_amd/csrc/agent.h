@@ -233,6 +233,7 @@ struct hp_agent {
     // chain launch.  RLARM_SPLIT: unset = where it fits and the sequence has at least SPLIT_MIN_UPDATES updates, 0 = never,
     // 1 = wherever it fits (single updates too: parity tests)
     int split_mode = -1;                 // RLARM_SPLIT=0|1: never / also for short sequences (default: from SPLIT_MIN_UPDATES updates)
+    unsigned *split_reset_pending = nullptr;   // a split launch whose tiles wrote gradients only went out: the next optimizer launch clears its counter set
     unsigned *k1_sync = nullptr;         // device: hand-off counters of the split launch, then the sticky fault word (SPLIT_FAULT)
     unsigned *fault_host = nullptr;      // pinned + mapped mirror of the fault word (agent_check_fault), and its device address
     unsigned *fault_host_dev = nullptr;

@@ -85,6 +85,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // split form (slab8_split.h): target chains one update ahead, the critic's weight gradients + optimizer step inside the chain
     // launch.  Needs the chain kernel's own look-ahead (plans two updates ahead, gather workgroups) and the fused optimizer.
     const bool split = ride && ahead && !dw_ride && update_takes_split_form(a, n_updates);
+    HP_KLOG("#open");
     {
         ProfScope ps(a, PROF_PLAN);
         const int first = ride ? (n_updates < lead ? n_updates : lead) : n_updates;
@@ -105,10 +106,12 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     // 20-step form, and an intermittent optimizer mismatch in the teacher-forced test that the prologue form never showed;
     // removed.
     if (split) {
+        HP_KLOG("#prologue");
         GatherCtx g0{b, on, gn, a->plan.as<PlanRec>(), sq};
         HP_TRY(enqueue_split_prologue(a, &g0));
     }
     for (int u = 0; u < n_updates; ++u) {
+        HP_KLOG("#update");
         GatherCtx gc{b, on, gn, a->plan.as<PlanRec>() + (size_t)u * a->B, sq};
         gc.split = split;
         gc.qset = u & 1;
@@ -155,6 +158,7 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
             if (!fused) HP_TRY(enqueue_adam(a, last_fold));
         }
     }
+    HP_KLOG("#close");
     if (with_adam && a->peer) HP_TRY(peer_enqueue_seq_end(a->peer, n_updates));
     return HP_OK;
 }
@@ -737,8 +741,9 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
     const bool same = a->graph && a->g_buf == b && a->g_on == on && a->g_gn == gn && a->g_rng == rng &&
                       a->g_n_new == n_new && a->g_n_batches == n_batches && a->g_future_p == future_p &&
                       a->g_sq == sq_threshold && a->g_stage == b->st_obs.p && a->g_slots == b->st_slots.p && a->g_open == open;
-    if (s == hipStreamLegacy) a->graph_refused = true;   // the legacy default stream cannot be captured: eager launches
-    if (a->graph_refused) {   // see below
+    // the legacy default stream cannot be captured: eager launches for THIS call only (the context may be back on a capturable
+    // stream at the next one; only a refused capture with collectives, below, is sticky)
+    if (a->graph_refused || s == hipStreamLegacy) {
         HP_TRY(ensure_plan(a, n_batches));
         HP_TRY(a->norm_plan.ensure((size_t)b->T * sizeof(PlanRec)));
         HP_TRY(enqueue_cycle_tail(a, b, on, gn, rng, future_p, sq_threshold, n_batches, a->norm_plan.as<PlanRec>(), open));
@@ -798,6 +803,47 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
 int hp_agent_update_form(hp_agent *a, int32_t n_updates, int32_t *form) {
     HP_REQUIRE(a && form, HP_ERR_INVALID, "hp_agent_update_form: null argument");
     *form = update_takes_split_form(a, n_updates) ? 1 : 0;
+    return HP_OK;
+}
+
+// The kernels a sequence of n_updates sampled updates enqueues on this agent AS IT IS NOW (engine, switches, attached communicator
+// or peer exchange): the launch logic itself runs under a stream capture that is thrown away -- nothing executes, no state moves
+// -- with the launch log on.  out: "#open,k..,#prologue,k..,#update,k..,k..,#update,...,#close,k.." (markers start with '#';
+// "rccl:ncclAllReduce" stands for RCCL's own kernel).  What bench.py names in its line, instead of re-deriving the choice.
+// caller_exchanges != 0: the host-driven form (hp_agent_forward_backward -> the caller's all-reduce -> hp_agent_apply), one update.
+int hp_agent_update_kernels(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rng *rng, double future_p, double sq_threshold,
+                            int32_t n_updates, int32_t caller_exchanges, char *out, int32_t out_len) {
+    HP_TRY(check_handles(a, b, on, gn, rng, "hp_agent_update_kernels"));
+    HP_SERIALISE(a);
+    HP_REQUIRE(out && out_len > 0 && n_updates > 0, HP_ERR_INVALID, "hp_agent_update_kernels: bad argument");
+    HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_update_kernels: not in profiling mode (its launches are bracketed by events)");
+    hipStream_t s = a->ctx->stream;
+    HP_REQUIRE(s != hipStreamLegacy, HP_ERR_STATE, "hp_agent_update_kernels: the legacy default stream cannot be captured");
+    HP_TRY(ensure_plan(a, n_updates));
+    HP_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<std::string> log;
+    hipGraph_t graph = nullptr;
+    unsigned *pending = a->split_reset_pending;
+    HP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hp_klog = &log;
+    int st;
+    if (caller_exchanges) {
+        st = enqueue_updates(a, b, on, gn, rng, future_p, sq_threshold, 1, false);
+        HP_KLOG("host:all_reduce");
+        if (st == HP_OK) st = enqueue_adam(a);
+    } else {
+        st = enqueue_updates(a, b, on, gn, rng, future_p, sq_threshold, n_updates, true);
+    }
+    hp_klog = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    a->split_reset_pending = pending;
+    if (e != hipSuccess) (void)hipGetLastError();   // (a capture with collectives may be refused: the log is complete all the same)
+    if (st != HP_OK) return st;
+    std::string j;
+    for (size_t i = 0; i < log.size(); ++i) j += (i ? "," : "") + log[i];
+    HP_REQUIRE((int)j.size() + 1 <= out_len, HP_ERR_INVALID, "hp_agent_update_kernels: %zu bytes needed", j.size() + 1);
+    memcpy(out, j.c_str(), j.size() + 1);
     return HP_OK;
 }
 

@@ -235,6 +235,14 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
     ADAM_STAMP(3);
 }
 
+// optimizer kernels that follow a split launch whose tiles left the step to them (SPLIT_TILES_GRADS): block 0, threads 64 .. 127 clear
+// the counter set that launch counted in, as the actor's tile launch does in the fused forms (gemm_lds.h)
+__device__ __forceinline__ void split_reset_by_block0(const AdamFuse &F) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && F.reset_sync && tid >= 64 && tid < 64 + SPLIT_COUNTERS * 8)
+        __hip_atomic_store(F.reset_sync + (tid - 64) * SPLIT_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // loss means from the per-slab partial sums: one wavefront, fixed reduction tree (deterministic)
 __device__ __forceinline__ void loss_finalize(const AdamFuse &F) {
     const int lane = threadIdx.x;

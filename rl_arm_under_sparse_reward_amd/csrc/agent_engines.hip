@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFu
     if (blockIdx.x == 0) peer_signal(D, D.flags_g, epoch);
     if (!peer_wait(D, D.flags_g[D.rank], epoch)) return;   // dead exchange: no step from a partial sum (peer.h)
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    split_reset_by_block0(F);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void k_peer_adam2(const PeerDev D, const AdamF
     if (blockIdx.x == 0) peer_signal(D, D.flags_r, epoch);
     if (!peer_wait(D, D.flags_r[D.rank], epoch, 3u)) return;
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    split_reset_by_block0(F);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
     const int owner = t / peer_slice_len(D, n4);
@@ -63,9 +65,11 @@ static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, 
     if (p->phases == 2) {
         HP_TRY(peer_enqueue_reduce_slice(p, n4, u, mean));
         HP_TRY(peer_enqueue_gate(p, 3, u));
+        HP_KLOG("k_peer_adam2");
         hipLaunchKernelGGL(k_peer_adam2, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u);
     } else {
         HP_TRY(peer_enqueue_gate(p, 1, u));
+        HP_KLOG("k_peer_adam");
         hipLaunchKernelGGL(k_peer_adam, dim3((n4 + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, F, n4, u, mean ? 1 : 0);
     }
     HP_CHECK_HIP(hipGetLastError());
@@ -173,15 +177,21 @@ __global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_ride_u(unsigned lo
 // data-parallel ranks, tile-wise one-shot exchange (gemm_lds.h PEER): weight gradients + rank exchange + optimizer step in ONE
 // launch, the riders behind the tiles as above.  Replaces k_gemm_lds -> k_peer_adam (its kernel boundary, its second pass over
 // the gradients: +6 us per update at world size 1), and lets early tiles exchange while later ones still multiply.
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer(const GemmGroup grp, const AdamFuse F, const RideArgs R, int tiles,
-                                                                   const PeerDev D, int u, int mean) {
-    const PeerTile PT{&D, u, mean};
-    gemm_ride_body<true, false, true>(grp, &F, R, tiles, &PT);
+// row0: first flag row of this launch's tiles (0; the actor's tile launch behind a split launch: the critic's tile count)
+// t03 / t47: the tile -> problem table as leading scalars (preloaded with the wave, gemm_lds.h TileHead), as in k_gemm_lds_adam
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
+                                                                   const AdamFuse F, const RideArgs R, int tiles, const PeerDev D, int u,
+                                                                   int mean, int row0) {
+    const TileHead TH{t03, t47};
+    const PeerTile PT{&D, u, mean, row0};
+    gemm_ride_body<true, false, true>(grp, &F, R, tiles, &PT, &TH);
 }
-__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer_u(const GemmGroup grp, const AdamFuse F, const RideArgs R, int tiles,
-                                                                     const PeerDev D, int u, int mean) {
-    const PeerTile PT{&D, u, mean};
-    gemm_ride_body<true, true, true>(grp, &F, R, tiles, &PT);
+__global__ __launch_bounds__(GL_THREADS) void k_gemm_lds_adam_peer_u(unsigned long long t03, unsigned long long t47, const GemmGroup grp,
+                                                                     const AdamFuse F, const RideArgs R, int tiles, const PeerDev D, int u,
+                                                                     int mean, int row0) {
+    const TileHead TH{t03, t47};
+    const PeerTile PT{&D, u, mean, row0};
+    gemm_ride_body<true, true, true>(grp, &F, R, tiles, &PT, &TH);
 }
 
 // Large minibatches: 64 x 64 tiles with the batch rows split over workgroups (dw64.h), same riders behind the tiles
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(256) void k_gather_fused(const double *__restrict__
 __global__ __launch_bounds__(256) void k_adam_frag(const AdamFuse F, const float *__restrict__ g, int n) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    split_reset_by_block0(F);
     if (idx >= n) return;
     adam_apply(F, idx, g[idx]);
 }
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(256) void k_adam_frag(const AdamFuse F, const float
 __global__ __launch_bounds__(256) void k_adam_frag4(const AdamFuse F, const float *__restrict__ g, int n4) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
+    split_reset_by_block0(F);
     if (t >= n4) return;
     const float4 g4 = *reinterpret_cast<const float4 *>(g + 4 * t);
     const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -354,6 +366,7 @@ __global__ void k_unpack_actions(const float *__restrict__ X, int rows, int ld, 
 // ------------------------------------------------------------------------------- host side
 int launch_group(hp_agent *a, const Launch &L, int which) {
     ProfScope ps(a, which);
+    HP_KLOG(L.g.uni ? "k_gemm_lds_u" : "k_gemm_lds");
     hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_u : k_gemm_lds, dim3(L.tiles), dim3(GL_THREADS), 0, a->ctx->stream, L.g);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -362,6 +375,7 @@ int launch_group(hp_agent *a, const Launch &L, int which) {
 int enqueue_gather(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, const PlanRec *plan, double sq, int xset,
                    hipStream_t stream) {
     ProfScope ps(a, PROF_SAMPLE);
+    HP_KLOG("k_gather_fused");
     hipLaunchKernelGGL(k_gather_fused, dim3((a->B + 3) / 4), dim3(256), 0, stream ? stream : a->ctx->stream, b->d_obs, b->d_ag,
                        b->d_g, b->d_act, plan, a->B, (int)b->T, (int)b->obs_dim, (int)b->goal_dim, (int)b->act_dim, sq, on->d,
                        gn->d, a->cfg.clip_obs, a->cfg.clip_range, (float)a->cfg.max_action, a->ldx, a->act_off,
@@ -462,8 +476,15 @@ bool split_fits_rows(const hp_agent *a, int rows) {
     const int per_xcd = a->ctx->cu_count / 8, nslab = a->Mp / rows;
     return 3 * ((nslab + 7) / 8) + 1 <= per_xcd;
 }
+// Data-parallel ranks take the split launch too (round 6): with the tile-wise peer exchange the critic's in-launch tiles exchange
+// and step by themselves (SPLIT_TILES_PEER), with any other transport -- RCCL, the two-phase or gated peer forms, a caller that
+// exchanges itself -- they leave the gradients to the exchange + optimizer launches that follow (SPLIT_TILES_GRADS).
+// Not when ranks SHARE a device (rehearsals on a 1-GPU box; hp_peer_set_gate is how the library is told): the in-launch waits of
+// one rank's tiles for its own chains assume that the launch is resident as a whole, and eight ranks' launches on one device are
+// not (measured: the bounded hand-off of an 8-rank rehearsal gave up, fault word 0x11) -- those keep the two-launch form.
 bool split_fits(const hp_agent *a) {
-    if (!a->slab8 || a->dw64 || !a->fuse_adam_ok || a->comm || a->peer) return false;
+    if (!a->slab8 || a->dw64 || !a->fuse_adam_ok) return false;
+    if (a->peer && a->peer->gate) return false;
     if (a->Mp < GL_RING_MIN_K || a->dw_ksplit > 1) return false;   // the in-launch tiles take the ring path, unsplit
     return split_fits_rows(a, a->s8_rows);
 }
@@ -680,6 +701,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             P.n_pref = want;
         }
         const unsigned grid = n_chain + P.n_plan + P.n_ahead + P.n_pref;
+        HP_KLOG("k_fb_slab8");
         if (a->s8_rows == 4)
             hipLaunchKernelGGL(s8r4::k_fb_slab8, dim3(grid), dim3(S8_THREADS), 0, s, P);
         else if (a->s8_rows == 8)
@@ -692,6 +714,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
         ProfScope ps(a, PROF_GEMM_FWD);
         P.n_plan = ride ? 1 : 0;
         P.n_ahead = P.n_pref = P.xcd_split = 0;
+        HP_KLOG("k_fb_slab32");
         hipLaunchKernelGGL(s32::k_fb_slab32, dim3(2 * nslab + P.n_plan), dim3(S32_THREADS), 0, s, P);
         HP_CHECK_HIP(hipGetLastError());
     }
@@ -728,8 +751,10 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 AdamFuse F = adam_fuse(a);
                 F.keep_grads = (gc == nullptr || a->keep_grads_dbg) ? 1 : 0;
                 if (gc && gc->polyak_after) fold_polyak(a, F);
+                HP_KLOG("k_dw64_adam");
                 hipLaunchKernelGGL(k_dw64_adam, dim3(grid), dim3(DW_THREADS), 0, s, L.g, F, R, X);
             } else {
+                HP_KLOG("k_dw64");
                 hipLaunchKernelGGL(k_dw64, dim3(grid), dim3(DW_THREADS), 0, s, L.g, R, X);
             }
             HP_CHECK_HIP(hipGetLastError());
@@ -741,8 +766,9 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             AdamFuse F = adam_fuse(a);
             F.keep_grads = a->keep_grads_dbg ? 1 : 0;
             if (gc->polyak_after) fold_polyak(a, F);
-            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_peer_u : k_gemm_lds_adam_peer, dim3(grid), dim3(GL_THREADS), 0, s, L.g, F, R,
-                               L.tiles, a->peer->dev, gc->peer_u, a->grad_mean ? 1 : 0);
+            HP_KLOG(L.g.uni ? "k_gemm_lds_adam_peer_u" : "k_gemm_lds_adam_peer");
+            hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_peer_u : k_gemm_lds_adam_peer, dim3(grid), dim3(GL_THREADS), 0, s, L.head(0), L.head(1), L.g, F, R,
+                               L.tiles, a->peer->dev, gc->peer_u, a->grad_mean ? 1 : 0, 0);
             HP_CHECK_HIP(hipGetLastError());
         } else if (riders) {
             ProfScope ps(a, PROF_DW);
@@ -753,9 +779,11 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
                 F.keep_grads = a->keep_grads_dbg ? 1 : 0;
                 if (gc->polyak_after) fold_polyak(a, F);
                 L.g.loss_wg = a->loss_wg;
+                HP_KLOG(L.g.uni ? "k_gemm_lds_adam_ride_u" : "k_gemm_lds_adam_ride");
                 hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_ride_u : k_gemm_lds_adam_ride, dim3(grid + L.g.loss_wg), dim3(GL_THREADS), 0, s, L.head(0), L.head(1),
                                    front, L.g, F, R);
             } else {
+                HP_KLOG(L.g.uni ? "k_gemm_lds_ride_u" : "k_gemm_lds_ride");
                 hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_ride_u : k_gemm_lds_ride, dim3(grid), dim3(GL_THREADS), 0, s, L.g, R, front);
             }
             HP_CHECK_HIP(hipGetLastError());
@@ -768,6 +796,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
             if (gc && gc->polyak_after) fold_polyak(a, F);
             const int front = L.tiles + (sep_bias_on(a) ? L.separate_bias() : 0);
             L.g.loss_wg = a->loss_wg;
+            HP_KLOG(L.g.uni ? "k_gemm_lds_adam_u" : "k_gemm_lds_adam");
             hipLaunchKernelGGL(L.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front + L.g.loss_wg), dim3(GL_THREADS), 0, s, L.head(0), L.head(1), L.g, F);
             HP_CHECK_HIP(hipGetLastError());
         } else {
@@ -780,13 +809,19 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
 // ---- one update in the split form: k_fb_split8 (chains + the critic's tiles and optimizer step [+ the actor's]), then -- in
 // the two-launch form -- the actor's tiles
 // k_fb_split8 with its role table as leading scalar arguments: word r = role r, byte x = its workgroups on XCD x
-static void launch_split(unsigned grid, hipStream_t s, const FbSplitArgs &Q) {
+static void launch_split(unsigned grid, hipStream_t s, const FbSplitArgs &Q, int tiles_mode = SPLIT_TILES_ADAM) {
     unsigned long long w[SR_N];
     for (int r = 0; r < SR_N; ++r) {
         w[r] = 0ull;
         for (int x = 0; x < 8; ++x) w[r] |= ((Q.nrole[x] >> (8 * r)) & 0xffull) << (8 * x);
     }
-    hipLaunchKernelGGL(s8r4::k_fb_split8, dim3(grid), dim3(S8_THREADS), 0, s, w[0], w[1], w[2], w[3], w[4], w[5], w[6], Q);
+    HP_KLOG(tiles_mode == SPLIT_TILES_PEER ? "k_fb_split8<1>" : (tiles_mode == SPLIT_TILES_GRADS ? "k_fb_split8<2>" : "k_fb_split8<0>"));
+    if (tiles_mode == SPLIT_TILES_PEER)
+        hipLaunchKernelGGL(s8r4::k_fb_split8<SPLIT_TILES_PEER>, dim3(grid), dim3(S8_THREADS), 0, s, w[0], w[1], w[2], w[3], w[4], w[5], w[6], Q);
+    else if (tiles_mode == SPLIT_TILES_GRADS)
+        hipLaunchKernelGGL(s8r4::k_fb_split8<SPLIT_TILES_GRADS>, dim3(grid), dim3(S8_THREADS), 0, s, w[0], w[1], w[2], w[3], w[4], w[5], w[6], Q);
+    else
+        hipLaunchKernelGGL(s8r4::k_fb_split8<SPLIT_TILES_ADAM>, dim3(grid), dim3(S8_THREADS), 0, s, w[0], w[1], w[2], w[3], w[4], w[5], w[6], Q);
 }
 static void split_common(hp_agent *a, FbSplitArgs &Q, int set) {
     Q.sync = a->k1_sync + (set & 1) * SPLIT_SET_WORDS;
@@ -797,7 +832,11 @@ static void split_common(hp_agent *a, FbSplitArgs &Q, int set) {
 }
 
 static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built, bool fuse_adam, int only) {
-    HP_REQUIRE(only == 0 && fuse_adam && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine / call");
+    HP_REQUIRE(only == 0 && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine / call");
+    // what the in-launch tiles do behind their products (slab8_split_args.h): the optimizer step (single rank), the tile-wise rank
+    // exchange + the step (data-parallel ranks on a device each, gemm_lds.h PEER), or nothing -- the caller exchanges the gradient
+    // vector and steps in launches of its own (RCCL; two-phase / gated peer memory; utils.sync_grads from a host loop)
+    const int mode = !fuse_adam ? SPLIT_TILES_GRADS : (gc->peer_u >= 0 ? SPLIT_TILES_PEER : SPLIT_TILES_ADAM);
     hipStream_t s = a->ctx->stream;
     FbSlabArgs &P = built.P;
     const int xs = built.xs, nslab = built.nslab;
@@ -829,7 +868,8 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     // of the optimizer steps: W3c after the actor-side chains' first critic dX layer (counter 4), W4c / W1c after their critic
     // forward (3), W2c after the second dX layer (5).  The actor's tiles are the launch behind this one (the form that held them
     // in this launch too, behind an "actor-side chains done" counter, measured 45.7 vs 38.0 us/update in round 4 and is gone).
-    Launch L = build_dw_half(a, true, built.sXA, nullptr);
+    Launch L = build_dw_half(a, true, built.sXA, mode == SPLIT_TILES_GRADS ? gc->grads_out : nullptr);
+    Launch La = build_dw_half(a, false, built.sXP, mode == SPLIT_TILES_GRADS ? gc->grads_out : nullptr);
     Q.tile_stage = 0u | (0u << 4) | (1u << 8) | (2u << 12);
     const unsigned gate_sel = 4u | (3u << 4) | (5u << 8) | (3u << 12);
     Q.tiles = L.g;
@@ -848,22 +888,48 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
     F.tl_mark = Q.tl_mark;
     Q.adam = F;
     Q.s = P;
+    if (mode == SPLIT_TILES_PEER) {
+        HP_REQUIRE(a->peer && a->peer->d_dev && L.tiles + La.tiles <= HP_PEER_TILES, HP_ERR_STATE,
+                   "tile-wise exchange in the split launch: %d + %d tiles exceed the flag rows", L.tiles, La.tiles);
+        Q.peer = a->peer->d_dev;
+        Q.peer_u = gc->peer_u;
+        Q.peer_mean = a->grad_mean ? 1 : 0;
+    }
     const unsigned grid = build_split_roles(a, Q, true, gc->t_plan != nullptr, P.n_plan, P.n_ahead, L.tiles);
     {
         ProfScope ps(a, PROF_GEMM_FWD);
-        launch_split(grid, s, Q);
+        launch_split(grid, s, Q, mode);
         HP_CHECK_HIP(hipGetLastError());
     }
-    {   // the actor's weight gradients + optimizer step: 144 tiles at the reference shapes, one per CU
+    {   // the actor's weight gradients (+ optimizer step): 144 tiles at the reference shapes, one per CU
         ProfScope ps(a, PROF_DW);
-        Launch La = build_dw_half(a, false, built.sXP, nullptr);
+        if (mode == SPLIT_TILES_GRADS) {
+            // gradients only (k_gemm_lds); the optimizer launch behind the exchange clears this launch's counter set (enqueue_adam /
+            // enqueue_peer_adam take it from split_reset_pending)
+            HP_KLOG(La.g.uni ? "k_gemm_lds_u" : "k_gemm_lds");
+            hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_u : k_gemm_lds, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.g);
+            HP_CHECK_HIP(hipGetLastError());
+            a->split_reset_pending = Q.sync;
+            return HP_OK;
+        }
         AdamFuse Fa = adam_fuse(a);
         Fa.keep_grads = a->keep_grads_dbg ? 1 : 0;
         if (gc->polyak_after) fold_polyak(a, Fa);
         Fa.reset_sync = Q.sync;   // every split launch then starts from a clean set whatever the parity of the sequence before it
-        const int front = La.tiles + (sep_bias_on(a) ? La.separate_bias() : 0);
-        La.g.loss_wg = a->loss_wg;
-        hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front + La.g.loss_wg), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa);
+        if (mode == SPLIT_TILES_PEER) {
+            // the same tiles exchanging by themselves (gemm_lds.h PEER), flag rows behind the critic's; tile 0 writes the loss log
+            // and clears the counter set (the bias gradients stay inside the tn == 0 tiles, as in every tile-wise launch)
+            RideArgs R;
+            memset(&R, 0, sizeof(R));
+            HP_KLOG(La.g.uni ? "k_gemm_lds_adam_peer_u" : "k_gemm_lds_adam_peer");
+            hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_peer_u : k_gemm_lds_adam_peer, dim3(La.tiles), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa, R,
+                               La.tiles, a->peer->dev, gc->peer_u, a->grad_mean ? 1 : 0, L.tiles);
+        } else {
+            const int front = La.tiles + (sep_bias_on(a) ? La.separate_bias() : 0);
+            La.g.loss_wg = a->loss_wg;
+            HP_KLOG(La.g.uni ? "k_gemm_lds_adam_u" : "k_gemm_lds_adam");
+            hipLaunchKernelGGL(La.g.uni ? k_gemm_lds_adam_u : k_gemm_lds_adam, dim3(front + La.g.loss_wg), dim3(GL_THREADS), 0, s, La.head(0), La.head(1), La.g, Fa);
+        }
         HP_CHECK_HIP(hipGetLastError());
     }
     return HP_OK;
@@ -924,7 +990,11 @@ int enqueue_adam(hp_agent *a, bool polyak_after) {
     if (a->slab) {
         AdamFuse F = adam_fuse(a);
         if (polyak_after) fold_polyak(a, F);
-        if (n % 4 == 0 && a->la.total % 4 == 0)
+        F.reset_sync = a->split_reset_pending;   // behind a split launch whose tiles wrote gradients only (enqueue_split_update)
+        a->split_reset_pending = nullptr;
+        const bool by4 = n % 4 == 0 && a->la.total % 4 == 0;
+        HP_KLOG(by4 ? "k_adam_frag4" : "k_adam_frag");
+        if (by4)
             hipLaunchKernelGGL(k_adam_frag4, dim3((n / 4 + 255) / 256), dim3(256), 0, a->ctx->stream, F, a->grads, n / 4);
         else
             hipLaunchKernelGGL(k_adam_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, F, a->grads, n);
@@ -939,6 +1009,7 @@ int enqueue_polyak(hp_agent *a) {
     const int n = a->n_arena;
     const double om = 1.0 - a->cfg.polyak;
     if (a->slab) {
+        HP_KLOG("k_polyak_frag");
         hipLaunchKernelGGL(k_polyak_frag, dim3((n + 255) / 256), dim3(256), 0, a->ctx->stream, a->targets, a->params,
                            a->fragFT, n, (float)om, (float)a->cfg.polyak, arena_map(a));
         HP_CHECK_HIP(hipGetLastError());
@@ -967,6 +1038,8 @@ int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after) {
     if (polyak_after) fold_polyak(a, F);
     F.grads_base = a->grads;
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;   // RLARM_KEEP_GRADS=1: hp_agent_get_grads then returns the exchanged sum
+    F.reset_sync = a->split_reset_pending;
+    a->split_reset_pending = nullptr;
     ProfScope ps(a, PROF_ADAM);
     return peer_enqueue_adam(a->peer, F, a->n_arena, u, a->grad_mean);
 }

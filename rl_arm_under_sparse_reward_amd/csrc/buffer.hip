@@ -467,26 +467,24 @@ int hp_buffer_sample_device_us(hp_buffer *b, hp_rng *rng, int64_t batch, double 
     PlanRec *d_plan = b->plan.as<PlanRec>();
     double *d_out = b->out.as<double>();
     float *d_r = reinterpret_cast<float *>(d_out + batch * row);
-    hipEvent_t e0, e1, e2;
-    HP_CHECK_HIP(hipEventCreate(&e0));
-    HP_CHECK_HIP(hipEventCreate(&e1));
-    HP_CHECK_HIP(hipEventCreate(&e2));
+    struct Events {   // destroyed on every exit path
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < 3; ++i) HP_CHECK_HIP(hipEventCreate(&ev.e[i]));
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
     HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r, nullptr));   // warm
-    HP_CHECK_HIP(hipEventRecord(e0, s));
+    HP_CHECK_HIP(hipEventRecord(ev.e[0], s));
     for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
-    HP_CHECK_HIP(hipEventRecord(e1, s));
+    HP_CHECK_HIP(hipEventRecord(ev.e[1], s));
     for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_dict(b, d_plan, batch, sq_threshold, d_out, d_r, nullptr));
-    HP_CHECK_HIP(hipEventRecord(e2, s));
-    HP_CHECK_HIP(hipEventSynchronize(e2));
+    HP_CHECK_HIP(hipEventRecord(ev.e[2], s));
+    HP_CHECK_HIP(hipEventSynchronize(ev.e[2]));
     float ms01 = 0.f, ms12 = 0.f;
-    HP_CHECK_HIP(hipEventElapsedTime(&ms01, e0, e1));
-    HP_CHECK_HIP(hipEventElapsedTime(&ms12, e1, e2));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms01, ev.e[0], ev.e[1]));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms12, ev.e[1], ev.e[2]));
     *draw_us = 1e3 * ms01 / reps;
     *gather_us = 1e3 * ms12 / reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
     return HP_OK;
 }
 
@@ -582,6 +580,7 @@ extern "C" int hp_buffer_sample_dev(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_n
     HP_TRY(sample_dev_check(b, rng, on, gn, batch, clip_obs, o, "hp_buffer_sample_dev"));
     HP_SERIALISE(b);
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");  // np.random.randint(0, 0, B), her.py:24
+    if ((size_t)batch * sizeof(PlanRec) > b->plan.bytes) HP_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));   // an earlier asynchronous call may still read the plan that is about to be freed
     HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
     PlanRec *d_plan = b->plan.as<PlanRec>();
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
@@ -599,6 +598,10 @@ extern "C" int hp_buffer_sample_dev_us(hp_buffer *b, hp_rng *rng, hp_norm *on, h
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
     hipStream_t s = b->ctx->stream;
     const size_t ldx = (size_t)(b->obs_dim + b->goal_dim);
+    // growing `plan` / `out` frees memory that earlier asynchronous hp_buffer_sample_dev launches may still read: wait for them
+    // explicitly instead of relying on hipFree's implicit device synchronisation
+    if ((size_t)batch * sizeof(PlanRec) > b->plan.bytes || (size_t)batch * (2 * ldx + b->act_dim + 1) * 4 > b->out.bytes)
+        HP_CHECK_HIP(hipStreamSynchronize(s));
     HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
     HP_TRY(b->out.ensure((size_t)batch * (2 * ldx + b->act_dim + 1) * 4));
     PlanRec *d_plan = b->plan.as<PlanRec>();
@@ -606,26 +609,24 @@ extern "C" int hp_buffer_sample_dev_us(hp_buffer *b, hp_rng *rng, hp_norm *on, h
     o.x_next = o.x + batch * ldx;
     o.actions = o.x_next + batch * ldx;
     o.r = o.actions + batch * b->act_dim;
-    hipEvent_t e0, e1, e2;
-    HP_CHECK_HIP(hipEventCreate(&e0));
-    HP_CHECK_HIP(hipEventCreate(&e1));
-    HP_CHECK_HIP(hipEventCreate(&e2));
+    struct Events {   // destroyed on every exit path
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < 3; ++i) HP_CHECK_HIP(hipEventCreate(&ev.e[i]));
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
     HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));   // warm
-    HP_CHECK_HIP(hipEventRecord(e0, s));
+    HP_CHECK_HIP(hipEventRecord(ev.e[0], s));
     for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
-    HP_CHECK_HIP(hipEventRecord(e1, s));
+    HP_CHECK_HIP(hipEventRecord(ev.e[1], s));
     for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));
-    HP_CHECK_HIP(hipEventRecord(e2, s));
-    HP_CHECK_HIP(hipEventSynchronize(e2));
+    HP_CHECK_HIP(hipEventRecord(ev.e[2], s));
+    HP_CHECK_HIP(hipEventSynchronize(ev.e[2]));
     float ms01 = 0.f, ms12 = 0.f;
-    HP_CHECK_HIP(hipEventElapsedTime(&ms01, e0, e1));
-    HP_CHECK_HIP(hipEventElapsedTime(&ms12, e1, e2));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms01, ev.e[0], ev.e[1]));
+    HP_CHECK_HIP(hipEventElapsedTime(&ms12, ev.e[1], ev.e[2]));
     *draw_us = 1e3 * ms01 / reps;
     *gather_us = 1e3 * ms12 / reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
     return HP_OK;
 }
 

@@ -77,12 +77,14 @@ __global__ void k_scale_div(float *v, int n, float denom) {
 int comm_allreduce_sum_f32(hp_comm *c, float *dev, size_t n) {
     RcclApi *api = rccl();
     if (!api) return HP_ERR_STATE;
+    HP_KLOG("rccl:ncclAllReduce");
     HP_CHECK_NCCL(api, api->AllReduce(dev, dev, n, ncclFloat32, ncclSum, (ncclComm_t)c->nccl, c->ctx->stream));
     return HP_OK;
 }
 
 int comm_allreduce_mean_f32(hp_comm *c, float *dev, size_t n) {
     HP_TRY(comm_allreduce_sum_f32(c, dev, n));
+    HP_KLOG("k_scale_div");
     hipLaunchKernelGGL(k_scale_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->ctx->stream, dev, (int)n,
                        (float)c->world);
     HP_CHECK_HIP(hipGetLastError());

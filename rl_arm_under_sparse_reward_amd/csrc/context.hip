@@ -54,6 +54,8 @@ __global__ __launch_bounds__(64) void k_cal_mfma(int n8, unsigned long long *out
     if (threadIdx.x == 0) out[1] = __builtin_readcyclecounter() - c0;
 }
 
+thread_local std::vector<std::string> *hp_klog = nullptr;
+
 void hp_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -119,6 +121,13 @@ int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream) {
         }
     }
     ctx->stream = next;
+    return HP_OK;
+}
+
+int hp_ctx_get_stream(hp_ctx *ctx, void **hip_stream) {
+    HP_REQUIRE(ctx && hip_stream, HP_ERR_INVALID, "hp_ctx_get_stream: null argument");
+    CtxGuard guard(ctx);
+    *hip_stream = (void *)ctx->stream;
     return HP_OK;
 }
 

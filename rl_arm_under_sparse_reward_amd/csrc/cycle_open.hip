@@ -176,6 +176,7 @@ int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rn
     A.fault_host = a->fault_host_dev;
     const size_t mt_bytes = 4 * MT_N * sizeof(uint32_t) + MT_IBUF * sizeof(int);
     const size_t lds = norm_bytes > mt_bytes ? norm_bytes : mt_bytes;
+    HP_KLOG("k_cycle_open");
     hipLaunchKernelGGL(k_cycle_open, dim3((unsigned)(2 + OPEN_PARTS * b->staged_n)), dim3(OPEN_THREADS), lds, a->ctx->stream, A);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;

@@ -161,6 +161,8 @@ __device__ __forceinline__ float gl_fold16(float s) {
 struct PeerTile {
     const PeerDev *D;
     int u, mean;
+    int row0;   // first flag row of this launch's tiles: the split form exchanges the critic's tiles (rows 0 ..) inside the chain
+                // launch and the actor's (rows behind them) in the launch that follows, within the same epoch
 };
 // First tile of problems 0-3 / 4-7 (16 bits each, 0xffff: no such problem) and the first bias panel, handed to the kernel as LEADING
 // SCALAR arguments: those are preloaded into SGPRs when the wave starts (gfx942+ kernarg preload, Makefile), so the
@@ -439,7 +441,7 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
             // The flag row names the TILE, not the workgroup: with a split reduction (p.ks > 1) the workgroup that gets here is
             // whichever slice arrived last -- another slice on another rank, so bx would differ from rank to rank.  tile0 + t
             // lies inside the problem's own range of the launch order (slice 0's workgroup index) and is the same everywhere.
-            const int row = p.ks > 1 ? p.tile0 + t : bx;
+            const int row = PT->row0 + (p.ks > 1 ? p.tile0 + t : bx);
             peer_signal_row(D, D.flags_t, row, epoch);
             if (!peer_wait(D, D.flags_t[D.rank] + (size_t)row * HP_PEER_MAX, epoch, 1u)) return;
             // 3. rank-ordered sum (the same float32 expression on every rank: the replicas stay bit-identical)

@@ -16,6 +16,11 @@
 // ------------------------------------------------------------------ error plumbing
 void hp_set_error(const char *fmt, ...);
 
+// launch log (hp_agent_update_kernels, rlarm_hip_debug.h): while non-null on the calling thread, every launch site on the path of
+// an update sequence records the kernel it enqueues -- the names bench.py reports are read off the launch logic itself
+extern thread_local std::vector<std::string> *hp_klog;
+#define HP_KLOG(name) do { if (hp_klog) hp_klog->push_back(name); } while (0)
+
 #define HP_CHECK_HIP(expr)                                                                   \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

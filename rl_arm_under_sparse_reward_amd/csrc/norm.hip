@@ -121,6 +121,7 @@ int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const Pla
     chunk = chunk > 256 ? 256 : chunk;
     chunk = rows < chunk ? (int)rows : chunk;
     const size_t lds = (size_t)chunk * (sizeof(PlanRec) + (size_t)W * 8);
+    HP_KLOG("k_norm_update_from_plan");
     hipLaunchKernelGGL(k_norm_update_from_plan, dim3(1), dim3(NORM_THREADS), lds, o->ctx->stream, o->d, g->d, d_plan,
                        (long long)rows, b->st_obs.as<double>(), b->st_ag, b->st_g, (int)b->T,
                        (int)b->obs_dim, (int)b->goal_dim, clip_obs, recompute ? 1 : 0, o->eps * o->eps, o->std_f32,
@@ -130,12 +131,14 @@ int norm_launch_update_from_plan(hp_norm *o, hp_norm *g, hp_buffer *b, const Pla
 }
 
 int norm_launch_begin(hp_norm *nz) {
+    HP_KLOG("k_norm_begin");
     hipLaunchKernelGGL(k_norm_begin, dim3(1), dim3(NORM_MAX), 0, nz->ctx->stream, nz->d, nz->size);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }
 
 int norm_launch_end(hp_norm *nz) {
+    HP_KLOG("k_norm_end");
     hipLaunchKernelGGL(k_norm_end, dim3(1), dim3(NORM_MAX), 0, nz->ctx->stream, nz->d, nz->size, nz->eps * nz->eps,
                        nz->std_f32);
     HP_CHECK_HIP(hipGetLastError());

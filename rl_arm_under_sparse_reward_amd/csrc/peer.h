@@ -35,6 +35,7 @@ struct hp_peer {
     bool gate = false;         // every wait of the gradient exchange in a one-wavefront kernel of its own (hp_peer_set_gate)
     bool tiles = true;         // one-shot form inside the weight-gradient launch: every tile exchanges by itself (RLARM_PEER_TILES=0: off)
     PeerDev dev;
+    PeerDev *d_dev = nullptr;  // device copy of `dev` (hp_peer_connect): what kernels whose argument block has no room for it read (k_fb_split8)
 };
 
 float *peer_grad_buffer(hp_peer *p, int parity);

@@ -32,6 +32,8 @@
 // RCCL (comm.hip) stays as the fallback transport; utils.Communicator picks this one when a self-check passes.
 #include "internal.h"
 
+#include <cstdlib>
+
 #include "peer.h"
 
 // the gradient channel's epoch base moves on by an EVEN count per sequence, so that the buffer parity of update u is
@@ -157,6 +159,7 @@ int peer_check_alive(const hp_peer *p, const char *who) {
 }
 
 int peer_enqueue_seq_end(hp_peer *p, int n_updates) {
+    HP_KLOG("k_peer_seq_end");
     hipLaunchKernelGGL(k_peer_seq_end, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, n_updates);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -164,6 +167,7 @@ int peer_enqueue_seq_end(hp_peer *p, int n_updates) {
 
 int peer_enqueue_gate(hp_peer *p, int channel, int u) {
     if (!p->gate) return HP_OK;
+    HP_KLOG("k_peer_gate");
     hipLaunchKernelGGL(k_peer_gate, dim3(1), dim3(64), 0, p->ctx->stream, p->dev, channel, u);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -172,6 +176,7 @@ int peer_enqueue_gate(hp_peer *p, int channel, int u) {
 int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean) {
     HP_TRY(peer_enqueue_gate(p, 1, u));
     const int per = (n4 + p->world - 1) / p->world;
+    HP_KLOG("k_peer_reduce_slice");
     hipLaunchKernelGGL(k_peer_reduce_slice, dim3((per + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev, n4, u, mean ? 1 : 0);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -179,6 +184,7 @@ int peer_enqueue_reduce_slice(hp_peer *p, int n4, int u, bool mean) {
 
 int peer_allreduce_small(hp_peer *p, float *dev, size_t n, bool mean) {
     HP_REQUIRE(n <= HP_PEER_SMALL, HP_ERR_INVALID, "peer all-reduce: %zu floats exceed the mailbox (%d)", n, HP_PEER_SMALL);
+    HP_KLOG("k_peer_small");
     hipLaunchKernelGGL(k_peer_small, dim3(1), dim3(256), 0, p->ctx->stream, p->dev, dev, (int)n, mean ? 1 : 0);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -219,6 +225,17 @@ static void peer_fill_dev(hp_peer *p) {
             p->dev.red[q][k] = reinterpret_cast<float *>(b + L.red + k * gstride);
         }
     }
+}
+
+// Failure injection for the start-up paths that only a multi-GPU node can fail for real (tests/test_gpu_bench_contract.py):
+// RLARM_PEER_INJECT=ipc[@rank] -> hp_peer_connect fails on that rank (default 0) as if hipIpcOpenMemHandle had refused a peer's
+// handle; =selfcheck[@rank] -> hp_peer_selfcheck reports mismatches there.  Either way every rank must agree to drop the
+// exchange and take the next transport down (utils.Communicator.attach_peer), and the run must still print its line.
+static bool peer_inject(const hp_peer *p, const char *what) {
+    const char *e = getenv("RLARM_PEER_INJECT");
+    const size_t n = strlen(what);
+    if (!e || strncmp(e, what, n) != 0 || (e[n] != '\0' && e[n] != '@')) return false;
+    return p->rank == (e[n] == '@' ? atoi(e + n + 1) : 0);
 }
 
 extern "C" {
@@ -285,6 +302,8 @@ int hp_peer_create(hp_ctx *ctx, int32_t rank, int32_t world, int64_t n_grad_floa
 int hp_peer_connect(hp_peer *p, const uint8_t *handles) {
     HP_REQUIRE(p && handles, HP_ERR_INVALID, "hp_peer_connect: null argument");
     CtxGuard guard(p->ctx);
+    HP_REQUIRE(!peer_inject(p, "ipc"), HP_ERR_HIP, "hp_peer_connect: hipIpcOpenMemHandle(rank %d) failed: injected (RLARM_PEER_INJECT=ipc)",
+               (p->rank + 1) % p->world);
     for (int q = 0; q < p->world; ++q) {
         if (q == p->rank) continue;
         HP_REQUIRE(memcmp(handles + 64 * q, p->handle, 64) != 0, HP_ERR_INVALID, "hp_peer_connect: rank %d sent this rank's own handle", q);
@@ -300,6 +319,9 @@ int hp_peer_connect(hp_peer *p, const uint8_t *handles) {
         p->remote[q] = ptr;
     }
     peer_fill_dev(p);
+    // the same table in device memory, for the kernels that take it by pointer (written once, here; read-only afterwards)
+    if (!p->d_dev) HP_CHECK_HIP(hipMalloc((void **)&p->d_dev, sizeof(PeerDev)));
+    HP_CHECK_HIP(hipMemcpy(p->d_dev, &p->dev, sizeof(PeerDev), hipMemcpyHostToDevice));
     p->connected = true;
     return HP_OK;
 }
@@ -338,6 +360,7 @@ int hp_peer_selfcheck(hp_peer *p, uint32_t *mismatches) {
     HP_CHECK_HIP(hipMemcpyAsync(h, p->dev.error, 8, hipMemcpyDeviceToHost, s));
     HP_CHECK_HIP(hipStreamSynchronize(s));
     *mismatches = h[1] + (h[0] ? 0x80000000u : 0u);   // top bit: a wait timed out
+    if (peer_inject(p, "selfcheck")) *mismatches += 7u;
     return HP_OK;
 }
 
@@ -370,6 +393,7 @@ void hp_peer_destroy(hp_peer *p) {
         if (q != p->rank && p->remote[q]) (void)hipIpcCloseMemHandle(p->remote[q]);
     if (p->local) (void)hipFree(p->local);
     if (p->d_epoch) (void)hipFree(p->d_epoch);
+    if (p->d_dev) (void)hipFree(p->d_dev);
     if (p->h_error) (void)hipHostFree(p->h_error);
     delete p;
 }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_test_uniform(MtState *st, long l
 // ------------------------------------------------------------------------------ launchers
 int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int32_t T, int64_t batch,
                     int32_t n_batches, double future_p, PlanRec *d_plan, hipStream_t stream) {
+    HP_KLOG("k_draw_plan");
     hipLaunchKernelGGL(k_draw_plan, dim3(1), dim3(MT_THREADS), 0, stream ? stream : rng->ctx->stream, rng->d_state, d_meta,
                        (long long)n_eps_fixed, (int)T, (long long)batch, (int)n_batches, future_p, d_plan);
     HP_CHECK_HIP(hipGetLastError());
@@ -81,6 +82,7 @@ int rng_launch_plan(hp_rng *rng, const BufMeta *d_meta, int64_t n_eps_fixed, int
 
 int rng_launch_plan2(hp_rng *rng, int64_t n_first, int32_t T, int64_t batch_first, PlanRec *d_plan_first,
                      const BufMeta *d_meta, int64_t batch, int32_t n_batches, double future_p, PlanRec *d_plan) {
+    HP_KLOG("k_draw_plan2");
     hipLaunchKernelGGL(k_draw_plan2, dim3(1), dim3(MT_THREADS), 0, rng->ctx->stream, rng->d_state, (long long)n_first, (int)T,
                        (long long)batch_first, d_plan_first, d_meta, (long long)batch, (int)n_batches, future_p, d_plan);
     HP_CHECK_HIP(hipGetLastError());

@@ -90,6 +90,9 @@ __device__ __forceinline__ void adam_prepare_wt(AgentDevState *st, const AdamCfg
     wt_store(&st->bc2_sqrt, (float)sqrt(bc2));
 }
 
+// TILES: what the in-launch tiles do behind their products (slab8_split_args.h: SPLIT_TILES_*); one kernel per form, so that the
+// single-rank launch keeps its own register allocation and code placement
+template <int TILES>
 __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long long r2, unsigned long long r3, unsigned long long r4,
                  unsigned long long r5, unsigned long long r6, const FbSplitArgs Q) {
@@ -181,7 +184,18 @@ void k_fb_split8(unsigned long long r0, unsigned long long r1, unsigned long lon
                           1u, reinterpret_cast<int *>(dq)))
             return;
         SPLIT_STAMP(1);
-        gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, false);
+        if constexpr (TILES == SPLIT_TILES_GRADS) {
+            // gradients into the buffer the exchange reads (plain stores: the kernel boundary publishes them); no parameter is
+            // written in this launch, so no gate
+            gemm_tile<false, false, true>(Q.tiles, nullptr, tile, tlds, bsum, false);
+        } else if constexpr (TILES == SPLIT_TILES_PEER) {
+            // the ranks' same tile meets through the exchange block's per-tile flag rows (rows 0 .. tiles - 1: the actor's tiles of
+            // the launch behind this one use the rows that follow), summed in rank order, then the gate and the step
+            const PeerTile PT{Q.peer, Q.peer_u, Q.peer_mean, 0};
+            gemm_tile<true, false, true, true>(Q.tiles, &Q.adam, tile, tlds, bsum, false, &PT);
+        } else {
+            gemm_tile<true, false, true>(Q.tiles, &Q.adam, tile, tlds, bsum, false);
+        }
         SPLIT_STAMP(3);
     } else if (role == SR_T) {
         // ------------------------------------------------------------------ target side, one update ahead

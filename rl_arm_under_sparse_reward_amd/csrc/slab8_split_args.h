@@ -2,6 +2,7 @@
 // its host side (agent_engines.hip): roles, the argument block, the time-line build's stamp arrays.  Included once, outside the
 // per-height namespaces, by slab8.h.
 #pragma once
+#include "peer.h"
 
 #ifdef SLAB_TIMELINE   // time-line builds: every workgroup of the last split launch stamps {start, hand-off point, -, end}
 __device__ unsigned long long g_split_tl[1024][4];
@@ -33,6 +34,15 @@ struct FbSplitArgs {
     int tl_mark;                     // time-line builds: this launch records its per-workgroup stamps (the last one WITH target chains)
     GemmGroup tiles;                 // weight-gradient problems: the critic's four
     AdamFuse adam;                   // their optimizer epilogue
+    // data-parallel ranks, tile-wise exchange inside this launch (k_fb_split8<SPLIT_TILES_PEER>; gemm_lds.h PEER): the rank's exchange
+    // block as mapped in this process -- a DEVICE copy of hp_peer::dev (by value it would push this block past the 4 KB kernarg
+    // segment) --, index of the update in its sequence (the exchange epoch), SUM / MEAN
+    const PeerDev *peer;
+    int peer_u, peer_mean;
 };
+// what the in-launch weight-gradient tiles of k_fb_split8 do behind their products
+enum { SPLIT_TILES_ADAM = 0,   // single rank: optimizer step of the critic inside the launch (behind the actor-side chains' gates)
+       SPLIT_TILES_PEER = 1,   // data-parallel ranks, one device each: rank exchange tile by tile, then the same step (utils.py:43-48 + Adam)
+       SPLIT_TILES_GRADS = 2 };// gradients only: exchange (RCCL, two-phase / gated peer memory) + optimizer follow as launches of their own
 static_assert(sizeof(FbSplitArgs) <= 4096, "kernel arguments of k_fb_split8 exceed the 4 KB kernarg segment");
 

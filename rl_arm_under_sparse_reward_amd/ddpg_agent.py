@@ -262,6 +262,11 @@ class ddpg_agent:
                         _lib.register_pending(self)
                 return
             n_updates = 1
+        with _lib.pending_lock:
+            # owed updates that a failed flush parked come FIRST, like in the reference's sequential loop: an explicit call is a
+            # point to try them again, exactly as the argument-less form above does (if they fail again this call raises and
+            # issues nothing of its own)
+            self._pending_parked = False
         self._flush_updates()
         self._issue_updates(int(n_updates))
 
@@ -274,7 +279,9 @@ class ddpg_agent:
         0` on an empty buffer, ddpg_agent.py:227): the error names the deferred call it belongs to, what could not be issued
         stays owed (`pending_updates`) but is PARKED -- no later library call retries it by itself, so every object stays usable
         and the caller can remove the cause (e.g. store an episode).  The owed updates are tried again by the next
-        `_update_network()` call, by `retry_pending_updates()`, or dropped by `discard_pending_updates()`."""
+        `_update_network()` / `_update_network(n)` call (in front of that call's own updates: the order of updates never
+        changes), by `retry_pending_updates()`, or dropped by `discard_pending_updates()`.  Every OTHER caller of this method
+        (train_cycle, weight reads, close_comm) leaves parked updates parked."""
         with _lib.pending_lock:
             if self._pending_parked:
                 return
@@ -415,17 +422,49 @@ class ddpg_agent:
         self._update_network(n_batches)
         self._soft_update_target_network()
 
+    def update_kernels(self, n_updates=None):
+        """The kernels a sequence of `n_updates` updates enqueues on this agent as it is NOW -- engine, switches, attached
+        transport -- read off the library's own launch logic (hp_agent_update_kernels: the logic runs under a discarded stream
+        capture, nothing executes).  {'open': [...], 'prologue': [...], 'updates': [[...] per update], 'close': [...]}."""
+        self._flush_updates()
+        n = int(n_updates or self.args.n_batches)
+        host_loop = self.comm.active and self._native_comm is None and self._peer is None
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self.lib.hp_agent_update_kernels(*self._handles(), float(self.her_module.future_p),
+                                                    float(self.her_module.sq_threshold), n, 1 if host_loop else 0, buf, len(buf)))
+        out, cur = {"open": [], "prologue": [], "updates": [], "close": []}, None
+        for tok in buf.value.decode().split(","):
+            if tok == "#update":
+                out["updates"].append([])
+                cur = out["updates"][-1]
+            elif tok.startswith("#"):
+                cur = out[tok[1:]]
+            elif tok:
+                cur.append(tok)
+        return out
+
     def engine(self):
         """Kernels this agent's updates run (hp_agent_engine): e.g. {'engine': 'slab8', 'slab_rows': 4, 'weight_grad':
-        'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 3'} at 4096."""
+        'gemm_lds 32x32'} at the reference batch, {'engine': 'slab32', 'slab_rows': 32, 'weight_grad': 'dw64 split 3'} at 4096.
+        `kernels_per_update`: the launches of one steady-state update of an n_batches sequence, by name, as the library
+        enqueues them with the transport attached NOW (ask before close_comm)."""
         e, r, d, f = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.hp_agent_engine(self.h, C.byref(e), C.byref(r), C.byref(d)))
         _lib.check(self.lib.hp_agent_update_form(self.h, int(self.args.n_batches), C.byref(f)))
-        return {"engine": {0: "layers", 8: "slab8", 32: "slab32"}[e.value], "slab_rows": r.value,
-                "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32",
-                "launches_per_update": {0: "chains | weight gradients + Adam",
-                                        1: "split: chains (targets one update ahead) + critic weight gradients + Adam | actor weight gradients + Adam",
-                                        2: "split, one launch: chains + all weight gradients + Adam"}[f.value]}
+        out = {"engine": {0: "layers", 8: "slab8", 32: "slab32"}[e.value], "slab_rows": r.value,
+               "weight_grad": f"dw64 split {d.value}" if d.value else "gemm_lds 32x32",
+               "launches_per_update": {0: "chains | weight gradients (+ Adam, or exchange + Adam)",
+                                       1: "split: chains (targets one update ahead) + critic weight gradients (+ exchange + Adam) | "
+                                          "actor weight gradients (+ exchange + Adam)"}[f.value]}
+        try:
+            k = self.update_kernels()
+            ups = k["updates"]
+            out["kernels_per_update"] = ups[min(2, len(ups) - 1)]
+            out["kernels_per_sequence_extra"] = k["open"] + k["prologue"] + k["close"]
+        except _lib.HpError as err:      # e.g. the legacy stream cannot be captured: the form above still stands
+            out["kernels_per_update"] = None
+            out["kernels_error"] = str(err)
+        return out
 
     def policy_snapshot(self):
         """Publish the current actor + normalizer statistics to feeders that call the policy while cycles run

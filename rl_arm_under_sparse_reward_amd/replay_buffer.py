@@ -112,10 +112,11 @@ class DeviceEpisodeBuffer:
 
     def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False):
         """hp_buffer_sample_dev: the minibatch as the learner consumes it (ddpg_agent.py:227-243) in torch CUDA tensors
-        allocated here, written on torch's current stream: x, x_next [B, obs+goal], actions [B, act], r [B, 1], float32."""
+        allocated here: x, x_next [B, obs+goal], actions [B, act], r [B, 1], float32.  The kernels run on the CONTEXT's stream,
+        ordered with torch's current stream by events on both sides (_lib.Context.torch_bridge): the context is not rebound, so
+        a fused learner on the same context keeps replaying its cached graphs, and no host synchronisation happens."""
         import torch
 
-        self.ctx.on_torch_stream()
         B = int(batch)
         dev = torch.device("cuda", self.ctx.device_id)
         ldx = self.dims["obs"] + self.dims["g"]
@@ -132,8 +133,10 @@ class DeviceEpisodeBuffer:
             idx["her"] = torch.empty(B, dtype=torch.uint8, device=dev)
             for k, t in idx.items():
                 setattr(o, k, t.data_ptr())
-        _lib.check(self.lib.hp_buffer_sample_dev(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold),
-                                                 float(clip_obs), C.byref(o)))
+        with self.ctx.torch_bridge() as note:
+            _lib.check(self.lib.hp_buffer_sample_dev(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold),
+                                                     float(clip_obs), C.byref(o)))
+            note(list(out.values()) + (list(idx.values()) if idx else []))
         return (out, idx) if with_indices else out
 
     def __del__(self):

@@ -38,6 +38,7 @@ class Communicator:
         self.peer = None          # library-side peer-memory exchange (hp_peer *), see attach_peer
         self.shared_device = False   # two or more ranks on one physical device (set by attach_peer)
         self.gate = gate             # peer exchange: waits in gate kernels (hp_peer_set_gate); None = exactly when ranks share a device
+        self.peer_refused = None     # why attach_peer did not return an exchange although it was tried (for the run's record)
 
     def agree(self, flag, ctx=None):
         """True iff `flag` is true on EVERY rank (collective).  Transport decisions must be taken by all ranks together."""
@@ -114,6 +115,8 @@ class Communicator:
         every = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(self.world_size)]
         dist.all_gather(every, mine)
         if not agree(ok):
+            self.peer_refused = "hp_peer_create failed" + ("" if not ok else " on another rank") + (
+                ": " + _lib.last_error(lib) if not ok else "")
             if ok:
                 lib.hp_peer_destroy(h)
             return None
@@ -130,6 +133,7 @@ class Communicator:
         _lib.check(lib.hp_peer_set_gate(h, 1 if (self.shared_device if self.gate is None else self.gate) else 0))
         ok = lib.hp_peer_connect(h, raw) == 0
         if not agree(ok):      # before any collective kernel: a rank that could not map its peers must not leave the others waiting
+            self.peer_refused = ("mapping the peers' exchange memory failed" + (" on another rank" if ok else ": " + _lib.last_error(lib)))
             lib.hp_peer_destroy(h)
             return None
         # self-check: rank r contributes (r + 1) * (i + 1); the rank-ordered sum is exact in float32.  Every rank runs EVERY
@@ -153,6 +157,8 @@ class Communicator:
         ok = ok and checked and bad.value == 0
         ok = lib.hp_peer_status(h, C.byref(err)) == 0 and err.value == 0 and ok
         if not agree(ok):
+            self.peer_refused = ("attach-time self-check failed" + (" on another rank" if ok else
+                                 f" (gradient channel: {bad.value} mismatching elements, error word 0x{err.value:x})"))
             lib.hp_peer_destroy(h)
             return None
         self.peer, self._native_lib = h, lib

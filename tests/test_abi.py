@@ -51,7 +51,7 @@ def test_stable_and_diagnostic_surfaces_are_separate():
     assert debug == _lib.DEBUG_SYMBOLS
     assert not [s for s in stable if "debug" in s or s in ("hp_agent_set_adam", "hp_ctx_launch_floor")]
     version = int(re.search(r"#define\s+HP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert version == _lib.ABI_VERSION == 3
+    assert version == _lib.ABI_VERSION == 4
     if os.path.exists(os.path.join(PKG, "librlarm_hip.so")):
         assert ctypes.CDLL(os.path.join(PKG, "librlarm_hip.so")).hp_abi_version() == version
 
@@ -115,7 +115,8 @@ def test_pending_updates_are_issued_in_front_of_any_other_library_call():
 
 def test_switch_list_is_the_documented_one():
     """Every RLARM_* switch the product reads is in DESIGN.md section 4's list, the list names nothing else, and it stays at 15
-    (the forms measured and lost go with their switches)."""
+    (the forms measured and lost go with their switches) + the one failure-injection hook of round 6
+    (RLARM_PEER_INJECT)."""
     read = set()
     for root, _, files in os.walk(PKG):
         for f in files:
@@ -129,4 +130,4 @@ def test_switch_list_is_the_documented_one():
     sec = design[design.index("Switches (A/B and debugging"):design.index("## 5. Parity")]
     documented = set(re.findall(r"`(RLARM_[A-Z0-9_]+)", sec))
     assert read == documented, (sorted(read - documented), sorted(documented - read))
-    assert len(documented) <= 15, sorted(documented)
+    assert len(documented) <= 16, sorted(documented)

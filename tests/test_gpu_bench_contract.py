@@ -44,7 +44,7 @@ def test_driver_invocation_prints_the_contract_line():
     eng = d["config"]["engine"]
     assert (eng["engine"], eng["slab_rows"], eng["weight_grad"]) == ("slab8", 4, "gemm_lds 32x32")
     assert eng["launches_per_update"].startswith("split")          # round 4: the default form at the headline shape
-    assert d["roofline"]["kernel"] == "k_fb_split8"
+    assert d["roofline"]["kernel"] == "k_fb_split8<0>" and eng["kernels_per_update"] == ["k_fb_split8<0>", "k_gemm_lds_adam"]
     cal = d["calibration"]
     assert 0.5 < cal["launch_floor_us"] < 10 and 20 < cal["lds_dma_GBps_per_cu"] < 400 and 4 < cal["mfma4x4_dependent_cycles"] < 40
     r = d["roofline"]
@@ -166,3 +166,79 @@ def test_alternatives_pass_survives_a_failing_transport():
     bad = [x for x in alts if x["exchange"].startswith("peer memory, two-phase")]
     assert len(bad) == 1 and "error" in bad[0] and "injected" in bad[0]["error"]
     assert sum("us_per_update" in x for x in alts) >= 3
+
+
+def _trace_kernel_names(flags, env, tmp_path):
+    """Kernel names rocprofv3 --kernel-trace lists for `bench.py flags` (short form, as tools/trace_summary.py prints them)."""
+    import shutil
+    import sqlite3
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    out = str(tmp_path / "trace")
+    e = dict(os.environ, TMPDIR="/tmp", RLARM_BENCH_ALTERNATIVES="0", **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "t", "--", sys.executable,
+                        os.path.join(REPO, "bench.py"), *flags], cwd="/tmp", env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, p.stdout[-1500:]
+    dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+    assert dbs, os.listdir(out)
+    names = set()
+    for (nm,) in sqlite3.connect(dbs[0]).execute("select distinct name from kernels"):
+        n = nm[5:] if nm.startswith("void ") else nm
+        names.add(n.split("(")[0].split("::")[-1])
+    return json.loads(line[0]), names
+
+
+@pytest.mark.parametrize("transport,chain,tiles", [("peer", "k_fb_split8<1>", "k_gemm_lds_adam_peer"), ("rccl", "k_fb_split8<2>", "k_gemm_lds")])
+def test_forced_data_parallel_line_names_the_kernels_it_ran(transport, chain, tiles, tmp_path):
+    """VERDICT r05 items 1 + 2.  A data-parallel rank takes the split launch (round 6) and the line says so with the kernels the
+    library's launch logic enqueues WHILE the transport is attached (round 5 asked after close_comm() and named the single-rank
+    k_fb_split8 for a rank that ran k_fb_slab8): `config.engine.kernels_per_update` = hp_agent_update_kernels, the roofline's
+    kernel is one of them, and a rocprofv3 --kernel-trace of the same command lists every one of them."""
+    flags = ("--steps", "400", "--warmup", "80", "--no-cpu-baseline")
+    d, traced = _trace_kernel_names(flags, {"RLARM_BENCH_FORCE_DP": "1", "RLARM_COMM": transport}, tmp_path)
+    c, r = d["config"], d["roofline"]
+    assert c["exchange"] == {"peer": "peer-memory", "rccl": "rccl"}[transport]
+    kp = c["engine"]["kernels_per_update"]
+    assert kp[0] == chain and tiles in kp, kp
+    assert c["engine"]["launches_per_update"].startswith("split")
+    assert r["kernel"] in kp and r["kernels_per_update"] == kp
+    own = [k for k in kp if not k.startswith("rccl:")]             # (RCCL's kernel carries RCCL's own name in the trace)
+    assert set(own) <= traced, (own, sorted(traced))
+    assert "k_fb_slab8" not in traced and "k_fb_split8<0>" not in traced     # nothing of the two-launch / single-rank forms ran
+    assert r["all_matrix_kernels"]["chain"]["kernel"] == chain and 0 < r["frac"] < 1
+    assert r["duration_source"] in ("live", "committed")
+
+
+@pytest.mark.parametrize("inject", ["selfcheck", "ipc"])
+def test_first_contact_failures_of_the_peer_exchange_still_yield_a_line(inject):
+    """VERDICT r05 item 6.  What only a multi-GPU node can fail for real, forced on the one device: the attach-time self-check
+    reporting mismatches (RLARM_PEER_INJECT=selfcheck) and hipIpcOpenMemHandle refusing a peer's handle (=ipc), on one rank.
+    Every rank must drop the peer exchange together, the run must degrade to the next transport (RCCL on a device each; two
+    ranks on ONE device cannot use RCCL, so torch.distributed here), print the headline with the failure recorded and the
+    alternatives pass inside its time box, and exit 0."""
+    d = _run("--gpus", "2", "--episodes", "64", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", timeout=600,
+             RLARM_BENCH_ALTERNATIVES="1", RLARM_BENCH_ALT_BUDGET_S="45", RLARM_PEER_INJECT=inject + "@1")
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["exchange"] in ("rccl", "torch.distributed") and c["replicas_bit_identical"] is True
+    fb = c["exchange_fallbacks"]
+    assert fb and fb[0]["exchange"] == "peer-memory" and ("self-check" if inject == "selfcheck" else "mapping") in fb[0]["refused_at_attach"]
+    alts = d["exchange_alternatives"]
+    assert len(alts) == 5 and all("exchange" in x for x in alts)
+    assert all(("us_per_update" in x) or ("skipped" in x) or ("error" in x) for x in alts)
+    assert not any(x.get("ran_as", "").startswith("peer-memory") for x in alts)      # the injection refuses it every time
+
+
+def test_alternatives_pass_is_time_boxed():
+    """... and the extra passes fit their time box: with 12 s for five transports every pass that starts gets a cut number of
+    cycles or is recorded as skipped, and the line is printed."""
+    d = _run("--gpus", "2", "--episodes", "64", "--steps", "80", "--warmup", "40", "--no-cpu-baseline", "--no-profile", timeout=600,
+             RLARM_BENCH_ALTERNATIVES="1", RLARM_BENCH_ALT_BUDGET_S="12")
+    alts = d["exchange_alternatives"]
+    assert len(alts) == 5 and any("skipped" in x for x in alts), alts
+    for x in alts:
+        if "us_per_update" in x:
+            assert x["steps"] <= 400 and x["replicas_bit_identical"] is True

@@ -261,13 +261,21 @@ def test_every_update_meets_the_bar_on_the_full_shard(batch, k, monkeypatch):
           f"grad / max|g| {worst[1]:.2e}, optimizer {worst[2]:.2f} x (1 ulp + 5e-10), param {worst[3]:.2e}, ReLU ties {worst[5]}")
 
 
-@pytest.mark.parametrize("transport", ["peer", "peer+notiles", "peer+2phase", "native", "torch"])
+@pytest.mark.parametrize("transport", ["peer", "peer+notiles", "peer+2phase", "native", "torch",
+                                       "peer+split", "peer+notiles+split", "peer+2phase+split", "native+split"])
 def test_every_update_meets_the_bar_through_the_data_parallel_optimizer(transport, monkeypatch):
     """1-rank group, forced exchange: backward -> exchange -> separate optimizer kernel (k_peer_adam; k_peer_reduce_slice +
     k_peer_adam2; RCCL + k_adam_frag4; torch.distributed + hp_agent_apply), the kernels every rank of a multi-GPU job runs --
-    and, round 4, "peer" = weight gradients + tile-wise exchange + optimizer step in ONE launch (k_gemm_lds_adam_peer)."""
+    and, round 4, "peer" = weight gradients + tile-wise exchange + optimizer step in ONE launch (k_gemm_lds_adam_peer).
+    Round 6, +split: the same transports through the split launch, which data-parallel ranks now take as well -- "peer": the
+    critic's in-launch tiles exchange tile-wise and step inside k_fb_split8<1>, the actor's in k_gemm_lds_adam_peer behind it;
+    every other transport: k_fb_split8<2> (gradients only) + k_gemm_lds, then the exchange and the optimizer kernel."""
     import torch.distributed as dist
     from rl_arm_under_sparse_reward_amd.utils import Communicator
+    split = transport.endswith("+split")
+    if split:
+        transport = transport[:-6]
+        monkeypatch.setenv("RLARM_SPLIT", "1")         # single updates too (the teacher-forced loop issues them one at a time)
     if transport.endswith("+2phase"):
         transport = transport[:-7]
         monkeypatch.setenv("RLARM_PEER_PHASES", "2")
@@ -286,6 +294,13 @@ def test_every_update_meets_the_bar_through_the_data_parallel_optimizer(transpor
         worst, agent = _run(256, 4, comm=comm)
         assert (agent._peer is not None) == (transport == "peer")
         assert (agent._native_comm is not None) == (transport == "native")
+        kernels = agent.update_kernels(1)["updates"][0]
+        print(f"data-parallel optimizer path {transport}{' +split' if split else ''}: kernels of one update {kernels}")
+        if split:
+            tiles_in_launch = os.environ.get("RLARM_PEER_TILES") != "0" and os.environ.get("RLARM_PEER_PHASES") != "2"
+            assert kernels[0] == ("k_fb_split8<1>" if transport == "peer" and tiles_in_launch else "k_fb_split8<2>"), kernels
+        else:
+            assert kernels[0] == "k_fb_slab8", kernels
         _lib.Context.default().synchronize()
         torch.cuda.synchronize()
         agent.close_comm()

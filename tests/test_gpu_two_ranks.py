@@ -30,6 +30,15 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir, transport="torch"):
     import sys
+    split = transport.endswith("split")
+    if split:
+        # Round 6: data-parallel ranks on a device each take the split launch (slab8_split.h) like a single rank does: the critic's
+        # tiles exchange INSIDE the chain launch (k_fb_split8<1>), the actor's in k_gemm_lds_adam_peer behind it.  Ranks that
+        # share a device (gate kernels on) keep the two-launch form -- the split launch's in-launch waits need the whole launch
+        # resident, which eight ranks on one device do not give it -- so the rehearsal runs like "peertiles": gates off, batch 64
+        # (2 x 48 chains: every chain of both ranks resident), split forced for the 8-update sequences of this test.
+        transport = transport[:-5]
+        os.environ["RLARM_SPLIT"] = "1"
     if transport == "auto":                  # nothing forced: the library picks transport and form (peer memory; two-phase from 4 ranks)
         os.environ.pop("RLARM_COMM", None)
         os.environ.pop("RLARM_PEER_PHASES", None)
@@ -81,6 +90,11 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     rng = DeviceRandomState(seed)
     agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100), None, dict(ENV_PARAMS), comm=comm, rng=rng)
     assert agent._native_comm is None        # gloo group: no RCCL (two ranks share one device)
+    kernels = agent.update_kernels(N_UP)["updates"][2]
+    if split:
+        assert kernels[0] == ("k_fb_split8<1>" if transport.startswith("peertiles") else "k_fb_split8<2>"), kernels
+    elif transport != "torch":
+        assert kernels[0] == "k_fb_slab8", kernels
     peer = transport.startswith("peer") or transport == "auto"
     assert (agent._peer is not None) == peer
     if peer:
@@ -121,7 +135,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
         tr, _ = st.sample(batch, fp, rs)
         res = learner.update(*oupd.minibatch_tensors(tr, on, gn))
         want.append([res["actor_loss"], res["critic_loss"]])
-    out = {"got": got, "want": np.array(want), "actor": agent._get_flat(NET_ACTOR), "critic": agent._get_flat(NET_CRITIC),
+    out = {"got": got, "want": np.array(want), "kernels": kernels, "actor": agent._get_flat(NET_ACTOR), "critic": agent._get_flat(NET_CRITIC),
            "actor0": oupd.flatten(list(a0.values())), "oracle_actor": learner.flat("actor"),
            "oracle_critic": learner.flat("critic"), "critic0": oupd.flatten(list(c0.values())),
            "rng_equal": bool(np.array_equal(rng.get_state()[1], rs.get_state()[1]) and rng.get_state()[2] == rs.get_state()[2]),
@@ -171,7 +185,8 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("peertiles", 2), ("peertilesks", 2), ("auto", 4), ("torch", 4), ("peer", 4)],
+@pytest.fixture(scope="module", params=[("torch", 2), ("peer", 2), ("peer2", 2), ("peertiles", 2), ("peertilesks", 2), ("auto", 4), ("torch", 4), ("peer", 4),
+                                        ("peertilessplit", 2)],
                 ids=lambda p: f"{p[0]}-w{p[1]}")
 def two_ranks(request, tmp_path_factory):
     """torch: collectives through torch.distributed (gloo, host-staged) from a host-driven loop.
@@ -240,6 +255,7 @@ def test_peer_exchange_keeps_ranks_identical_through_graph_cycles(two_ranks):
     r0 = two_ranks[0]
     if r0["transport"] == "torch":
         pytest.skip("peer-memory transport only")
+    print(f"[{r0['transport']} x {len(two_ranks)}] kernels of one update: {r0['kernels']}")
     for r1 in two_ranks[1:]:
         assert r0["normalizer_golden_ok"] and r1["normalizer_golden_ok"]   # _mpi_average through the mailboxes: reference bits
         assert r0["cycle_mode"] == 1 and r1["cycle_mode"] == 1          # the cycle, exchange included, replays as a hipGraph

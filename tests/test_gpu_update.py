@@ -417,7 +417,13 @@ def _run_cycles(agent, n_cycles=3, n_batches=4, graph=False):
                                                     ("peer+2phase", True, "sum"), ("peer+2phase", False, "mean"),
                                                     # round 4: "peer" is now the tile-wise exchange inside the weight-gradient launch
                                                     # (gemm_lds.h PEER); +notiles keeps k_gemm_lds -> k_peer_adam covered
-                                                    ("peer+notiles", True, "sum"), ("peer+notiles", False, "mean")])
+                                                    ("peer+notiles", True, "sum"), ("peer+notiles", False, "mean"),
+                                                    # round 6: data-parallel ranks take the split launch too (k_fb_split8<1>: the
+                                                    # critic's in-launch tiles exchange tile-wise; <2>: gradients only, exchange
+                                                    # and optimizer as launches of their own)
+                                                    ("peer+split", True, "sum"), ("peer+split", False, "mean"),
+                                                    ("native+split", True, "sum"), ("native+split", False, "mean"),
+                                                    ("peer+notiles+split", True, "sum"), ("peer+2phase+split", True, "sum")])
 def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, monkeypatch):
     """The data-parallel code path (backward -> all-reduce SUM of the gradient vector -> Adam; normalizer
     begin -> all-reduce MEAN -> end; parameter broadcast) run in a 1-rank RCCL group must reproduce the
@@ -428,6 +434,10 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
     import socket
     import torch.distributed as dist
     from rl_arm_under_sparse_reward_amd.utils import Communicator
+    split = transport.endswith("+split")
+    if split:                           # the 4-update sequences of _run_cycles take the split form only when forced
+        transport = transport[:-6]
+        monkeypatch.setenv("RLARM_SPLIT", "1")
     if transport.endswith("+2phase"):   # reduce-scatter + all-gather form of the peer exchange (one rank: one slice)
         transport = transport[:-7]
         monkeypatch.setenv("RLARM_PEER_PHASES", "2")
@@ -458,6 +468,8 @@ def test_rccl_path_world1_equals_single_rank_bitwise(transport, graph, reduce, m
         assert (comm.native is not None) == (transport == "native")
         assert (comm.peer is not None) == (transport == "peer")      # one-shot exchange over peer memory (csrc/peer.hip)
         got = _run_cycles(agent, graph=graph)
+        first = agent.update_kernels(4)["updates"][1][0]
+        assert first.startswith("k_fb_split8<") == split and (not split or first != "k_fb_split8<0>"), first
         _lib.Context.default().synchronize()
         torch.cuda.synchronize()
         agent.close_comm()

@@ -4,6 +4,17 @@ per-launch sequence of one update step (durations in us).  Usage: trace_summary.
 import sqlite3
 import sys
 
+
+def short_kernel(name):
+    """'void s8r4::k_fb_split8<0>(unsigned long long, ...)' -> 'k_fb_split8<0>': no return type, namespace or argument list
+    (what csrc's launch log -- hp_agent_update_kernels -- calls the kernel, and what bench.py looks a committed average up by;
+    bench.py carries the same five lines)."""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("(")[0].split("::")[-1]
+
+
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
 # the split launch's prologue (target chains of a sequence's first update only: a much smaller grid) is listed on its own row
@@ -23,13 +34,13 @@ except Exception:   # noqa: BLE001
     pass
 print(f"{'kernel':44s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'share':>6s}")
 for r in rows:
-    nm = r[0] if "[prologue" not in r[0] else r[0].split("(")[0] + "[prologue]"
+    nm = short_kernel(r[0].split("[prologue")[0]) + ("[prologue]" if "[prologue" in r[0] else "")   # (first column: no spaces)
     print(f"{nm[:44]:44s} {r[1]:7d} {r[2]/1e3:8.2f} {r[3]/1e3:8.2f} {r[4]/1e3:8.2f} {100*r[5]/tot:5.1f}%")
 ks = cur.execute("select start,end,name,grid_x from kernels order by start").fetchall()
-g = [i for i, k in enumerate(ks) if k[2].startswith("k_gather_fused")]
+g = [i for i, k in enumerate(ks) if short_kernel(k[2]).startswith(("k_fb_split8", "k_fb_slab"))]
 if len(g) > 4:
     i0 = g[len(g) // 2]
     i1 = g[len(g) // 2 + 1]
     seq = ks[i0:i1]
-    print("one update step:", " ".join(f"{k[2].split('(')[0][2:8]}:{(k[1]-k[0])/1e3:.1f}" for k in seq),
+    print("one update step:", " ".join(f"{short_kernel(k[2])}:{(k[1]-k[0])/1e3:.1f}" for k in seq),
           f"| total {(seq[-1][1]-seq[0][0])/1e3:.1f} us, {len(seq)} launches")
