@@ -1014,7 +1014,7 @@ def sample_kernel_fused_fields(a, r):
                 if short_kernel(k).startswith("k_gather_fused") and v.get("batch") == (1 << 18):
                     traffic, tsrc = v["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
     return {
-        "bound": "hbm", "kernel": "k_gather_fused (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 device tensors)",
+        "bound": "hbm", "kernel": "k_gather_fused2 (hp_buffer_sample_dev: gather + relabel + reward + clip + normalise -> float32 device tensors; 16-byte loads, two transitions per wavefront instruction)",
         "achieved": big["achieved_GBps_528B"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(big["achieved_GBps_528B"] / HBM_PEAK_GBPS, 5),
         "bytes_per_transition": 528, "bytes_per_transition_this_build": 812,
         "achieved_this_build_bytes": big["achieved_GBps_812B_this_build"],

@@ -817,10 +817,16 @@ int hp_agent_update_kernels(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn,
     HP_SERIALISE(a);
     HP_REQUIRE(out && out_len > 0 && n_updates > 0, HP_ERR_INVALID, "hp_agent_update_kernels: bad argument");
     HP_REQUIRE(!a->prof, HP_ERR_STATE, "hp_agent_update_kernels: not in profiling mode (its launches are bracketed by events)");
-    hipStream_t s = a->ctx->stream;
-    HP_REQUIRE(s != hipStreamLegacy, HP_ERR_STATE, "hp_agent_update_kernels: the legacy default stream cannot be captured");
+    // nothing of the capture ever runs, so it need not be taken on the stream the context is bound to: a context on the legacy
+    // default stream (a host-driven torch.distributed loop), which cannot be captured, borrows its own stream for the log
+    hipStream_t bound = a->ctx->stream, s = (bound == hipStreamLegacy || bound == hipStreamPerThread) ? a->ctx->own_stream : bound;
     HP_TRY(ensure_plan(a, n_updates));
-    HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_CHECK_HIP(hipStreamSynchronize(bound));
+    struct Rebind {   // every launch site reads ctx->stream
+        hp_ctx *c; hipStream_t keep;
+        ~Rebind() { c->stream = keep; }
+    } rebind{a->ctx, bound};
+    a->ctx->stream = s;
     std::vector<std::string> log;
     hipGraph_t graph = nullptr;
     unsigned *pending = a->split_reset_pending;

@@ -169,6 +169,119 @@ __global__ __launch_bounds__(256) void k_gather_fused(const FusedSampleArgs A) {
     }
 }
 
+// The same kernel with 16-byte loads and TWO transitions per wavefront instruction (round 6).  A transition's sources are three
+// vectors of doubles -- the contiguous [obs t | obs t+1] run (2 od), g' (gd), the action (ad) -- cut into units of two doubles: od +
+// ceil(gd / 2) + ceil(ad / 2) units = 31 for the bmirobot shapes (27, 3, 4), so 32 lanes carry a transition with ONE 16-byte load
+// each (rows are 8-byte aligned; the last unit of an odd-length vector loads [len - 2, len - 1] and keeps its second double, so no
+// load reads past a row) and a wavefront instruction carries two.  Against k_gather_fused: half the load instructions per
+// transition for the same bytes, 2 x FLIGHT transitions in flight per wavefront instead of FLIGHT, the normalizers' mean / std
+// fetched once per lane instead of once per pass, g' of the reward taken from the units already loaded (one extra 8-byte load per
+// transition pair for ag[t + 1] instead of two).  Same arithmetic per element: identical bits.  Shapes that do not fit 32 lanes
+// take k_gather_fused.
+#ifndef FS2_FLIGHT
+#define FS2_FLIGHT 4
+#endif
+typedef double fs_d2 __attribute__((ext_vector_type(2), aligned(8)));
+template <int FLIGHT>
+__global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) {
+    const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int od = A.od, gd = A.gd, ad = A.ad, ldx = od + gd;
+    const int ug = (gd + 1) >> 1, ua = (ad + 1) >> 1;
+    // this lane's unit: 0 = two doubles of the [obs t | obs t+1] run, 1 = of g', 2 = of the action, 3 = none
+    const int unit = l < od ? 0 : l < od + ug ? 1 : l < od + ug + ua ? 2 : 3;
+    const int j = unit == 0 ? l : unit == 1 ? l - od : l - od - ug;
+    const int len = unit == 0 ? 2 * od : unit == 1 ? gd : ad;
+    const bool tail = unit != 3 && 2 * j + 1 >= len;      // last unit of an odd-length vector
+    const int e0 = unit == 3 ? 0 : (tail ? len - 2 : 2 * j);
+    // per slot (the unit's two doubles): which output it feeds.  dst 0: x, 1: x_next, 2: actions, -1: nothing
+    int dst[2], off[2];
+    float mu[2] = {0.f, 0.f};
+    double sd[2] = {1.0, 1.0}, clip[2] = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int el = e0 + s;
+        const bool ok = unit != 3 && !(tail && s == 0);
+        dst[s] = -1;
+        off[s] = 0;
+        if (ok && unit == 0) {
+            const int col = el < od ? el : el - od;
+            dst[s] = el < od ? 0 : 1;
+            off[s] = col;
+            mu[s] = A.onz->mean[col]; sd[s] = A.onz->std[col]; clip[s] = A.clip_o;
+        } else if (ok && unit == 1) {
+            dst[s] = 0;                 // ... and x_next: g_next := g (ddpg_agent.py:231)
+            off[s] = od + el;
+            mu[s] = A.gnz->mean[el]; sd[s] = A.gnz->std[el]; clip[s] = A.clip_g;
+        } else if (ok) {
+            dst[s] = 2;
+            off[s] = el;
+        }
+    }
+    // reward operands: lanes l < gd of each half hold component l.  g'[c] sits in lane od + (c / 2) -- the last unit for the last
+    // component of an odd gd -- slot c % 2 (slot 1 there)
+    const int rc = l < gd ? l : gd - 1;
+    const bool rc_tail = (gd & 1) && rc == gd - 1;
+    const int g_lane = (h << 5) + od + (rc_tail ? ug - 1 : (rc >> 1)), g_slot = rc_tail ? 1 : (rc & 1);
+    for (long long base = wave * (2 * FLIGHT); base < A.batch; base += n_waves * (2 * FLIGHT)) {
+        PlanRec rec[FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {
+            const long long m = base + 2 * k + h;
+            rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+        }
+        fs_d2 v[FLIGHT];
+        double ra[FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {      // every load of the pass before the first use
+            const long long e = rec[k].e;
+            const int t = rec[k].t;
+            const double *obs0 = A.obs + (e * (A.T + 1) + t) * od;
+            const double *g_src = rec[k].her ? A.ag + (e * (A.T + 1) + rec[k].fut) * gd : A.g + (e * A.T + t) * gd;   // her.py:35-36
+            const double *p = unit == 0 ? obs0 + e0 : unit == 1 ? g_src + e0 : unit == 2 ? A.act + (e * A.T + t) * ad + e0 : obs0;
+            v[k] = *reinterpret_cast<const fs_d2 *>(p);
+            ra[k] = A.ag[(e * (A.T + 1) + t + 1) * gd + rc];
+        }
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {
+            const long long m = base + 2 * k + h;
+            const bool live = m < A.batch;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const double val = s ? v[k].y : v[k].x;
+                if (!live || dst[s] < 0) continue;
+                if (dst[s] == 2) {
+                    if (A.a) A.a[m * ad + off[s]] = (float)val;
+                    continue;
+                }
+                double c = fmin(fmax(val, -A.clip_obs), A.clip_obs);                    // _preproc_og
+                c = __ddiv_rn(__dsub_rn(c, (double)mu[s]), sd[s]);                       // normalizer.normalize
+                const float x = (float)fmin(fmax(c, -clip[s]), clip[s]);
+                if (dst[s] == 0) { if (A.x) A.x[m * ldx + off[s]] = x; }
+                else if (A.xn) A.xn[m * ldx + off[s]] = x;
+                if (unit == 1 && A.xn) A.xn[m * ldx + off[s]] = x;
+            }
+            // reward (her.py:38): (ag_next - g')^2 per component in lanes l < gd, lane 0 of the half adds them left to right
+            const double gx = __shfl(v[k].x, g_lane), gy = __shfl(v[k].y, g_lane);
+            const double d = __dsub_rn(ra[k], g_slot ? gy : gx);
+            const double sq = __dmul_rn(d, d);
+            double sum = 0.0;
+            for (int c = 0; c < gd; ++c) {
+                const double sc = __shfl(sq, (h << 5) + c);
+                sum = (c == 0) ? sc : __dadd_rn(sum, sc);
+            }
+            if (live && l == 0) {
+                if (A.r) A.r[m] = hp_reward(sum, A.sq_threshold);
+                if (A.o_e) A.o_e[m] = rec[k].e;
+                if (A.o_t) A.o_t[m] = rec[k].t;
+                if (A.o_fut) A.o_fut[m] = rec[k].fut;
+                if (A.o_her) A.o_her[m] = (unsigned char)rec[k].her;
+            }
+        }
+    }
+}
+
 // Batched compute_reward / _is_success of the bmirobot GoalEnvs (bmirobot_env_push_F.py:84-90, :243-245; identical in
 // bmirobot_env_pickandplace_v2.py) on device arrays [n][goal_dim] float64.  mode 0: sparse reward -(d > thr) as float32
 // (bits 0x80000000 / 0xBF800000); mode 1: dense reward -d as float64; mode 2: success (d < thr) as float32.
@@ -551,11 +664,26 @@ static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_no
     A.o_e = reinterpret_cast<long long *>(o->e); A.o_t = reinterpret_cast<long long *>(o->t);
     A.o_fut = reinterpret_cast<long long *>(o->future_t);
     A.o_her = o->her;
+    const int64_t cap = (int64_t)b->ctx->cu_count * 32;           // grid-stride beyond 32 workgroups per compute unit
+    const int ug = (b->goal_dim + 1) / 2, ua = (b->act_dim + 1) / 2;
+    if (b->obs_dim + ug + ua <= 32 && b->goal_dim >= 2 && b->act_dim >= 2) {
+        // 16-byte loads, two transitions per wavefront instruction (k_gather_fused2): the reference's shapes
+        HP_KLOG("k_gather_fused2");
+        if (batch >= 16384) {
+            const int64_t waves = (batch + 2 * FS2_FLIGHT - 1) / (2 * FS2_FLIGHT), wgs = (waves + 3) / 4;
+            hipLaunchKernelGGL(k_gather_fused2<FS2_FLIGHT>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+        } else {
+            const int64_t waves = (batch + 1) / 2, wgs = (waves + 3) / 4;
+            hipLaunchKernelGGL(k_gather_fused2<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+        }
+        HP_CHECK_HIP(hipGetLastError());
+        return HP_OK;
+    }
     // (us per 262144 transitions of a 5000-episode shard: 4 in flight, grid capped at 8 / 32 workgroups per CU 126.8 / 121.0; 8 in
     // flight 133.6; 2 in flight, cap 16: 130.5; 1 in flight, cap 64: 124.0 -- ~2.1 G transitions/s whatever the shape of the launch)
     const int flight = batch >= 16384 ? 4 : 1;
     const int64_t waves = (batch + flight - 1) / flight, wgs = (waves + 3) / 4;
-    const int64_t cap = (int64_t)b->ctx->cu_count * 32;           // grid-stride beyond 32 workgroups per compute unit
+    HP_KLOG("k_gather_fused");
     if (flight == 4) hipLaunchKernelGGL(k_gather_fused<4>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
     else hipLaunchKernelGGL(k_gather_fused<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
     HP_CHECK_HIP(hipGetLastError());

@@ -366,6 +366,48 @@ def test_sample_device_matches_oracle_at_baseline_sizes(n, B, k, mode, clip_obs)
     assert set(np.unique(got["r"].cpu().numpy().view(np.uint32))) <= {0x80000000, 0xBF800000}
 
 
+@pytest.mark.parametrize("od,gd,ad,B", [(12, 5, 3, 700), (7, 2, 2, 20000), (40, 3, 4, 513), (27, 3, 4, 19999), (30, 1, 4, 300)])
+def test_sample_device_other_shapes_take_the_right_kernel_and_stay_bit_exact(od, gd, ad, B):
+    """Round 6: the fused sampler packs a transition into 32 lanes of 16-byte loads (k_gather_fused2) when obs + ceil(goal / 2) +
+    ceil(act / 2) <= 32 -- the reference's (27, 3, 4) -- and keeps the one-element-per-lane kernel for anything else.  Odd goal /
+    action widths (a unit's tail loads [len - 2, len - 1], never past the row), a shape too wide for 32 lanes, a 1-wide goal, and
+    the reference's shape at a ragged grid-striding batch: all bit-equal to the oracle, rewards and indices included."""
+    from oracle.running_norm import RunningNorm
+    from rl_arm_under_sparse_reward_amd.normalizer import normalizer
+    from gpu_common import ctx
+
+    n, T = 23, 100
+    rs0 = np.random.RandomState(77)
+    obs = rs0.uniform(-1, 1, (n, T + 1, od))
+    ag = rs0.uniform(0, 0.3, (n, T + 1, gd))
+    ag[:, 1::7] = ag[:, 0:-1:7][:, :ag[:, 1::7].shape[1]]          # some exact successes beside the relabelled ones
+    g = np.repeat(rs0.uniform(0, 0.3, (n, 1, gd)), T, axis=1)
+    act = rs0.uniform(-0.5, 0.5, (n, T, ad))
+    eps = [obs, ag, g, act]
+    on, gn = RunningNorm(od, default_clip_range=5), RunningNorm(gd, default_clip_range=5)
+    o_dev, g_dev = normalizer(od, default_clip_range=5, ctx=ctx()), normalizer(gd, default_clip_range=5, ctx=ctx())
+    for a_, b_, v in ((on, o_dev, obs[:, 3] * 2.0 + 0.1), (gn, g_dev, ag[:, 5])):
+        a_.update(v); b_.update(v)
+        a_.recompute_stats(); b_.recompute_stats()
+    st = EpisodeStore(T, od, gd, ad, n * T)
+    rs = np.random.RandomState(31)
+    st.store_episode(eps, rs)
+    dev = fresh_rng(31)
+    buf = DeviceEpisodeBuffer(n, T, od, gd, ad)
+    buf.store(dev, eps)
+    for _ in range(2):
+        ref, ridx = st.sample(B, 0.8, rs)
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, 0.8, squared_threshold(0.05), 0.7, with_indices=True)
+        from oracle.ddpg_update import minibatch_tensors
+        x, xn, a, r = (t.numpy() for t in minibatch_tensors(ref, on, gn, 0.7))
+        for key, want in (("x", x), ("x_next", xn), ("actions", a), ("r", r)):
+            assert np.array_equal(bits(got[key].cpu().numpy()), bits(want)), key
+        for key in ("e", "t", "future_t"):
+            assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), key
+    assert state_equal(dev, *rs.get_state()[1:3])
+    assert len(set(np.unique(got["r"].cpu().numpy().view(np.uint32)))) == 2        # both reward values occur
+
+
 def test_sample_device_dense_reward_partial_outputs_and_errors():
     """Dense reward (compute_reward :89-90 narrowed to float32 as ddpg_agent.py:243 does), NULL outputs, and the reference's
     error on an empty buffer."""

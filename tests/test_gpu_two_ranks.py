@@ -90,7 +90,7 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     rng = DeviceRandomState(seed)
     agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100), None, dict(ENV_PARAMS), comm=comm, rng=rng)
     assert agent._native_comm is None        # gloo group: no RCCL (two ranks share one device)
-    kernels = agent.update_kernels(N_UP)["updates"][2]
+    kernels = agent.update_kernels(N_UP)["updates"][-1]      # (a host-driven exchange reports ONE update)
     if split:
         assert kernels[0] == ("k_fb_split8<1>" if transport.startswith("peertiles") else "k_fb_split8<2>"), kernels
     elif transport != "torch":

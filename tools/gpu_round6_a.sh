@@ -4,19 +4,18 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/r06a; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -5 $O/pytest.log
-B="python bench.py --steps 4000 --warmup 400 --no-cpu-baseline --no-profile"
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -15 $O/pytest.log
+B="python bench.py --steps 4000 --warmup 400 --no-cpu-baseline"
 $B > $O/bench_b256.log 2>&1; tail -1 $O/bench_b256.log > $O/bench_n1_b256.json
 RLARM_BENCH_FORCE_DP=1 $B > $O/dp.log 2>&1; tail -1 $O/dp.log > $O/bench_n1_b256_forced_dp_world1.json
 RLARM_BENCH_FORCE_DP=1 RLARM_PEER_TILES=0 $B > $O/dp0.log 2>&1; tail -1 $O/dp0.log > $O/bench_n1_b256_forced_dp_world1_separate_exchange_launch.json
 RLARM_BENCH_FORCE_DP=1 RLARM_COMM=rccl $B > $O/dpr.log 2>&1; tail -1 $O/dpr.log > $O/bench_n1_b256_forced_dp_world1_rccl.json
-RLARM_BENCH_FORCE_DP=1 RLARM_SPLIT=0 $B > $O/dps0.log 2>&1; tail -1 $O/dps0.log > $O/bench_n1_b256_forced_dp_world1_two_launch.json
-RLARM_BENCH_FORCE_DP=1 RLARM_COMM=rccl RLARM_SPLIT=0 $B > $O/dprs0.log 2>&1; tail -1 $O/dprs0.log > $O/bench_n1_b256_forced_dp_world1_rccl_two_launch.json
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read())
-    print(sys.argv[1].split('/')[-1], round(d['ms_per_step']*1e3,3), 'us/update', d['config'].get('exchange'), d['config']['engine'].get('kernels_per_update'))
+    r=d.get('roofline',{})
+    print(sys.argv[1].split('/')[-1], round(d['ms_per_step']*1e3,3), 'us/update', d['config'].get('exchange'), d['config']['engine'].get('kernels_per_update'), r.get('kernel'), r.get('frac'), r.get('avg_launch_us'))
 except Exception as e:
     print(sys.argv[1], 'unreadable', e)
 PY
