@@ -996,7 +996,7 @@ def sample_kernel_fused_fields(a, r):
     fused = {}
     for nb, reps in ((a.batch, 200), (1 << 18, 20)):
         _l.check(r.ctx.lib.hp_buffer_sample_dev_us(buf.h, r.rng.h, r.agent.o_norm.h, r.agent.g_norm.h, nb,
-                                                   float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, reps,
+                                                   float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, reps, 0,
                                                    C.byref(fd), C.byref(fg)))
         fused[nb] = {"batch": nb, "avg_launch_us": round(fg.value, 3), "index_draw_kernel_us": round(fd.value, 3),
                      "achieved_GBps_528B": round(528 * nb / (fg.value * 1e-6) / 1e9, 2),

@@ -39,7 +39,8 @@ extern "C" {
  * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
  * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  3 (round 5): hp_buffer_sample_dev (device-output fused
  * sampler) was added.  4 (round 6): hp_ctx_get_stream was added (a host that hands device outputs to a framework orders the
- * framework's stream with the context's through events instead of rebinding the context).  hp_abi_version() returns the
+ * framework's stream with the context's through events instead of rebinding the context), and the sampler's throughput mode
+ * (hp_buffer_enable_f32_rows, hp_buffer_sample_dev_f32).  hp_abi_version() returns the
  * library's value; a host must refuse a library whose version differs from the header it was built against. */
 #define HP_ABI_VERSION 4
 
@@ -159,6 +160,17 @@ typedef struct {
 } hp_sample_dev_out;
 int hp_buffer_sample_dev(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
                          double sq_threshold, double clip_obs, const hp_sample_dev_out *dev_out);
+/* Throughput mode of the sampler (SURVEY 8b's `storage_dtype` = fp32; opt-in, NOT bit-identical to the reference's float64 rows):
+ * hp_buffer_enable_f32_rows builds -- from what the buffer holds now, and behind every later store -- a float32 mirror of the
+ * observations and actions laid out for the gather (one (episode, timestep) per 128-byte line: obs_t | action_t), the goals
+ * staying float64.  hp_buffer_sample_dev_f32 = hp_buffer_sample_dev reading that mirror: same stream, same draws, indices,
+ * relabelled goals (her.py:35-36), rewards (:38) and goal columns of x / x_next BIT-identical; actions identical (the learner takes
+ * float32(actions) either way); the observation columns are those of float32-rounded observations (replay_buffer.py:23-27 stores
+ * float64), about half the bytes per transition.  Needs obs_dim + act_dim <= 32.  The float64 arrays stay the source of truth:
+ * hp_buffer_sample / hp_buffer_sample_dev / the fused learner are unaffected. */
+int hp_buffer_enable_f32_rows(hp_buffer *buf);
+int hp_buffer_sample_dev_f32(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
+                             double sq_threshold, double clip_obs, const hp_sample_dev_out *dev_out);
 
 /* ---- GoalEnv reward / success as batched device ops --------------------------------------------
  * compute_reward (bmirobot_env_push_F.py:84-90 -> goal_distance :20-23; byte-identical in

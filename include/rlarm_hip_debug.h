@@ -30,9 +30,9 @@ int hp_buffer_sample_device_us(hp_buffer *buf, hp_rng *rng, int64_t batch, doubl
                                int32_t reps, double *draw_us, double *gather_us);
 
 /* the same for hp_buffer_sample_dev's fused kernel (gather + relabel + reward + clip + normalise -> float32, device outputs
- * into library scratch) */
+ * into library scratch); f32_rows != 0: hp_buffer_sample_dev_f32's kernel on the throughput rows */
 int hp_buffer_sample_dev_us(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
-                            double sq_threshold, double clip_obs, int32_t reps, double *draw_us, double *gather_us);
+                            double sq_threshold, double clip_obs, int32_t reps, int32_t f32_rows, double *draw_us, double *gather_us);
 
 /* test hook: load torch.optim.Adam state (exp_avg, exp_avg_sq in the flat order of utils.py:18-27; either may be NULL) and the
  * number of optimizer steps already taken (shared by both optimizers, ddpg_agent.py:272,277 step together) */

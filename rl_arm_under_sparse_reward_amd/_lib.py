@@ -90,7 +90,10 @@ PROTOTYPES = {
     "hp_buffer_sample_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                        C.c_double, C.POINTER(SampleDevOut)]),
     "hp_buffer_sample_dev_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
-                                          C.c_double, C.c_int32, f64p, f64p]),
+                                          C.c_double, C.c_int32, C.c_int32, f64p, f64p]),
+    "hp_buffer_enable_f32_rows": (C.c_int, [C.c_void_p]),
+    "hp_buffer_sample_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                           C.c_double, C.POINTER(SampleDevOut)]),
     "hp_buffer_destroy": (None, [C.c_void_p]),
     "hp_compute_reward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p]),

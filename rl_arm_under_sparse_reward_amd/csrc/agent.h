@@ -424,6 +424,10 @@ struct GatherCtx {   // where the minibatch comes from (nullptr plan = inputs al
     int peer_u = -1;
     const PlanRec *t_plan = nullptr;
 };
+// what the in-launch weight-gradient tiles of k_fb_split8 do behind their products (slab8_split.h: one instantiation per form)
+enum { SPLIT_TILES_ADAM = 0,   // single rank: optimizer step of the critic inside the launch (behind the actor-side chains' gates)
+       SPLIT_TILES_PEER = 1,   // data-parallel ranks, one device each: rank exchange tile by tile, then the same step (utils.py:43-48 + Adam)
+       SPLIT_TILES_GRADS = 2 };// gradients only: exchange (RCCL, two-phase / gated peer memory) + optimizer follow as launches of their own
 #define SPLIT_MIN_UPDATES 12  // shorter sequences keep the two-launch form: the prologue launch costs ~17 us per sequence, an update gains ~1.4
 
 // workgroups of the chain kernel that carry chains (the spare ones -- index plan, look-ahead gather, L2 warmers -- follow)
@@ -445,7 +449,7 @@ int enqueue_forward_backward_slab(hp_agent *a, const GatherCtx *gc, bool fuse_ad
 bool split_fits(const hp_agent *a);
 bool split_fits_rows(const hp_agent *a, int rows);
 // ... and its prologue: the target chains of a sequence's FIRST update (plan = that update's index plan) into Q' set 0
-int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc);
+int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc, int tiles_mode);   // tiles_mode: SPLIT_TILES_* of the sequence's updates
 // a bounded in-launch hand-off gave up earlier (k_cycle_open, k_fb_split8): HP_ERR_STATE + message; free for the host
 int agent_check_fault(const hp_agent *a, const char *who);
 int enqueue_adam(hp_agent *a, bool polyak_after = false);   // polyak_after: see GatherCtx (slab engines; returns whether via *folded)

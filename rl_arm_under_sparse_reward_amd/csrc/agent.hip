@@ -108,7 +108,8 @@ static int enqueue_updates(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, 
     if (split) {
         HP_KLOG("#prologue");
         GatherCtx g0{b, on, gn, a->plan.as<PlanRec>(), sq};
-        HP_TRY(enqueue_split_prologue(a, &g0));
+        const bool fuse = with_adam && !a->comm && (!a->peer || peer_tiles_ok(a));   // (as for the updates below)
+        HP_TRY(enqueue_split_prologue(a, &g0, !fuse ? SPLIT_TILES_GRADS : (a->peer ? SPLIT_TILES_PEER : SPLIT_TILES_ADAM)));
     }
     for (int u = 0; u < n_updates; ++u) {
         HP_KLOG("#update");

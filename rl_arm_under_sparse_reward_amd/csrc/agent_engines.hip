@@ -936,7 +936,7 @@ static int enqueue_split_update(hp_agent *a, const GatherCtx *gc, FbBuilt &built
 }
 
 // target chains of the sequence's first update (its plan: gc->plan) -> Q' set 0; also clears the first update's counter set
-int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
+int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc, int tiles_mode) {
     HP_REQUIRE(gc && split_fits(a), HP_ERR_STATE, "split launch: not available for this engine");
     FbBuilt built;
     GatherCtx g0 = *gc;
@@ -963,7 +963,7 @@ int enqueue_split_prologue(hp_agent *a, const GatherCtx *gc) {
     Q.s = P;
     const unsigned grid = build_split_roles(a, Q, false, true, 0, 0, 0);
     ProfScope ps(a, PROF_PLAN);   // (once per sequence, with the index draws: not an update's launch)
-    launch_split(grid, a->ctx->stream, Q);
+    launch_split(grid, a->ctx->stream, Q, tiles_mode);   // (no tiles here: the instantiation the sequence's updates run, so that a rank executes ONE k_fb_split8)
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
 }

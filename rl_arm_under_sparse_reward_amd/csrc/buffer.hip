@@ -282,6 +282,171 @@ __global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) 
     }
 }
 
+// ---- throughput rows (SURVEY 8b storage_dtype = fp32; hp_buffer_enable_f32_rows / hp_buffer_sample_dev_f32) -----------------------
+// The float64 arrays above are the reference's layout and stay the source of truth.  The mirror below is laid out for the
+// gather instead: one (episode, timestep) = ONE 128-byte line of float32 [obs_t | action_t | 0], so a transition's
+// observations and action are two adjacent, line-aligned lines (the float64 rows are a 432-byte run at any 8-byte offset:
+// 4.4 lines, plus a line for the action); the goals stay float64 -- the reward and the relabelled goal are bit-exact as before --
+// as [ag_t | g_t | 0] per 64 bytes, so ag[t + 1] and g[t] share 128 bytes.  PMC, 2^18 transitions: 947 B fetched per transition
+// from the float64 rows (7.4 lines), 5xx from these.  Observations and actions are rounded to float32 at store time (actions
+// lose nothing the learner sees: it consumes float32(actions)); the normaliser arithmetic on them is unchanged (float64).
+__global__ __launch_bounds__(256) void k_pack_rows(const long long *__restrict__ slots, long long n, long long first,
+                                                   const double *__restrict__ obs, const double *__restrict__ ag,
+                                                   const double *__restrict__ g, const double *__restrict__ act, float *p_row,
+                                                   double *p_goal, int T, int od, int gd, int ad, int row_w, int goal_w) {
+    // one workgroup per (episode, block of 8 timesteps); slots == nullptr: episodes first .. first + n - 1
+    const long long i = blockIdx.x / ((T + 8) / 8);
+    const int t0 = (int)(blockIdx.x % ((T + 8) / 8)) * 8;
+    const long long e = slots ? slots[i] : first + i;
+    for (int idx = threadIdx.x; idx < 8 * row_w; idx += blockDim.x) {
+        const int t = t0 + idx / row_w, c = idx % row_w;
+        if (t > T) continue;
+        float v = 0.f;
+        if (c < od) v = (float)obs[(e * (T + 1) + t) * od + c];
+        else if (c < od + ad && t < T) v = (float)act[(e * T + t) * ad + (c - od)];
+        p_row[(e * (T + 1) + t) * row_w + c] = v;
+    }
+    for (int idx = threadIdx.x; idx < 8 * goal_w; idx += blockDim.x) {
+        const int t = t0 + idx / goal_w, c = idx % goal_w;
+        if (t > T) continue;
+        double v = 0.0;
+        if (c < gd) v = ag[(e * (T + 1) + t) * gd + c];
+        else if (c < 2 * gd && t < T) v = g[(e * T + t) * gd + (c - gd)];
+        p_goal[(e * (T + 1) + t) * goal_w + c] = v;
+    }
+}
+
+// hp_buffer_sample_dev on the throughput rows.  32 lanes per transition, two transitions per wavefront instruction, one 16-byte
+// load per lane: lanes 0 .. 2 row_w / 4 - 1 the two adjacent row lines (row t, row t + 1), then ceil(gd / 2) lanes ag[t + 1],
+// ceil(gd / 2) lanes g' (= ag[future_t] when relabelled, her.py:35-36, else the g half of goal row t).
+struct PackedSampleArgs {
+    const float *p_row;
+    const double *p_goal;
+    int row_w, goal_w;
+    FusedSampleArgs f;
+};
+template <int FLIGHT>
+__global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P) {
+    const FusedSampleArgs &A = P.f;
+    const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int od = A.od, gd = A.gd, ad = A.ad, ldx = od + gd, rw = P.row_w, gw = P.goal_w;
+    const int rl = rw >> 2, ug = (gd + 1) >> 1;          // lanes per row line, lanes per goal vector
+    // unit: 0 row t, 1 row t + 1 (float4 each), 2 ag[t + 1], 3 g' (two doubles each), 4 none
+    const int unit = l < rl ? 0 : l < 2 * rl ? 1 : l < 2 * rl + ug ? 2 : l < 2 * rl + 2 * ug ? 3 : 4;
+    const int j = unit == 0 ? l : unit == 1 ? l - rl : unit == 2 ? l - 2 * rl : l - 2 * rl - ug;
+    // row lanes: columns 4 j .. 4 j + 3 of the line; per component where it goes (dst 0: x, 1: x_next, 2: actions, -1: nowhere)
+    int dst[4], off[4];
+    float mu[4] = {0.f, 0.f, 0.f, 0.f};
+    double sd[4] = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = 4 * j + c;
+        dst[c] = -1;
+        off[c] = 0;
+        if (unit <= 1 && col < od) {
+            dst[c] = unit;
+            off[c] = col;
+            mu[c] = A.onz->mean[col];
+            sd[c] = A.onz->std[col];
+        } else if (unit == 0 && col < od + ad) {
+            dst[c] = 2;
+            off[c] = col - od;
+        }
+    }
+    // goal lanes: doubles 2 j, 2 j + 1 of the vector (the last unit of an odd gd keeps its FIRST double only; the rows are padded)
+    float gmu[2] = {0.f, 0.f};
+    double gsd[2] = {1.0, 1.0};
+    bool gok[2] = {false, false};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int c = 2 * j + s;
+        if (unit == 3 && c < gd) {
+            gok[s] = true;
+            gmu[s] = A.gnz->mean[c];
+            gsd[s] = A.gnz->std[c];
+        }
+    }
+    const int rc = l < gd ? l : gd - 1;                   // reward: lanes l < gd of each half hold component l
+    const int a_lane = (h << 5) + 2 * rl + (rc >> 1), g_lane = a_lane + ug, r_slot = rc & 1;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    union Ld { f4_t f; d2_t d; };
+    for (long long base = wave * (2 * FLIGHT); base < A.batch; base += n_waves * (2 * FLIGHT)) {
+        PlanRec rec[FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {
+            const long long m = base + 2 * k + h;
+            rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+        }
+        Ld v[FLIGHT];
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {      // every load of the pass before the first use
+            const long long e = rec[k].e;
+            const int t = rec[k].t;
+            const float *row = P.p_row + (e * (A.T + 1) + t) * rw;
+            const double *goal_t = P.p_goal + (e * (A.T + 1) + t) * gw;
+            // g': the ag half of goal row future_t, or the g half of goal row t.  The g half starts at double gd: a 16-byte load of
+            // doubles [gd + 2 j, gd + 2 j + 1] is 8-byte aligned, like the float64 rows' loads
+            const double *gsrc = rec[k].her ? P.p_goal + (e * (A.T + 1) + rec[k].fut) * gw : goal_t + gd;
+            const void *p = unit <= 1 ? (const void *)(row + 4 * l) : unit == 2 ? (const void *)(goal_t + gw + 2 * j)
+                          : unit == 3 ? (const void *)(gsrc + 2 * j) : (const void *)row;
+            typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+            const f4_a8 raw = *reinterpret_cast<const f4_a8 *>(p);
+            v[k].f = raw;
+        }
+#pragma unroll
+        for (int k = 0; k < FLIGHT; ++k) {
+            const long long m = base + 2 * k + h;
+            const bool live = m < A.batch;
+            if (unit <= 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!live || dst[c] < 0) continue;
+                    const float raw = v[k].f[c];
+                    if (dst[c] == 2) {
+                        if (A.a) A.a[m * ad + off[c]] = raw;
+                        continue;
+                    }
+                    double x = fmin(fmax((double)raw, -A.clip_obs), A.clip_obs);           // _preproc_og
+                    x = __ddiv_rn(__dsub_rn(x, (double)mu[c]), sd[c]);                     // normalizer.normalize
+                    const float o = (float)fmin(fmax(x, -A.clip_o), A.clip_o);
+                    if (dst[c] == 0) { if (A.x) A.x[m * ldx + off[c]] = o; }
+                    else if (A.xn) A.xn[m * ldx + off[c]] = o;
+                }
+            } else if (unit == 3) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (!live || !gok[s]) continue;
+                    double x = fmin(fmax(v[k].d[s], -A.clip_obs), A.clip_obs);
+                    x = __ddiv_rn(__dsub_rn(x, (double)gmu[s]), gsd[s]);
+                    const float o = (float)fmin(fmax(x, -A.clip_g), A.clip_g);
+                    if (A.x) A.x[m * ldx + od + 2 * j + s] = o;
+                    if (A.xn) A.xn[m * ldx + od + 2 * j + s] = o;                          // g_next := g (ddpg_agent.py:231)
+                }
+            }
+            // reward (her.py:38) on the float64 goals: the same left-to-right sum as every other gather
+            const double ax = __shfl(v[k].d[0], a_lane), ay = __shfl(v[k].d[1], a_lane);
+            const double gx = __shfl(v[k].d[0], g_lane), gy = __shfl(v[k].d[1], g_lane);
+            const double d = __dsub_rn(r_slot ? ay : ax, r_slot ? gy : gx);
+            const double sq = __dmul_rn(d, d);
+            double sum = 0.0;
+            for (int c = 0; c < gd; ++c) {
+                const double sc = __shfl(sq, (h << 5) + c);
+                sum = (c == 0) ? sc : __dadd_rn(sum, sc);
+            }
+            if (live && l == 0) {
+                if (A.r) A.r[m] = hp_reward(sum, A.sq_threshold);
+                if (A.o_e) A.o_e[m] = rec[k].e;
+                if (A.o_t) A.o_t[m] = rec[k].t;
+                if (A.o_fut) A.o_fut[m] = rec[k].fut;
+                if (A.o_her) A.o_her[m] = (unsigned char)rec[k].her;
+            }
+        }
+    }
+}
+
 // Batched compute_reward / _is_success of the bmirobot GoalEnvs (bmirobot_env_push_F.py:84-90, :243-245; identical in
 // bmirobot_env_pickandplace_v2.py) on device arrays [n][goal_dim] float64.  mode 0: sparse reward -(d > thr) as float32
 // (bits 0x80000000 / 0xBF800000); mode 1: dense reward -d as float64; mode 2: success (d < thr) as float32.
@@ -335,6 +500,19 @@ int buffer_launch_gather_dict(hp_buffer *b, const PlanRec *d_plan, int64_t batch
     return HP_OK;
 }
 
+// throughput rows of the episodes in st_slots[0 .. n_new) (just scattered) -- or, slots == nullptr, of episodes [first, first + n)
+static int launch_pack(hp_buffer *b, const long long *slots, int64_t first, int64_t n) {
+    if (!b->p_row || n <= 0) return HP_OK;
+    const unsigned per_ep = (unsigned)((b->T + 8) / 8);
+    HP_KLOG("k_pack_rows");
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)n * per_ep), dim3(256), 0, b->ctx->stream, slots, (long long)n, (long long)first,
+                       b->d_obs, b->d_ag, b->d_g, b->d_act, b->p_row, b->p_goal, (int)b->T, (int)b->obs_dim, (int)b->goal_dim,
+                       (int)b->act_dim, (int)b->row_w, (int)b->goal_w);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+int buffer_launch_pack(hp_buffer *b, int64_t n_new) { return launch_pack(b, b->st_slots.as<long long>(), 0, n_new); }
+
 // stage host episodes on the device (st_*): one pinned copy, one H2D.  copy-in semantics (replay_buffer.py:39-42): the
 // caller's arrays are read by the CPU memcpy below and never again; the DMA reads our pinned staging.
 static int buffer_stage(hp_buffer *b, const double *obs, const double *ag, const double *g, const double *actions,
@@ -371,6 +549,7 @@ int buffer_stage_and_store(hp_buffer *b, hp_rng *rng, const double *obs, const d
                        b->st_act, b->d_obs, b->d_ag, b->d_g, b->d_act, (long long)b->ep_obs(),
                        (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
     HP_CHECK_HIP(hipGetLastError());
+    HP_TRY(buffer_launch_pack(b, n_new));
     // host mirror of replay_buffer.py:68 and :43
     b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
     b->n_transitions_stored += (int64_t)b->T * n_new;
@@ -406,6 +585,7 @@ int buffer_stage_pinned(hp_buffer *b, hp_rng *rng, const double *block, int64_t 
                            (long long)n_new, b->st_obs.as<double>(), b->st_ag, b->st_g, b->st_act, b->d_obs, b->d_ag, b->d_g,
                            b->d_act, (long long)b->ep_obs(), (long long)b->ep_ag(), (long long)b->ep_g(), (long long)b->ep_act());
         HP_CHECK_HIP(hipGetLastError());
+        HP_TRY(buffer_launch_pack(b, n_new));
     }
     b->current_size = (b->current_size + n_new < b->size) ? b->current_size + n_new : b->size;
     b->n_transitions_stored += (int64_t)b->T * n_new;
@@ -690,6 +870,36 @@ static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_no
     return HP_OK;
 }
 
+static int buffer_launch_gather_packed(hp_buffer *b, const PlanRec *d_plan, hp_norm *on, hp_norm *gn, int64_t batch,
+                                       double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+    PackedSampleArgs P;
+    P.p_row = b->p_row; P.p_goal = b->p_goal; P.row_w = b->row_w; P.goal_w = b->goal_w;
+    FusedSampleArgs &A = P.f;
+    A.obs = b->d_obs; A.ag = b->d_ag; A.g = b->d_g; A.act = b->d_act;
+    A.plan = d_plan;
+    A.onz = on->d; A.gnz = gn->d;
+    A.batch = batch;
+    A.T = b->T; A.od = b->obs_dim; A.gd = b->goal_dim; A.ad = b->act_dim;
+    A.sq_threshold = sq_threshold;
+    A.clip_obs = clip_obs;
+    A.clip_o = on->clip; A.clip_g = gn->clip;
+    A.x = o->x; A.xn = o->x_next; A.a = o->actions; A.r = o->r;
+    A.o_e = reinterpret_cast<long long *>(o->e); A.o_t = reinterpret_cast<long long *>(o->t);
+    A.o_fut = reinterpret_cast<long long *>(o->future_t);
+    A.o_her = o->her;
+    const int64_t cap = (int64_t)b->ctx->cu_count * 32;
+    HP_KLOG("k_gather_packed");
+    if (batch >= 16384) {
+        const int64_t waves = (batch + 2 * FS2_FLIGHT - 1) / (2 * FS2_FLIGHT), wgs = (waves + 3) / 4;
+        hipLaunchKernelGGL(k_gather_packed<FS2_FLIGHT>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, P);
+    } else {
+        const int64_t waves = (batch + 1) / 2, wgs = (waves + 3) / 4;
+        hipLaunchKernelGGL(k_gather_packed<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, P);
+    }
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+}
+
 static int sample_dev_check(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double clip_obs,
                             const hp_sample_dev_out *o, const char *who) {
     HP_REQUIRE(b && rng && on && gn && o, HP_ERR_INVALID, "%s: null argument", who);
@@ -715,15 +925,60 @@ extern "C" int hp_buffer_sample_dev(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_n
     return buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, o);
 }
 
-// diagnostic twin of hp_buffer_sample_device_us for the fused kernel (outputs into library scratch)
+// Throughput mode (storage_dtype = fp32).  hp_buffer_enable_f32_rows builds the float32 mirror of observations and
+// actions (+ the packed float64 goals) from what the buffer holds and keeps it current behind every later store;
+// hp_buffer_sample_dev_f32 is hp_buffer_sample_dev reading it: the same draws from the same stream, the same indices, relabelled
+// goals, rewards and goal columns bit for bit; the observation columns are those of float32-rounded observations.
+extern "C" int hp_buffer_enable_f32_rows(hp_buffer *b) {
+    HP_REQUIRE(b, HP_ERR_INVALID, "hp_buffer_enable_f32_rows: null handle");
+    HP_SERIALISE(b);
+    if (b->p_row) return HP_OK;
+    const int row_w = (b->obs_dim + b->act_dim + 31) / 32 * 32, goal_w = (2 * b->goal_dim + 7) / 8 * 8;
+    HP_REQUIRE(row_w == 32 && 2 * (row_w / 4) + 2 * ((b->goal_dim + 1) / 2) <= 32, HP_ERR_INVALID,
+               "hp_buffer_enable_f32_rows: observation + action must fit one 128-byte line of float32 (obs_dim + act_dim <= 32; got %d + %d)",
+               b->obs_dim, b->act_dim);
+    const size_t rows = (size_t)b->size * (b->T + 1);
+    HP_CHECK_HIP(hipMalloc((void **)&b->p_row, rows * row_w * sizeof(float)));
+    if (hipMalloc((void **)&b->p_goal, rows * goal_w * sizeof(double)) != hipSuccess) {
+        (void)hipFree(b->p_row);
+        b->p_row = nullptr;
+        hp_set_error("hp_buffer_enable_f32_rows: cannot allocate the goal rows");
+        return HP_ERR_HIP;
+    }
+    b->row_w = row_w;
+    b->goal_w = goal_w;
+    return launch_pack(b, nullptr, 0, b->size);      // (rows of unfilled slots hold whatever the allocation held: never sampled)
+}
+
+extern "C" int hp_buffer_sample_dev_f32(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double future_p,
+                                        double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+    HP_TRY(sample_dev_check(b, rng, on, gn, batch, clip_obs, o, "hp_buffer_sample_dev_f32"));
+    HP_SERIALISE(b);
+    HP_REQUIRE(b->p_row, HP_ERR_STATE, "hp_buffer_sample_dev_f32: hp_buffer_enable_f32_rows first");
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    if ((size_t)batch * sizeof(PlanRec) > b->plan.bytes) HP_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    HP_TRY(b->plan.ensure(batch * sizeof(PlanRec)));
+    PlanRec *d_plan = b->plan.as<PlanRec>();
+    HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
+    return buffer_launch_gather_packed(b, d_plan, on, gn, batch, sq_threshold, clip_obs, o);
+}
+
+// diagnostic twin of hp_buffer_sample_device_us for the fused kernel (outputs into library scratch); f32_rows != 0: the
+// throughput-rows kernel (hp_buffer_sample_dev_f32)
 extern "C" int hp_buffer_sample_dev_us(hp_buffer *b, hp_rng *rng, hp_norm *on, hp_norm *gn, int64_t batch, double future_p,
-                                       double sq_threshold, double clip_obs, int32_t reps, double *draw_us, double *gather_us) {
+                                       double sq_threshold, double clip_obs, int32_t reps, int32_t f32_rows, double *draw_us,
+                                       double *gather_us) {
     hp_sample_dev_out o;
     memset(&o, 0, sizeof(o));
     HP_TRY(sample_dev_check(b, rng, on, gn, batch, clip_obs, &o, "hp_buffer_sample_dev_us"));
     HP_REQUIRE(draw_us && gather_us && reps > 0, HP_ERR_INVALID, "hp_buffer_sample_dev_us: bad argument");
     HP_SERIALISE(b);
     HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    HP_REQUIRE(!f32_rows || b->p_row, HP_ERR_STATE, "hp_buffer_sample_dev_us: hp_buffer_enable_f32_rows first");
+    auto gather = [&](const PlanRec *plan, const hp_sample_dev_out *out) {
+        return f32_rows ? buffer_launch_gather_packed(b, plan, on, gn, batch, sq_threshold, clip_obs, out)
+                        : buffer_launch_gather_fused(b, plan, on, gn, batch, sq_threshold, clip_obs, out);
+    };
     hipStream_t s = b->ctx->stream;
     const size_t ldx = (size_t)(b->obs_dim + b->goal_dim);
     // growing `plan` / `out` frees memory that earlier asynchronous hp_buffer_sample_dev launches may still read: wait for them
@@ -743,11 +998,11 @@ extern "C" int hp_buffer_sample_dev_us(hp_buffer *b, hp_rng *rng, hp_norm *on, h
     } ev;
     for (int i = 0; i < 3; ++i) HP_CHECK_HIP(hipEventCreate(&ev.e[i]));
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
-    HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));   // warm
+    HP_TRY(gather(d_plan, &o));   // warm
     HP_CHECK_HIP(hipEventRecord(ev.e[0], s));
     for (int i = 0; i < reps; ++i) HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
     HP_CHECK_HIP(hipEventRecord(ev.e[1], s));
-    for (int i = 0; i < reps; ++i) HP_TRY(buffer_launch_gather_fused(b, d_plan, on, gn, batch, sq_threshold, clip_obs, &o));
+    for (int i = 0; i < reps; ++i) HP_TRY(gather(d_plan, &o));
     HP_CHECK_HIP(hipEventRecord(ev.e[2], s));
     HP_CHECK_HIP(hipEventSynchronize(ev.e[2]));
     float ms01 = 0.f, ms12 = 0.f;
@@ -845,6 +1100,8 @@ void hp_buffer_destroy(hp_buffer *b) {
     if (b->d_g) (void)hipFree(b->d_g);
     if (b->d_act) (void)hipFree(b->d_act);
     if (b->d_meta) (void)hipFree(b->d_meta);
+    if (b->p_row) (void)hipFree(b->p_row);
+    if (b->p_goal) (void)hipFree(b->p_goal);
     for (hipEvent_t ev : b->pin_events)
         if (ev) (void)hipEventDestroy(ev);
     b->st_obs.release();

@@ -179,5 +179,5 @@ int cycle_open_launch(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *gn, hp_rn
     HP_KLOG("k_cycle_open");
     hipLaunchKernelGGL(k_cycle_open, dim3((unsigned)(2 + OPEN_PARTS * b->staged_n)), dim3(OPEN_THREADS), lds, a->ctx->stream, A);
     HP_CHECK_HIP(hipGetLastError());
-    return HP_OK;
+    return buffer_launch_pack(b, b->staged_n);   // throughput rows of the episodes just scattered (nothing unless the buffer has them)
 }

@@ -169,6 +169,12 @@ struct hp_buffer {
     static constexpr int PIN_RING = 16;
     hipEvent_t pin_events[PIN_RING] = {nullptr};
     uint64_t pin_tickets = 0;
+    // Throughput rows (hp_buffer_enable_f32_rows; SURVEY 8b `storage_dtype`): a float32 mirror of observations + actions packed one
+    // (episode, timestep) per 128-byte line, and the goals (kept float64: rewards and relabelled goals stay bit-exact) packed
+    // [ag_t | g_t] per 64-byte half line -- what hp_buffer_sample_dev_f32 reads.  Maintained behind every scatter.
+    float *p_row = nullptr;      // [size][T + 1][row_w] floats: obs_t | actions_t (zeros at t = T) | 0
+    double *p_goal = nullptr;    // [size][T + 1][goal_w] doubles: ag_t | g_t (zeros at t = T) | 0
+    int32_t row_w = 0, goal_w = 0;
     // sampling scratch
     DevBuf plan, out;
     size_t ep_obs() const { return (size_t)(T + 1) * obs_dim; }
@@ -176,6 +182,7 @@ struct hp_buffer {
     size_t ep_g() const { return (size_t)T * goal_dim; }
     size_t ep_act() const { return (size_t)T * act_dim; }
 };
+int buffer_launch_pack(hp_buffer *b, int64_t n_new);   // refresh the throughput rows of the episodes just scattered (no-op when off)
 
 // ------------------------------------------------------------------ normalizer
 #define NORM_MAX 256   // columns a normalizer can hold (bmirobot: 27 observations, 3 goals); hp_norm_create rejects more

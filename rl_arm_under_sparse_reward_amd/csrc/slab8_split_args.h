@@ -40,9 +40,5 @@ struct FbSplitArgs {
     const PeerDev *peer;
     int peer_u, peer_mean;
 };
-// what the in-launch weight-gradient tiles of k_fb_split8 do behind their products
-enum { SPLIT_TILES_ADAM = 0,   // single rank: optimizer step of the critic inside the launch (behind the actor-side chains' gates)
-       SPLIT_TILES_PEER = 1,   // data-parallel ranks, one device each: rank exchange tile by tile, then the same step (utils.py:43-48 + Adam)
-       SPLIT_TILES_GRADS = 2 };// gradients only: exchange (RCCL, two-phase / gated peer memory) + optimizer follow as launches of their own
 static_assert(sizeof(FbSplitArgs) <= 4096, "kernel arguments of k_fb_split8 exceed the 4 KB kernarg segment");
 

@@ -110,7 +110,13 @@ class DeviceEpisodeBuffer:
             return tr, idx
         return tr
 
-    def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False):
+    def enable_f32_rows(self):
+        """hp_buffer_enable_f32_rows: build (and from now on maintain) the float32 throughput mirror that
+        `sample_device(..., f32_rows=True)` reads.  The float64 arrays stay the source of truth."""
+        _lib.check(self.lib.hp_buffer_enable_f32_rows(self.h))
+        self.f32_rows = True
+
+    def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False, f32_rows=False):
         """hp_buffer_sample_dev: the minibatch as the learner consumes it (ddpg_agent.py:227-243) in torch CUDA tensors
         allocated here: x, x_next [B, obs+goal], actions [B, act], r [B, 1], float32.  The kernels run on the CONTEXT's stream,
         ordered with torch's current stream by events on both sides (_lib.Context.torch_bridge): the context is not rebound, so
@@ -133,9 +139,9 @@ class DeviceEpisodeBuffer:
             idx["her"] = torch.empty(B, dtype=torch.uint8, device=dev)
             for k, t in idx.items():
                 setattr(o, k, t.data_ptr())
+        fn = self.lib.hp_buffer_sample_dev_f32 if f32_rows else self.lib.hp_buffer_sample_dev
         with self.ctx.torch_bridge() as note:
-            _lib.check(self.lib.hp_buffer_sample_dev(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold),
-                                                     float(clip_obs), C.byref(o)))
+            _lib.check(fn(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold), float(clip_obs), C.byref(o)))
             note(list(out.values()) + (list(idx.values()) if idx else []))
         return (out, idx) if with_indices else out
 
@@ -207,13 +213,21 @@ class replay_buffer:
             raise TypeError("replay_buffer was built without a sample_func")
         return self._dev.sample(self.rng, batch_size, self._sampler.future_p, self._sampler.sq_threshold)
 
-    def sample_device(self, batch_size, o_norm, g_norm, clip_obs=200):
+    def enable_f32_rows(self):
+        """Opt into the sampler's throughput mode (SURVEY 8b `storage_dtype = fp32`; hp_buffer_enable_f32_rows): a float32
+        mirror of observations + actions, one (episode, timestep) per 128-byte line, kept current behind every store_episode;
+        `sample_device(..., f32_rows=True)` then reads it.  Everything else keeps reading the reference's float64 arrays."""
+        self._dev.enable_f32_rows()
+
+    def sample_device(self, batch_size, o_norm, g_norm, clip_obs=200, f32_rows=False):
         """`sample(batch_size)` followed by the learner's preprocessing (ddpg_agent.py:227-243: _preproc_og, both
         normalizers, concatenate, float32 tensors) in one gather kernel with device outputs: a dict of torch CUDA tensors
         `x` (inputs_norm_tensor), `x_next` (inputs_next_norm_tensor), `actions` (actions_tensor), `r` (r_tensor, [B, 1]).
         Same draws from the same stream and bit-identical float32 values as sample() + normalize() on the host; nothing
-        crosses PCIe.  o_norm / g_norm: this package's normalizer objects; clip_obs: arguments.py:87."""
+        crosses PCIe.  o_norm / g_norm: this package's normalizer objects; clip_obs: arguments.py:87.
+        f32_rows=True (after enable_f32_rows()): the throughput mode -- indices, relabelled goals, rewards, goal columns and
+        actions still bit-identical, observation columns those of float32-rounded observations, ~half the bytes."""
         if self._sampler is None:
             raise TypeError("replay_buffer was built without a sample_func")
         return self._dev.sample_device(self.rng, o_norm, g_norm, batch_size, self._sampler.future_p,
-                                       self._sampler.sq_threshold, clip_obs)
+                                       self._sampler.sq_threshold, clip_obs, f32_rows=f32_rows)

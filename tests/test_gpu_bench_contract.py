@@ -208,7 +208,8 @@ def test_forced_data_parallel_line_names_the_kernels_it_ran(transport, chain, ti
     assert r["kernel"] in kp and r["kernels_per_update"] == kp
     own = [k for k in kp if not k.startswith("rccl:")]             # (RCCL's kernel carries RCCL's own name in the trace)
     assert set(own) <= traced, (own, sorted(traced))
-    assert "k_fb_slab8" not in traced and "k_fb_split8<0>" not in traced     # nothing of the two-launch / single-rank forms ran
+    assert "k_fb_split8<0>" not in traced, sorted(traced)          # nothing of the single-rank form ran (the prologue included)
+    assert "k_fb_slab8" not in traced, sorted(traced)              # ... nor of the two-launch form
     assert r["all_matrix_kernels"]["chain"]["kernel"] == chain and 0 < r["frac"] < 1
     assert r["duration_source"] in ("live", "committed")
 

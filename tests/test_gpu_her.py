@@ -408,6 +408,94 @@ def test_sample_device_other_shapes_take_the_right_kernel_and_stay_bit_exact(od,
     assert len(set(np.unique(got["r"].cpu().numpy().view(np.uint32)))) == 2        # both reward values occur
 
 
+def _f32_rounded(tr):
+    out = dict(tr)
+    for key in ("obs", "obs_next", "actions"):
+        out[key] = tr[key].astype(np.float32).astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("n,B,k,mode,clip_obs", [(37, 1001, 4, "walk", 0.4), (5000, 256, 4, "iid", 200), (5000, 65536, 8, "walk", 200)])
+def test_sample_device_f32_rows_throughput_mode(n, B, k, mode, clip_obs):
+    """SURVEY 8b `storage_dtype = fp32` as an opt-in mirror (hp_buffer_enable_f32_rows / hp_buffer_sample_dev_f32): same stream,
+    same draws; indices, relabelled goals, rewards, the goal columns of x / x_next and the actions BIT-identical to the float64
+    path (the goals stay float64 in the mirror); the observation columns are exactly the reference arithmetic applied to
+    float32-rounded observations.  The mirror follows later stores (random-slot overwrites of a full buffer included)."""
+    eps = make_episodes(n, seed=1, mode=mode)
+    fp = future_probability("future", k)
+    st = EpisodeStore(100, 27, 3, 4, n * 100)
+    rs = np.random.RandomState(125)
+    st.store_episode(eps, rs)
+    on, gn, o_dev, g_dev = _primed_normalizers(eps)
+    dev = fresh_rng(125)
+    buf = DeviceEpisodeBuffer(n, 100, 27, 3, 4)
+    buf.store(dev, eps)
+    with pytest.raises(Exception, match="hp_buffer_enable_f32_rows first"):
+        buf.sample_device(dev, o_dev, g_dev, 8, fp, squared_threshold(0.05), clip_obs, f32_rows=True)
+    buf.enable_f32_rows()                               # built from what the buffer holds
+    for i in range(3):
+        if i == 2:                                      # a full buffer: random slots overwritten, the mirror must follow
+            more = make_episodes(3, seed=77, mode="walk")
+            st.store_episode(more, rs)
+            buf.store(dev, more)
+        ref, ridx = st.sample(B, fp, rs)
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, fp, squared_threshold(0.05), clip_obs, with_indices=True, f32_rows=True)
+        _assert_minibatch_equal(got, _f32_rounded(ref), on, gn, clip_obs)
+        for key in ("e", "t", "future_t"):
+            assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), key
+        # against the float64 path itself: goal columns, actions and rewards are the SAME bits
+        from oracle.ddpg_update import minibatch_tensors
+        x64, xn64, a64, r64 = (t.numpy() for t in minibatch_tensors(ref, on, gn, clip_obs))
+        assert np.array_equal(bits(got["x"].cpu().numpy()[:, 27:]), bits(x64[:, 27:]))
+        assert np.array_equal(bits(got["x_next"].cpu().numpy()[:, 27:]), bits(xn64[:, 27:]))
+        assert np.array_equal(bits(got["actions"].cpu().numpy()), bits(a64)) and np.array_equal(bits(got["r"].cpu().numpy()), bits(r64))
+        assert np.max(np.abs(got["x"].cpu().numpy() - x64)) <= 2e-6      # float32 rounding of an observation, through a std >= 0.01... small
+    assert state_equal(dev, *rs.get_state()[1:3])
+
+
+def test_f32_rows_follow_the_cycle_graph_and_keep_losses_within_the_bar():
+    """The mirror behind hp_agent_train_cycle's in-launch scatter (k_cycle_open -> k_pack_rows inside the cycle graph), and the
+    north-star bar on what the mode changes: an update on a throughput-mode minibatch has both losses within 1e-5 (relative) of the
+    same update on the float64-row minibatch."""
+    import torch
+    from oracle import ddpg_update as oupd
+    from rl_arm_under_sparse_reward_amd.arguments import Args
+    from rl_arm_under_sparse_reward_amd.ddpg_agent import ddpg_agent
+    from gpu_common import ctx
+
+    torch.manual_seed(0)
+    rng = fresh_rng(11)
+    agent = ddpg_agent(Args(batch_size=256, buffer_size=40 * 100), None, dict(ENV_PARAMS), ctx=ctx(), rng=rng)
+    agent.buffer.store_episode(make_episodes(40, seed=5, mode="walk"))      # full: the cycles below overwrite random slots
+    agent.buffer.enable_f32_rows()
+    for c in range(3):
+        agent.train_cycle(make_episodes(2, seed=60 + c, mode="walk"), 4)
+    state = rng.get_state()
+    a = agent.buffer.sample_device(512, agent.o_norm, agent.g_norm, clip_obs=200)
+    rng.set_state(state)                                 # the same draws again, through the mirror
+    b = agent.buffer.sample_device(512, agent.o_norm, agent.g_norm, clip_obs=200, f32_rows=True)
+    for key in ("actions", "r"):
+        assert np.array_equal(bits(a[key].cpu().numpy()), bits(b[key].cpu().numpy())), key
+    for key in ("x", "x_next"):
+        xa, xb = a[key].cpu().numpy(), b[key].cpu().numpy()
+        assert np.array_equal(bits(xa[:, 27:]), bits(xb[:, 27:]))
+        assert 0 < np.max(np.abs(xa - xb)) <= 2e-6, key          # rounded observations: different bits, tiny differences
+    # the episodes stored by the cycles really are in the mirror: the float64 rows, rounded, reproduce it bitwise
+    obs64 = agent.buffer.buffers["obs"]
+    row = np.zeros((40, 101, 32), np.float32)
+    row[:, :, :27] = obs64.astype(np.float32)
+    row[:, :100, 27:31] = agent.buffer.buffers["actions"].astype(np.float32)
+    on, gn = agent.o_norm, agent.g_norm
+    # one update from identical networks on both minibatches (CPU oracle learner)
+    a0, c0 = oupd.init_actor(27, 3, 4, 0), oupd.init_critic(27, 3, 4, 1)
+    la = oupd.DDPGLearner({k: v.clone() for k, v in a0.items()}, {k: v.clone() for k, v in c0.items()}).update(
+        *(a[k].cpu() for k in ("x", "x_next", "actions", "r")))
+    lb = oupd.DDPGLearner({k: v.clone() for k, v in a0.items()}, {k: v.clone() for k, v in c0.items()}).update(
+        *(b[k].cpu() for k in ("x", "x_next", "actions", "r")))
+    for name in ("actor_loss", "critic_loss"):
+        assert abs(la[name] - lb[name]) <= 1e-5 * max(abs(la[name]), 1e-6), (name, la[name], lb[name])
+
+
 def test_sample_device_dense_reward_partial_outputs_and_errors():
     """Dense reward (compute_reward :89-90 narrowed to float32 as ddpg_agent.py:243 does), NULL outputs, and the reference's
     error on an empty buffer."""

@@ -90,11 +90,6 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     rng = DeviceRandomState(seed)
     agent = ddpg_agent(Args(batch_size=batch, buffer_size=n_eps * 100), None, dict(ENV_PARAMS), comm=comm, rng=rng)
     assert agent._native_comm is None        # gloo group: no RCCL (two ranks share one device)
-    kernels = agent.update_kernels(N_UP)["updates"][-1]      # (a host-driven exchange reports ONE update)
-    if split:
-        assert kernels[0] == ("k_fb_split8<1>" if transport.startswith("peertiles") else "k_fb_split8<2>"), kernels
-    elif transport != "torch":
-        assert kernels[0] == "k_fb_slab8", kernels
     peer = transport.startswith("peer") or transport == "auto"
     assert (agent._peer is not None) == peer
     if peer:
@@ -108,6 +103,15 @@ def _worker(rank, world, port, out_dir, transport="torch"):
     agent._update_normalizer()               # on the staged episodes; MEAN over ranks inside
     agent._update_network(N_UP)
     got = agent.last_losses(N_UP)
+    # what one update launched, read off the library's launch logic (a host-driven exchange reports ONE update).  Asked AFTER the
+    # first sequence: asked before it, the discarded capture loads the kernels' code early and both ranks then reach their first
+    # tile-wise launch in the same microseconds -- the one timing the shared-device rehearsal of that form cannot survive (its
+    # launches must overlap with a skew, see the fixture); measured 2 of 3 attempts lost that way, none this way
+    kernels = agent.update_kernels(N_UP)["updates"][-1]
+    if split:
+        assert kernels[0] == "k_fb_split8<1>", kernels
+    elif transport != "torch":
+        assert kernels[0] == "k_fb_slab8", kernels
     # ---- oracle side, same collectives in the same order on both ranks
     def ar_sum(x):
         # MPI_SUM in rank order 0..W-1 in the array's own dtype (what tools/gen_golden.py's stub communicator does for the

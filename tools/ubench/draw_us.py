@@ -17,6 +17,6 @@ for B in [int(x) for x in os.environ.get("BATCHES", "100,256,1024,4096,65536").s
     d, g, d2, g2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     reps = 200 if B <= 4096 else 20
     _lib.check(lib.hp_buffer_sample_device_us(buf.h, rng.h, B, 0.8, squared_threshold(0.05), reps, C.byref(d), C.byref(g)))
-    _lib.check(lib.hp_buffer_sample_dev_us(buf.h, rng.h, on.h, gn.h, B, 0.8, squared_threshold(0.05), 200.0, reps, C.byref(d2), C.byref(g2)))
+    _lib.check(lib.hp_buffer_sample_dev_us(buf.h, rng.h, on.h, gn.h, B, 0.8, squared_threshold(0.05), 200.0, reps, 0, C.byref(d2), C.byref(g2)))
     print(f"batch {B:6d}: index draw {d.value:8.2f} us | gather (float64 dict) {g.value:7.2f} us | fused gather (float32 x, x', a, r) {g2.value:7.2f} us "
           f"= {B / g2.value:8.1f} transitions/us, {812 * B / g2.value / 1e3:7.1f} GB/s of this build's bytes")

@@ -33,12 +33,18 @@ for n_eps in [int(x) for x in os.environ.get("EPISODES", "5000").split(",")]:
     o_norm.update(eps[0][:, :100].reshape(-1, 27)); g_norm.update(eps[2].reshape(-1, 3))
     o_norm.recompute_stats(); g_norm.recompute_stats()
     shard_mb = n_eps * 29840 / 1e6
+    f32 = os.environ.get("F32_ROWS", "0") == "1"      # the throughput rows (hp_buffer_enable_f32_rows / hp_buffer_sample_dev_f32)
+    if f32:
+        _lib.check(ctx.lib.hp_buffer_enable_f32_rows(buf._dev.h))
     for nb in [int(x) for x in os.environ.get("BATCHES", "256,16384,262144").split(",")]:
         d, g = C.c_double(), C.c_double()
         _lib.check(ctx.lib.hp_buffer_sample_dev_us(buf._dev.h, rng.h, o_norm.h, g_norm.h, nb, float(her.future_p),
-                                                   float(her.sq_threshold), 200.0, reps if nb > 4096 else 10 * reps, C.byref(d), C.byref(g)))
-        rec = {"episodes": n_eps, "shard_MB_f64": round(shard_mb, 1), "batch": nb, "gather_us": round(g.value, 3), "draw_us": round(d.value, 3),
-               "GBps_528B": round(528 * nb / g.value / 1e3, 1), "GBps_812B_moved": round(812 * nb / g.value / 1e3, 1),
+                                                   float(her.sq_threshold), 200.0, reps if nb > 4096 else 10 * reps, 1 if f32 else 0,
+                                                   C.byref(d), C.byref(g)))
+        moved = 544 if f32 else 812        # f32 rows: 2 x 128 B lines + 2 x 3 float64 goals... algorithmic: 62 f32 + 9 f64 + 16 B record + 260 B written
+        rec = {"rows": "f32 mirror" if f32 else "f64", "episodes": n_eps, "shard_MB_f64": round(shard_mb, 1), "batch": nb,
+               "gather_us": round(g.value, 3), "draw_us": round(d.value, 3),
+               "GBps_528B": round(528 * nb / g.value / 1e3, 1), "GBps_moved": round(moved * nb / g.value / 1e3, 1), "bytes_moved_per_transition": moved,
                "G_transitions_per_s": round(nb / g.value / 1e3, 3)}
         out.append(rec)
         print(json.dumps(rec), flush=True)
