@@ -1003,6 +1003,22 @@ def sample_kernel_fused_fields(a, r):
                      "achieved_GBps_812B_this_build": round(812 * nb / (fg.value * 1e-6) / 1e9, 2),
                      "transitions_per_s_kernel_only": round(nb / (fg.value * 1e-6), 1)}
     big = fused[1 << 18]
+    # ... and the opt-in throughput mode (hp_buffer_enable_f32_rows / hp_buffer_sample_dev_f32: float32 mirror of observations +
+    # actions, one timestep per 128-byte line; SURVEY 8b storage_dtype = fp32): 572 B per transition (62 f32 + 6 f64 + 16 read, 260 written)
+    f32 = None
+    try:
+        _l.check(r.ctx.lib.hp_buffer_enable_f32_rows(buf.h))
+        _l.check(r.ctx.lib.hp_buffer_sample_dev_us(buf.h, r.rng.h, r.agent.o_norm.h, r.agent.g_norm.h, 1 << 18,
+                                                   float(r.agent.her_module.future_p), float(r.agent.her_module.sq_threshold), 200.0, 20, 1,
+                                                   C.byref(fd), C.byref(fg)))
+        f32 = {"kernel": "k_gather_packed (hp_buffer_sample_dev_f32)", "batch": 1 << 18, "avg_launch_us": round(fg.value, 3),
+               "achieved_GBps_528B": round(528 * (1 << 18) / (fg.value * 1e-6) / 1e9, 2),
+               "frac_528B": round(528 * (1 << 18) / (fg.value * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+               "bytes_per_transition_this_mode": 572,
+               "note": "indices, relabelled goals, rewards, goal columns and actions bit-identical to the float64 rows; observation columns "
+                       "those of float32-rounded observations (tests/test_gpu_her.py::test_sample_device_f32_rows_throughput_mode)"}
+    except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the run its line
+        f32 = {"error": str(e)}
     # PMC traffic of the kernel (separate rocprofv3 --pmc passes, tools/gpu_round6.sh): the committed summary of the 2^18 launch
     traffic, tsrc = None, None
     for rnd in ("r06",):
@@ -1021,6 +1037,7 @@ def sample_kernel_fused_fields(a, r):
         "frac_this_build_bytes": round(big["achieved_GBps_812B_this_build"] / HBM_PEAK_GBPS, 5),
         "avg_launch_us": big["avg_launch_us"], "batch": 1 << 18, "traffic": traffic, "traffic_source": tsrc,
         "at_bench_batch": fused[a.batch],
+        "throughput_mode_f32_rows": f32,
         "note": "achieved = SURVEY 8d's algorithmic 528 B / transition (float32 storage) x 2^18 transitions / the kernel's average "
                 "launch time; this build keeps float64 rows (bit-identical rewards and inputs), so the bytes it really moves are "
                 "812 B / transition (the *_this_build figures).  Random 432-byte row pairs out of this run's shard "

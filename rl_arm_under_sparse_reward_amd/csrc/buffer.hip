@@ -316,9 +316,13 @@ __global__ __launch_bounds__(256) void k_pack_rows(const long long *__restrict__
     }
 }
 
-// hp_buffer_sample_dev on the throughput rows.  32 lanes per transition, two transitions per wavefront instruction, one 16-byte
-// load per lane: lanes 0 .. 2 row_w / 4 - 1 the two adjacent row lines (row t, row t + 1), then ceil(gd / 2) lanes ag[t + 1],
-// ceil(gd / 2) lanes g' (= ag[future_t] when relabelled, her.py:35-36, else the g half of goal row t).
+// hp_buffer_sample_dev on the throughput rows.  32 lanes per transition, two transitions per wavefront instruction, ONE 16-byte
+// load per lane: lanes 0-14 the float4s of the two adjacent row lines (row t: obs | action, row t + 1: obs), lanes 15 and 31 the
+// two halves of g' (= ag[future_t] when relabelled, her.py:35-36, else the g half of goal row t), lanes 16 and 17 ag[t + 1] for the
+// reward.  Each row lane then hands components 2, 3 of its float4 to the lane 16 above it, so that all 32 lanes carry two
+// elements through ONE pass of the float64 clip / normalise arithmetic (the kernel is bound by that arithmetic as much as by
+// bytes: a first version that kept four components per lane ran 104 us per 2^18 transitions against 68 for the float64 rows).
+// Needs obs_dim <= 28, obs_dim + act_dim <= 32, goal_dim <= 4 (hp_buffer_enable_f32_rows checks).
 struct PackedSampleArgs {
     const float *p_row;
     const double *p_goal;
@@ -332,46 +336,35 @@ __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P)
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const int od = A.od, gd = A.gd, ad = A.ad, ldx = od + gd, rw = P.row_w, gw = P.goal_w;
-    const int rl = rw >> 2, ug = (gd + 1) >> 1;          // lanes per row line, lanes per goal vector
-    // unit: 0 row t, 1 row t + 1 (float4 each), 2 ag[t + 1], 3 g' (two doubles each), 4 none
-    const int unit = l < rl ? 0 : l < 2 * rl ? 1 : l < 2 * rl + ug ? 2 : l < 2 * rl + 2 * ug ? 3 : 4;
-    const int j = unit == 0 ? l : unit == 1 ? l - rl : unit == 2 ? l - 2 * rl : l - 2 * rl - ug;
-    // row lanes: columns 4 j .. 4 j + 3 of the line; per component where it goes (dst 0: x, 1: x_next, 2: actions, -1: nowhere)
-    int dst[4], off[4];
-    float mu[4] = {0.f, 0.f, 0.f, 0.f};
-    double sd[4] = {1.0, 1.0, 1.0, 1.0};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int col = 4 * j + c;
-        dst[c] = -1;
-        off[c] = 0;
-        if (unit <= 1 && col < od) {
-            dst[c] = unit;
-            off[c] = col;
-            mu[c] = A.onz->mean[col];
-            sd[c] = A.onz->std[col];
-        } else if (unit == 0 && col < od + ad) {
-            dst[c] = 2;
-            off[c] = col - od;
-        }
-    }
-    // goal lanes: doubles 2 j, 2 j + 1 of the vector (the last unit of an odd gd keeps its FIRST double only; the rows are padded)
-    float gmu[2] = {0.f, 0.f};
-    double gsd[2] = {1.0, 1.0};
-    bool gok[2] = {false, false};
+    // what this lane LOADS: 0 a row float4 (lanes 0-14: column 4 l of the 64-float [row t | row t + 1] pair), 1 a g' half (lane
+    // 15: doubles 0, 1; lane 31: doubles 2, 3), 2 an ag[t + 1] half (lanes 16, 17), 3 nothing
+    const int load = l < 15 ? 0 : (l == 15 || l == 31) ? 1 : (l == 16 || l == 17) ? 2 : 3;
+    const int gj = l == 31 ? 1 : 0;                        // which half of g'
+    // what this lane COMPUTES, two slots: lanes 0-14 columns 4 l + s, lanes 16-30 columns 4 (l - 16) + 2 + s (handed down by lane
+    // l - 16), lanes 15 / 31 the goal components 2 gj + s.  dst 0: x, 1: x_next, 2: actions, 3: goal column of both, -1: nothing
+    int dst[2], off[2];
+    float mu[2] = {0.f, 0.f};
+    double sd[2] = {1.0, 1.0}, clip[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int c = 2 * j + s;
-        if (unit == 3 && c < gd) {
-            gok[s] = true;
-            gmu[s] = A.gnz->mean[c];
-            gsd[s] = A.gnz->std[c];
+        dst[s] = -1;
+        off[s] = 0;
+        if (load == 1) {
+            const int c = 2 * gj + s;
+            if (c < gd) { dst[s] = 3; off[s] = od + c; mu[s] = A.gnz->mean[c]; sd[s] = A.gnz->std[c]; clip[s] = A.clip_g; }
+        } else if (l != 15 && l != 31) {
+            const int col = 4 * (l & 15) + 2 * (l >> 4) + s;          // column of the 64-float pair
+            const int oc = col < rw ? col : col - rw;                 // ... inside its row
+            if (oc < od) { dst[s] = col < rw ? 0 : 1; off[s] = oc; mu[s] = A.onz->mean[oc]; sd[s] = A.onz->std[oc]; clip[s] = A.clip_o; }
+            else if (col < rw && oc < od + ad) { dst[s] = 2; off[s] = oc - od; }
         }
     }
     const int rc = l < gd ? l : gd - 1;                   // reward: lanes l < gd of each half hold component l
-    const int a_lane = (h << 5) + 2 * rl + (rc >> 1), g_lane = a_lane + ug, r_slot = rc & 1;
+    const int a_lane = (h << 5) + 16 + (rc >> 1), g_lane = (h << 5) + (rc < 2 ? 15 : 31), r_slot = rc & 1;
+    const int from = (h << 5) + (l & 15);                 // the row lane a lane 16-30 takes its components from
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     union Ld { f4_t f; d2_t d; };
     for (long long base = wave * (2 * FLIGHT); base < A.batch; base += n_waves * (2 * FLIGHT)) {
         PlanRec rec[FLIGHT];
@@ -387,44 +380,33 @@ __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P)
             const int t = rec[k].t;
             const float *row = P.p_row + (e * (A.T + 1) + t) * rw;
             const double *goal_t = P.p_goal + (e * (A.T + 1) + t) * gw;
-            // g': the ag half of goal row future_t, or the g half of goal row t.  The g half starts at double gd: a 16-byte load of
-            // doubles [gd + 2 j, gd + 2 j + 1] is 8-byte aligned, like the float64 rows' loads
+            // g': the ag half of goal row future_t, or the g half (doubles gd ..) of goal row t
             const double *gsrc = rec[k].her ? P.p_goal + (e * (A.T + 1) + rec[k].fut) * gw : goal_t + gd;
-            const void *p = unit <= 1 ? (const void *)(row + 4 * l) : unit == 2 ? (const void *)(goal_t + gw + 2 * j)
-                          : unit == 3 ? (const void *)(gsrc + 2 * j) : (const void *)row;
-            typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-            const f4_a8 raw = *reinterpret_cast<const f4_a8 *>(p);
-            v[k].f = raw;
+            const void *p = load == 0 ? (const void *)(row + 4 * l) : load == 1 ? (const void *)(gsrc + 2 * gj)
+                          : load == 2 ? (const void *)(goal_t + gw + 2 * (l - 16)) : (const void *)row;
+            v[k].f = *reinterpret_cast<const f4_a8 *>(p);
         }
 #pragma unroll
         for (int k = 0; k < FLIGHT; ++k) {
             const long long m = base + 2 * k + h;
             const bool live = m < A.batch;
-            if (unit <= 1) {
+            // components 2, 3 of row lane l go to lane l + 16
+            const float z = __shfl(v[k].f[2], from), w = __shfl(v[k].f[3], from);
+            const float lo = l < 16 ? v[k].f[0] : z, hi = l < 16 ? v[k].f[1] : w;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!live || dst[c] < 0) continue;
-                    const float raw = v[k].f[c];
-                    if (dst[c] == 2) {
-                        if (A.a) A.a[m * ad + off[c]] = raw;
-                        continue;
-                    }
-                    double x = fmin(fmax((double)raw, -A.clip_obs), A.clip_obs);           // _preproc_og
-                    x = __ddiv_rn(__dsub_rn(x, (double)mu[c]), sd[c]);                     // normalizer.normalize
-                    const float o = (float)fmin(fmax(x, -A.clip_o), A.clip_o);
-                    if (dst[c] == 0) { if (A.x) A.x[m * ldx + off[c]] = o; }
-                    else if (A.xn) A.xn[m * ldx + off[c]] = o;
+            for (int s = 0; s < 2; ++s) {
+                if (!live || dst[s] < 0) continue;
+                const float raw = s ? hi : lo;
+                if (dst[s] == 2) {
+                    if (A.a) A.a[m * ad + off[s]] = raw;
+                    continue;
                 }
-            } else if (unit == 3) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (!live || !gok[s]) continue;
-                    double x = fmin(fmax(v[k].d[s], -A.clip_obs), A.clip_obs);
-                    x = __ddiv_rn(__dsub_rn(x, (double)gmu[s]), gsd[s]);
-                    const float o = (float)fmin(fmax(x, -A.clip_g), A.clip_g);
-                    if (A.x) A.x[m * ldx + od + 2 * j + s] = o;
-                    if (A.xn) A.xn[m * ldx + od + 2 * j + s] = o;                          // g_next := g (ddpg_agent.py:231)
-                }
+                double x = dst[s] == 3 ? v[k].d[s] : (double)raw;
+                x = fmin(fmax(x, -A.clip_obs), A.clip_obs);                            // _preproc_og
+                x = __ddiv_rn(__dsub_rn(x, (double)mu[s]), sd[s]);                      // normalizer.normalize
+                const float o = (float)fmin(fmax(x, -clip[s]), clip[s]);
+                if (dst[s] != 1 && A.x) A.x[m * ldx + off[s]] = o;
+                if (dst[s] != 0 && A.xn) A.xn[m * ldx + off[s]] = o;                    // (goal columns: both, g_next := g, ddpg_agent.py:231)
             }
             // reward (her.py:38) on the float64 goals: the same left-to-right sum as every other gather
             const double ax = __shfl(v[k].d[0], a_lane), ay = __shfl(v[k].d[1], a_lane);
@@ -934,9 +916,9 @@ extern "C" int hp_buffer_enable_f32_rows(hp_buffer *b) {
     HP_SERIALISE(b);
     if (b->p_row) return HP_OK;
     const int row_w = (b->obs_dim + b->act_dim + 31) / 32 * 32, goal_w = (2 * b->goal_dim + 7) / 8 * 8;
-    HP_REQUIRE(row_w == 32 && 2 * (row_w / 4) + 2 * ((b->goal_dim + 1) / 2) <= 32, HP_ERR_INVALID,
-               "hp_buffer_enable_f32_rows: observation + action must fit one 128-byte line of float32 (obs_dim + act_dim <= 32; got %d + %d)",
-               b->obs_dim, b->act_dim);
+    HP_REQUIRE(row_w == 32 && b->obs_dim <= 28 && b->goal_dim <= 4, HP_ERR_INVALID,
+               "hp_buffer_enable_f32_rows: needs obs_dim <= 28, obs_dim + act_dim <= 32 (one 128-byte line of float32 per timestep) and "
+               "goal_dim <= 4; got %d, %d, %d", b->obs_dim, b->act_dim, b->goal_dim);
     const size_t rows = (size_t)b->size * (b->T + 1);
     HP_CHECK_HIP(hipMalloc((void **)&b->p_row, rows * row_w * sizeof(float)));
     if (hipMalloc((void **)&b->p_goal, rows * goal_w * sizeof(double)) != hipSuccess) {

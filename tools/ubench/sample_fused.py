@@ -41,7 +41,7 @@ for n_eps in [int(x) for x in os.environ.get("EPISODES", "5000").split(",")]:
         _lib.check(ctx.lib.hp_buffer_sample_dev_us(buf._dev.h, rng.h, o_norm.h, g_norm.h, nb, float(her.future_p),
                                                    float(her.sq_threshold), 200.0, reps if nb > 4096 else 10 * reps, 1 if f32 else 0,
                                                    C.byref(d), C.byref(g)))
-        moved = 544 if f32 else 812        # f32 rows: 2 x 128 B lines + 2 x 3 float64 goals... algorithmic: 62 f32 + 9 f64 + 16 B record + 260 B written
+        moved = 572 if f32 else 812        # f32 rows: 62 float32 + 6 float64 goals + the 16 B index record read, 65 float32 written
         rec = {"rows": "f32 mirror" if f32 else "f64", "episodes": n_eps, "shard_MB_f64": round(shard_mb, 1), "batch": nb,
                "gather_us": round(g.value, 3), "draw_us": round(d.value, 3),
                "GBps_528B": round(528 * nb / g.value / 1e3, 1), "GBps_moved": round(moved * nb / g.value / 1e3, 1), "bytes_moved_per_transition": moved,
