@@ -38,8 +38,8 @@ extern "C" {
 /* Version of the STABLE surface declared in this header.  2 (round 4): the diagnostic / test-hook entry points moved to
  * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
  * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  3 (round 5): hp_buffer_sample_dev (device-output fused
- * sampler) was added.  4 (round 6): hp_ctx_get_stream was added (a host that hands device outputs to a framework orders the
- * framework's stream with the context's through events instead of rebinding the context), and the sampler's throughput mode
+ * sampler) was added.  4 (round 6): hp_ctx_get_stream and hp_ctx_borrow_stream / hp_ctx_return_stream were added (a host that hands
+ * device outputs to a framework has them written on the framework's stream for that call instead of rebinding the context), and the sampler's throughput mode
  * (hp_buffer_enable_f32_rows, hp_buffer_sample_dev_f32).  hp_abi_version() returns the
  * library's value; a host must refuse a library whose version differs from the header it was built against. */
 #define HP_ABI_VERSION 4
@@ -72,6 +72,14 @@ int hp_ctx_create(int device_id, hp_ctx **out);
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 /* the stream the context enqueues on right now (its own one unless hp_ctx_set_stream changed it) */
 int hp_ctx_get_stream(hp_ctx *ctx, void **hip_stream);
+/* A caller's stream for the duration of ONE call sequence, without rebinding the context: between hp_ctx_borrow_stream and
+ * hp_ctx_return_stream (same thread; the context's lock is held in between) every launch of the library goes to `hip_stream`
+ * (NULL: the null stream, a framework's default), ordered on the device behind what the context's own stream held; the own
+ * stream is ordered behind the borrowed stream's work when it is next used.  No host synchronisation.  What
+ * replay_buffer.sample_device wraps hp_buffer_sample_dev in, so that torch consumes the outputs in ITS stream's order while a
+ * fused learner on the same context keeps its own stream and its cached graphs. */
+int hp_ctx_borrow_stream(hp_ctx *ctx, void *hip_stream);
+int hp_ctx_return_stream(hp_ctx *ctx);
 int hp_ctx_synchronize(hp_ctx *ctx);
 int hp_ctx_device_name(hp_ctx *ctx, char *buf, size_t len);
 int hp_ctx_pci_bus_id(hp_ctx *ctx, char *buf, size_t len);      /* "0000:05:00.0"; len >= 16 */
@@ -381,9 +389,13 @@ int hp_agent_train_cycle_pinned(hp_agent *ag, hp_buffer *buf, hp_norm *o_norm, h
  * 32 the 32-row engine (slab32.h); *dw_split = 0 for 32 x 32 weight-gradient tiles
  * (gemm_lds.h), else the number of batch-row slices per 64 x 64 tile (dw64.h).  Any pointer may be null. */
 int hp_agent_engine(hp_agent *ag, int32_t *engine, int32_t *slab_rows, int32_t *dw_split);
-/* Launch structure of a sequence of n_updates sampled updates (ddpg_agent.py:145-147) on this agent: *form = 0 chain launch +
- * weight-gradient launch per update; 1 split launch (target networks one update ahead, the critic's weight gradients + Adam inside
- * the chain launch) + the actor's weight-gradient launch; 2 the split launch holds the actor's tiles too (one launch per update). */
+/* Launch structure of a sequence of n_updates sampled updates WITH their optimizer steps (ddpg_agent.py:145-147;
+ * hp_agent_sample_and_update, hp_agent_train_cycle) on this agent as it is now: *form = 0 chain launch + weight-gradient launch per
+ * update; 1 split launch (target networks one update ahead, the critic's weight gradients inside the chain launch) + the actor's
+ * weight-gradient launch -- single rank: optimizer steps in both launches' epilogues; data-parallel ranks on a device each: the same
+ * with the tile-wise rank exchange in front of every step, or gradients only + exchange + optimizer launches (RCCL, two-phase
+ * peer memory).  Gradient-only calls (hp_agent_forward_backward) always take form 0.  The kernels by name:
+ * hp_agent_update_kernels (rlarm_hip_debug.h). */
 int hp_agent_update_form(hp_agent *ag, int32_t n_updates, int32_t *form);
 /* Sticky health word of the learner, free for the host (pinned memory, no synchronisation): 0 = healthy.  Bit 0: a bounded
  * in-launch hand-off gave up; one bit per source beside it (several may be set): bit 4 critic chains -> weight-gradient tiles,

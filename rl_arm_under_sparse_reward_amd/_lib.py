@@ -59,6 +59,8 @@ PROTOTYPES = {
     "hp_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
     "hp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_ctx_get_stream": (C.c_int, [C.c_void_p, c_void_pp]),
+    "hp_ctx_borrow_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_ctx_return_stream": (C.c_int, [C.c_void_p]),
     "hp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hp_ctx_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "hp_ctx_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -331,36 +333,23 @@ class Context:
         self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream or 1)
 
     def torch_bridge(self):
-        """Order ONE library call that writes torch-owned device memory with torch's current stream WITHOUT rebinding the
-        context (a rebind to torch's default stream = hipStreamLegacy costs a host synchronisation per hop and takes the cached
-        graphs of the fused learner off the table while it lasts): `with ctx.torch_bridge() as note: ...; note(tensors)` --
-        on entry the context's stream waits for what torch enqueued so far (its allocator may have handed out memory whose last
-        use is still in flight there), on exit torch's stream waits for what the call enqueued, and the tensors passed to
-        `note` are recorded on the context's stream for torch's caching allocator.  A context that already runs on torch's
-        current stream needs none of it."""
+        """Run ONE library call that writes torch-owned device memory ON torch's current stream, without rebinding the context
+        (hp_ctx_borrow_stream / hp_ctx_return_stream): `with ctx.torch_bridge(): ...`.  The launches inside land in torch's
+        stream order -- the caching allocator's assumption for memory it handed out, and what the consumer of the outputs runs
+        in -- behind what the context's own stream held; the own stream catches up lazily when it is next used, so a fused
+        learner on the same context keeps its stream and its cached graphs.  No host synchronisation either way."""
         import contextlib
 
         import torch
 
         @contextlib.contextmanager
         def bridge():
-            cur = torch.cuda.current_stream(self.device_id)
-            mine = C.c_void_p()
-            check(self.lib.hp_ctx_get_stream(self.h, C.byref(mine)))
-            m, c = (mine.value or 0), (cur.cuda_stream or 1)     # torch's default stream (handle 0) is hipStreamLegacy (1)
-            kept = []
-            if m == c:                                         # already on torch's stream (e.g. use_torch_stream): plain stream order
-                yield kept.extend
-                return
-            if m <= 2:
-                raise HpError("the context is bound to a special stream handle that is not torch's current stream: call "
-                              "Context.set_stream(None) first")
-            lib_stream = torch.cuda.ExternalStream(mine.value, device=torch.device("cuda", self.device_id))
-            lib_stream.wait_stream(cur)
-            yield kept.extend
-            cur.wait_stream(lib_stream)
-            for t in kept:
-                t.record_stream(lib_stream)
+            cur = C.c_void_p(torch.cuda.current_stream(self.device_id).cuda_stream or None)
+            check(self.lib.hp_ctx_borrow_stream(self.h, cur))
+            try:
+                yield
+            finally:
+                self.lib.hp_ctx_return_stream(self.h)
         return bridge()
 
     def synchronize(self):

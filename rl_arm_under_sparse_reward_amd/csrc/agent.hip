@@ -53,8 +53,9 @@ struct CycleOpts {
     std::function<int()> between;    // what follows the draws and precedes the first update
     bool polyak_folded = false;
 };
-// Does a sequence of n_updates sampled updates on this agent take the split form (slab8_split.h)?  ONE predicate for the
-// launch logic (enqueue_updates) and for what hp_agent_update_form reports.
+// Does a sequence of n_updates sampled updates WITH optimizer steps on this agent take the split form (slab8_split.h)?  ONE
+// predicate for the launch logic (enqueue_updates: `ride` = with_adam on a slab engine is the only further condition, the others
+// follow from the terms below) and for what hp_agent_update_form reports.
 static bool update_takes_split_form(const hp_agent *a, int n_updates) {
     const bool full = a->slab8 && chain_wgs(a) + 1 + S8_AHEAD_WGS > a->ctx->cu_count;   // no CU left for the chain kernel's spare workgroups
     return a->slab8 && a->gather_ahead && !full && split_fits(a) &&
@@ -798,9 +799,9 @@ static int train_cycle_staged(hp_agent *a, hp_buffer *b, hp_norm *on, hp_norm *g
     return HP_OK;
 }
 
-// which launch structure a sequence of n_updates sampled updates takes on this agent: 0 = chain launch + weight-gradient launch,
-// 1 = split launch (slab8_split.h: target chains one update ahead, the critic's tiles + optimizer step inside the chain launch)
-// + the actor's tile launch, 2 = split launch holding the actor's tiles as well (one launch per update)
+// which launch structure a sequence of n_updates sampled updates WITH optimizer steps takes on this agent: 0 = chain launch +
+// weight-gradient launch, 1 = split launch (slab8_split.h) + the actor's tile launch (data-parallel ranks included, round 6).
+// Gradient-only sequences (with_adam false) never split; hp_agent_update_kernels names the kernels of either.
 int hp_agent_update_form(hp_agent *a, int32_t n_updates, int32_t *form) {
     HP_REQUIRE(a && form, HP_ERR_INVALID, "hp_agent_update_form: null argument");
     *form = update_takes_split_form(a, n_updates) ? 1 : 0;

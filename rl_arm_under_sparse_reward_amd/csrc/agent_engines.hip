@@ -992,6 +992,10 @@ int enqueue_adam(hp_agent *a, bool polyak_after) {
         if (polyak_after) fold_polyak(a, F);
         F.reset_sync = a->split_reset_pending;   // behind a split launch whose tiles wrote gradients only (enqueue_split_update)
         a->split_reset_pending = nullptr;
+        // plain stores in the stand-alone optimizer kernels: write-through (adam_fuse: small minibatches) pays inside a tile launch,
+        // where other workgroups still multiply while the stepped state drains; a kernel that does nothing else only waits for its
+        // own acknowledgements (forced data-parallel world 1, us/update: RCCL form 44.7 -> 43.5, separate peer exchange 45.3 -> 44.9)
+        F.wt = 0;
         const bool by4 = n % 4 == 0 && a->la.total % 4 == 0;
         HP_KLOG(by4 ? "k_adam_frag4" : "k_adam_frag");
         if (by4)
@@ -1040,6 +1044,7 @@ int enqueue_peer_adam(hp_agent *a, int u, bool polyak_after) {
     F.keep_grads = a->keep_grads_dbg ? 1 : 0;   // RLARM_KEEP_GRADS=1: hp_agent_get_grads then returns the exchanged sum
     F.reset_sync = a->split_reset_pending;
     a->split_reset_pending = nullptr;
+    F.wt = 0;   // (plain stores in the stand-alone optimizer kernels: enqueue_adam)
     ProfScope ps(a, PROF_ADAM);
     return peer_enqueue_adam(a->peer, F, a->n_arena, u, a->grad_mean);
 }

@@ -131,11 +131,76 @@ int hp_ctx_get_stream(hp_ctx *ctx, void **hip_stream) {
     return HP_OK;
 }
 
+// ---- a caller's stream for the duration of ONE call (hp_ctx_borrow_stream / hp_ctx_return_stream) ---------------------------------
+// A host that hands device outputs to a framework wants them written on the framework's stream, in its order -- without rebinding
+// the context (hp_ctx_set_stream), whose own stream carries the fused learner's cached graphs.  Between borrow and return the
+// calling thread holds the context's lock and every launch of the library goes to the borrowed stream, ordered behind what the
+// context's own stream held (a device-side wait, skipped when the own stream has been idle since the last borrow).  The way back is
+// lazy: the first entry point that uses the own stream again orders it behind the borrowed stream's work (ctx_join_foreign, from
+// CtxGuard).  Measured on a torch learner (tools/ubench/level1_gpu.py, us per update): sampler on torch's stream 2083; sampler on
+// the own stream with an event fence each way 2206-2270 -- two active queues cost that loop ~190 us whatever orders them.
+}  // extern "C" (re-opened below)
+void ctx_join_foreign(hp_ctx *c) {
+    hipStream_t f = c->foreign;
+    c->foreign = nullptr;
+    if (!f || f == c->stream) return;
+    hipEvent_t &ev = c->fence_ev[1];
+    // (the legacy default stream takes event records under its null-stream name only)
+    if ((ev || hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) &&
+        hipEventRecord(ev, f == hipStreamLegacy ? nullptr : f) == hipSuccess && hipStreamWaitEvent(c->stream, ev, 0) == hipSuccess)
+        return;
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(f);      // no event on that stream: a host wait instead (rare: once per switch back)
+}
+extern "C" {
+
+int hp_ctx_borrow_stream(hp_ctx *ctx, void *hip_stream) {
+    HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_borrow_stream: null ctx");
+    ctx->mu.lock();                      // held until hp_ctx_return_stream (recursive: the calls in between lock it again)
+    (void)hipSetDevice(ctx->device);
+    auto fail = [&](const char *what, hipError_t e) {
+        hp_set_error("hp_ctx_borrow_stream: %s: %s", what, hipGetErrorString(e));
+        ctx->mu.unlock();
+        return HP_ERR_HIP;
+    };
+    if (ctx->borrowed_from) {
+        hp_set_error("hp_ctx_borrow_stream: a stream is borrowed already (hp_ctx_return_stream first)");
+        ctx->mu.unlock();
+        return HP_ERR_STATE;
+    }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : hipStreamLegacy;   // NULL: the null stream, a framework's default
+    if (s != ctx->stream) {
+        if (ctx->foreign && ctx->foreign != s) ctx_join_foreign(ctx);
+        if (ctx->own_dirty) {            // the borrowed stream's work waits for what the own stream holds
+            hipEvent_t &ev = ctx->fence_ev[0];
+            hipError_t e = ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess && (uintptr_t)ctx->stream > 2) e = hipEventRecord(ev, ctx->stream);
+            else if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess && (uintptr_t)ctx->stream > 2) e = hipStreamWaitEvent(s == hipStreamLegacy ? nullptr : s, ev, 0);
+            if (e != hipSuccess) return fail("ordering the borrowed stream behind the context's", e);
+            ctx->own_dirty = false;
+        }
+    }
+    ctx->borrowed_from = ctx->stream;
+    ctx->stream = s;
+    return HP_OK;
+}
+
+int hp_ctx_return_stream(hp_ctx *ctx) {
+    HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_return_stream: null ctx");
+    HP_REQUIRE(ctx->borrowed_from, HP_ERR_STATE, "hp_ctx_return_stream: no stream is borrowed");   // (only the borrowing thread can get here with it set)
+    if (ctx->stream != ctx->borrowed_from) ctx->foreign = ctx->stream;
+    ctx->stream = ctx->borrowed_from;
+    ctx->borrowed_from = nullptr;
+    ctx->mu.unlock();
+    return HP_OK;
+}
+
 int hp_ctx_synchronize(hp_ctx *ctx) {
     HP_REQUIRE(ctx, HP_ERR_INVALID, "hp_ctx_synchronize: null ctx");
     hipStream_t s;
     {   // wait outside the lock: a feeder thread may keep storing while this thread waits for a cycle
-        std::lock_guard<std::recursive_mutex> guard(ctx->mu);
+        CtxGuard guard(ctx);             // (also orders the own stream behind a stream borrowed earlier)
         s = ctx->stream;
     }
     // Short waits spin on the stream's status: a blocking hipStreamSynchronize parks the thread and its wake-up costs
@@ -294,6 +359,8 @@ void hp_ctx_destroy(hp_ctx *ctx) {
     ctx->reward_ws.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
+    for (hipEvent_t ev : ctx->fence_ev)
+        if (ev) (void)hipEventDestroy(ev);
     delete ctx;
 }
 

@@ -71,6 +71,11 @@ struct hp_ctx {
     hipStream_t stream = nullptr;      // stream kernels are enqueued on
     hipStream_t own_stream = nullptr;  // created by the context
     hipEvent_t order_ev = nullptr;     // hp_ctx_set_stream: orders the new stream behind the old one's work
+    // hp_ctx_borrow_stream / hp_ctx_return_stream (context.hip): the stream to go back to while a caller's stream is borrowed; a
+    // borrowed stream whose work the own stream has not been ordered behind yet; has the own stream been used since the last borrow?
+    hipStream_t borrowed_from = nullptr, foreign = nullptr;
+    bool own_dirty = true;
+    hipEvent_t fence_ev[2] = {nullptr, nullptr};   // own -> borrowed, borrowed -> own
     int cu_count = 0;
     char name[128] = {0};
     // Every entry point that enqueues on the stream or touches a handle's host mirror holds this for the duration of the
@@ -80,9 +85,16 @@ struct hp_ctx {
     std::recursive_mutex mu;
     DevBuf reward_ws;                  // scratch of the host-array forms of hp_compute_reward / hp_is_success
 };
+void ctx_join_foreign(hp_ctx *c);   // context.hip: order the context's stream behind the work of a stream that was borrowed
 struct CtxGuard {   // + the calling thread's current device: HIP keeps that per thread and a feeder thread starts on device 0
     std::lock_guard<std::recursive_mutex> g;
-    explicit CtxGuard(hp_ctx *c) : g(c->mu) { (void)hipSetDevice(c->device); }
+    explicit CtxGuard(hp_ctx *c) : g(c->mu) {
+        (void)hipSetDevice(c->device);
+        if (!c->borrowed_from) {         // (inside a borrow the launches go to the caller's stream: nothing to join, nothing dirtied)
+            if (c->foreign) ctx_join_foreign(c);
+            c->own_dirty = true;
+        }
+    }
 };
 #define HP_SERIALISE(handle) CtxGuard hp_serialise_guard_((handle)->ctx)
 

@@ -140,9 +140,8 @@ class DeviceEpisodeBuffer:
             for k, t in idx.items():
                 setattr(o, k, t.data_ptr())
         fn = self.lib.hp_buffer_sample_dev_f32 if f32_rows else self.lib.hp_buffer_sample_dev
-        with self.ctx.torch_bridge() as note:
+        with self.ctx.torch_bridge():
             _lib.check(fn(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold), float(clip_obs), C.byref(o)))
-            note(list(out.values()) + (list(idx.values()) if idx else []))
         return (out, idx) if with_indices else out
 
     def __del__(self):

@@ -182,4 +182,41 @@ def test_torch_learner_on_the_gpu_fed_by_the_device_output_sampler():
             tol = 1e-5 if i == 0 else 1e-5 * 1.3 ** min(i, 20)
             assert abs(res[name] - want_log[i][j]) <= tol * max(abs(want_log[i][j]), 1e-2), (i, name, res[name], want_log[i][j])
     assert state_equal(rng, *rs.get_state()[1:3])
-    ctx().set_stream(None)      # back on the context's own stream for whatever test runs next
+
+
+def test_sample_device_leaves_the_fused_learner_on_its_graphs():
+    """sample_device() used to rebind the shared Context to torch's stream -- hipStreamLegacy for torch's
+    default -- and leave it there, after which hp_agent_train_cycle refused graphs for good.  Now the sampler borrows torch's
+    stream for its own call only (hp_ctx_borrow_stream / hp_ctx_return_stream): a fused learner on the same context, interleaved
+    with sample_device() calls consumed by torch, keeps replaying its cycle graph and ends bit-identical to the learner that was
+    never interleaved (the sampler's draws are rewound so that both see the same random stream)."""
+    import ctypes as C
+    from rl_arm_under_sparse_reward_amd import _lib
+    from rl_arm_under_sparse_reward_amd.arguments import Args
+    from rl_arm_under_sparse_reward_amd.ddpg_agent import NET_ACTOR, NET_CRITIC, ddpg_agent
+
+    def run(interleave):
+        torch.manual_seed(0)
+        rng = fresh_rng(31)
+        agent = ddpg_agent(Args(batch_size=256, buffer_size=32 * 100), None, dict(ENV_PARAMS), ctx=ctx(), rng=rng)
+        agent.buffer.store_episode(make_episodes(20, seed=5, mode="walk"))
+        sums = []
+        for c in range(4):
+            agent.train_cycle(make_episodes(2, seed=90 + c, mode="walk"), 12)
+            if interleave:
+                state = rng.get_state()
+                mb = agent.buffer.sample_device(256, agent.o_norm, agent.g_norm, clip_obs=200)
+                sums.append(float((mb["x"].double().sum() + mb["r"].double().sum()).item()))     # consumed on torch's stream
+                rng.set_state(state)
+        mode, stream = C.c_int32(), C.c_void_p()
+        _lib.check(agent.lib.hp_agent_cycle_mode(agent.h, C.byref(mode)))
+        _lib.check(agent.lib.hp_ctx_get_stream(agent.ctx.h, C.byref(stream)))
+        return agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent.last_losses(12), mode.value, stream.value or 0, sums
+
+    plain = run(False)
+    mixed = run(True)
+    assert plain[3] == 1 and mixed[3] == 1                      # the cycle replays as a hipGraph in both
+    assert mixed[4] == plain[4] and mixed[4] > 2                # the context is still on its own stream (not hipStreamLegacy = 1)
+    for a, b in zip(plain[:3], mixed[:3]):
+        assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+    assert len(mixed[5]) == 4 and all(np.isfinite(v) for v in mixed[5])

@@ -67,7 +67,8 @@ def main():
             # FETCH_SIZE / WRITE_SIZE count KiB (the x2 fetch correction is applied further down); every other counter is a plain count
             unit = "KiB/launch" if counter in ("FETCH_SIZE", "WRITE_SIZE") else "per launch"
             print(f"  {str(name)[:50]:50s} {counter:12s} n={n:6d} avg={avg:12.1f} {unit}")
-            short = str(name).split("(")[0].split("::")[-1]   # k_fb_slab8 lives in a namespace per slab height
+            short = str(name).strip()
+            short = (short[5:] if short.startswith("void ") else short).split("(")[0].split("::")[-1]   # "void s8r4::k_fb_split8<0>(...)" -> "k_fb_split8<0>"
             table.setdefault(short, {})[counter] = avg
     if out_json:
         kernels = {}
