@@ -4,7 +4,7 @@ CPU restatement of the reference's hot path (HER 'future' relabel + episodic rep
 sampling + running normalizer + DDPG actor/critic update).  It exists so that the HIP
 path can be *checked*; it is never the thing shipped or measured.
 
-Who may import this package (enforced by tests/test_no_oracle_in_product.py):
+Who may import this package (enforced by tests/test_abi.py::test_product_never_imports_oracle):
   * tests/
   * __graft_entry__.smoke()
   * bench.py's `cpu_baseline` leg
