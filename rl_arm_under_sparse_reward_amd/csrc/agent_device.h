@@ -235,6 +235,94 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
     ADAM_STAMP(3);
 }
 
+// ---- the stand-alone optimizer kernels (k_adam_frag4, k_peer_adam, k_peer_adam2: every transport that exchanges the whole
+// gradient vector) ------------------------------------------------------------------------------------------------------------------
+// Thread t of those kernels used to step arena floats 4 t .. 4 t + 3: 64 consecutive threads = 256 consecutive reduction indices of
+// ONE row.  For the 256-wide layers that made the forward-fragment store a 16-byte piece every 1 KiB per lane and the dX-fragment
+// store four 4-byte pieces at 16-byte stride: 1.2 M partial L2 writes per step (k_adam_frag4: 8.9 us for 10.5 MB of traffic).
+// adam_quad_remap deals the float4s of such a layer in blocks of 4 rows x 64 columns instead -- lane = (row & 3) + 4 * (column
+// group) -- so the four lanes of a quad hold the same four columns of four consecutive rows: their forward-fragment float4s are
+// 64 contiguous bytes, and a 4 x 4 transpose inside the quad (DPP quad_perm, no LDS) turns the dX-fragment pieces into one float4
+// per lane, 64 contiguous bytes per quad again.  Same elements, same arithmetic: only who stores what changes.
+// returns the arena index this thread steps; quad: it sits in a dealt block (quad lanes = rows n .. n + 3 of the same columns)
+__device__ __forceinline__ int adam_quad_remap(const ArenaMap &am, int t, bool &quad) {
+    const int idx = 4 * t;
+    quad = false;
+    if (am.mode != 1) return idx;
+    const bool critic = idx >= am.la.total;
+    const NetLayout &l = critic ? am.lc : am.la;
+    const int base = critic ? am.la.total : 0, r = idx - base, K = am.H;
+    int w0 = -1;
+    if (r >= l.w2 && r < l.b2) w0 = l.w2;
+    else if (r >= l.w3 && r < l.b3) w0 = l.w3;
+    else if (r >= l.w4 && r < l.b4) w0 = l.w4;
+    if (w0 < 0 || (K & 63) || ((base + w0) & 15)) return idx;      // (16 floats = the 4 threads of a quad start together)
+    const int local = (r - w0) >> 2, blk = local >> 6, w = local & 63, kblocks = K >> 6;
+    const int row = 4 * (blk / kblocks) + (w & 3), k = 64 * (blk % kblocks) + 4 * (w >> 2);
+    quad = true;
+    return base + w0 + row * K + k;
+}
+// lane (quad position nn) gives v[0..3]; returns in out[c] what quad lane c held at index nn: the 4 x 4 transpose of the quad
+__device__ __forceinline__ void quad_transpose4(const float (&v)[4], float (&out)[4], int nn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // round r: lane s sends v[(s + r) & 3] to lane (s + r) & 3, which files it under out[s]
+        const float send = ((nn + r) & 3) == 0 ? v[0] : ((nn + r) & 3) == 1 ? v[1] : ((nn + r) & 3) == 2 ? v[2] : v[3];
+        float got;
+        const int bits = __float_as_int(send);
+        // quad_perm: destination lane d reads source lane (d - r) & 3
+        if (r == 0) got = send;
+        else if (r == 1) got = __int_as_float(__builtin_amdgcn_mov_dpp(bits, 0x93 /* [3,0,1,2] */, 0xf, 0xf, true));
+        else if (r == 2) got = __int_as_float(__builtin_amdgcn_mov_dpp(bits, 0x4e /* [2,3,0,1] */, 0xf, 0xf, true));
+        else got = __int_as_float(__builtin_amdgcn_mov_dpp(bits, 0x39 /* [1,2,3,0] */, 0xf, 0xf, true));
+        const int src = (nn - r) & 3;
+        out[0] = src == 0 ? got : out[0];
+        out[1] = src == 1 ? got : out[1];
+        out[2] = src == 2 ? got : out[2];
+        out[3] = src == 3 ? got : out[3];
+    }
+}
+// torch.optim.Adam on 4 consecutive arena elements of a dealt block + their fragment copies (+ the folded soft update): the
+// arithmetic of adam_apply4, the stores as described above.  Call from wave-uniform control flow over whole quads.
+__device__ __forceinline__ void adam_step4_quad(const AdamFuse &F, int idx0, const float (&g)[4]) {
+    AdamState4 S;
+    adam_fetch4(S, F, idx0);
+    const float4 p4 = S.p, m4 = S.m, v4 = S.v;
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mm[j] = __fadd_rn(mm[j], __fmul_rn(F.w, __fsub_rn(g[j], mm[j])));
+        vv[j] = __fadd_rn(__fmul_rn(vv[j], F.b2), __fmul_rn(__fmul_rn(F.omb2, g[j]), g[j]));
+        const float sq = __fsqrt_rn(vv[j]);
+        const float denom = __fadd_rn(__fdiv_rn(sq, S.bc2_sqrt), F.eps);
+        pp[j] = __fadd_rn(pp[j], __fdiv_rn(__fmul_rn(S.neg_step_size, mm[j]), denom));
+    }
+    *reinterpret_cast<float4 *>(F.p_out + idx0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4 *>(F.m + idx0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4 *>(F.v + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    float tt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (F.tgt) {   // same expression as k_polyak_frag, on the parameters just stepped
+        const float4 t4 = *reinterpret_cast<const float4 *>(F.tgt + idx0);
+        const float told[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tt[j] = __fadd_rn(__fmul_rn(F.one_minus, pp[j]), __fmul_rn(F.polyak, told[j]));
+        *reinterpret_cast<float4 *>(F.tgt + idx0) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+    }
+    int of, od;
+    frag8_offsets(F.am, idx0, of, od);
+    if (of >= 0) {
+        *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (F.tgt) *reinterpret_cast<float4 *>(F.fragFT + of) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+    }
+    if (od >= 0) {
+        // od = this row's slot (n & 3 = nn) of column k; the quad's transposed float4 for column k + nn starts 3 nn floats on
+        const int nn = (int)(threadIdx.x & 3);
+        float col[4] = {0.f, 0.f, 0.f, 0.f};
+        quad_transpose4(pp, col, nn);
+        *reinterpret_cast<float4 *>(F.fragD + od + 3 * nn) = make_float4(col[0], col[1], col[2], col[3]);
+    }
+}
+
 // optimizer kernels that follow a split launch whose tiles left the step to them (SPLIT_TILES_GRADS): block 0, threads 64 .. 127 clear
 // the counter set that launch counted in, as the actor's tile launch does in the fused forms (gemm_lds.h)
 __device__ __forceinline__ void split_reset_by_block0(const AdamFuse &F) {

@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFu
     if (!peer_wait(D, D.flags_g[D.rank], epoch)) return;   // dead exchange: no step from a partial sum (peer.h)
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     split_reset_by_block0(F);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n4) return;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= n4) return;
+    bool quad;
+    const int idx0 = adam_quad_remap(F.am, t0, quad), t = idx0 >> 2;   // which float4 of the arena this thread steps (agent_device.h)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t bytes = (size_t)n4 * 16;
     for (int q = 0; q < D.world; ++q) {   // rank order: the same float32 sum on every rank
@@ -38,7 +40,8 @@ __global__ __launch_bounds__(256) void k_peer_adam(const PeerDev D, const AdamFu
     }
     const float g[4] = {acc.x, acc.y, acc.z, acc.w};
     if (F.keep_grads) *reinterpret_cast<float4 *>(const_cast<float *>(F.grads_base) + 4 * (size_t)t) = acc;
-    adam_apply4(F, 4 * t, g);
+    if (quad) adam_step4_quad(F, idx0, g);
+    else adam_apply4(F, idx0, g);
 }
 
 
@@ -51,13 +54,16 @@ __global__ __launch_bounds__(256) void k_peer_adam2(const PeerDev D, const AdamF
     if (!peer_wait(D, D.flags_r[D.rank], epoch, 3u)) return;
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     split_reset_by_block0(F);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n4) return;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= n4) return;
+    bool quad;
+    const int idx0 = adam_quad_remap(F.am, t0, quad), t = idx0 >> 2;
     const int owner = t / peer_slice_len(D, n4);
     const float4 acc = peer_load4(D.red[owner][par], (size_t)n4 * 16, (unsigned)t * 16u, owner == D.rank);
     const float g[4] = {acc.x, acc.y, acc.z, acc.w};
     if (F.keep_grads) *reinterpret_cast<float4 *>(const_cast<float *>(F.grads_base) + 4 * (size_t)t) = acc;
-    adam_apply4(F, 4 * t, g);
+    if (quad) adam_step4_quad(F, idx0, g);
+    else adam_apply4(F, idx0, g);
 }
 
 static int peer_enqueue_adam(hp_peer *p, const AdamFuse &F, int n_arena, int u, bool mean) {
@@ -299,9 +305,12 @@ __global__ __launch_bounds__(256) void k_adam_frag4(const AdamFuse F, const floa
     if (blockIdx.x == 0 && threadIdx.x < 64) loss_finalize(F);
     split_reset_by_block0(F);
     if (t >= n4) return;
-    const float4 g4 = *reinterpret_cast<const float4 *>(g + 4 * t);
+    bool quad;
+    const int idx0 = adam_quad_remap(F.am, t, quad);   // the 256-wide layers dealt in 4-row x 64-column blocks (agent_device.h)
+    const float4 g4 = *reinterpret_cast<const float4 *>(g + idx0);
     const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-    adam_apply4(F, 4 * t, gv);
+    if (quad) adam_step4_quad(F, idx0, gv);
+    else adam_apply4(F, idx0, gv);
 }
 
 __global__ void k_polyak_frag(float *__restrict__ tgt, const float *__restrict__ src, float *fragFT, int n,
