@@ -586,9 +586,8 @@ def main():
     waves0 = r.env_waves if r.env_feeder is not None else 0
     t0 = time.perf_counter()
     r.run_steps(a.steps)
-    r.sync()
-    barrier(world)
-    r.sync()
+    r.sync()                      # this rank's K steps are done (ctx.synchronize + torch.cuda.synchronize) ...
+    barrier(world)                # ... and every other rank's: the region ends when the last rank leaves its sync
     dt = time.perf_counter() - t0
     gc.enable()
     r.agent.check_exchange()      # a timed region in which an exchange wait timed out (steps skipped) is not a measurement
