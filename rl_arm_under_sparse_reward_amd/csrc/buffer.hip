@@ -195,27 +195,35 @@ __global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) 
     const int len = unit == 0 ? 2 * od : unit == 1 ? gd : ad;
     const bool tail = unit != 3 && 2 * j + 1 >= len;      // last unit of an odd-length vector
     const int e0 = unit == 3 ? 0 : (tail ? len - 2 : 2 * j);
-    // per slot (the unit's two doubles): which output it feeds.  dst 0: x, 1: x_next, 2: actions, -1: nothing
-    int dst[2], off[2];
+    // per slot (the unit's two doubles): where it goes -- a primary output row (x, x_next or actions; nullptr: nowhere) and, for g',
+    // x_next as well -- and the constants of ONE branch-free expression for every lane: normalised elements clip at clip_obs, subtract
+    // their mean, divide by their std, clip at the normaliser's range; an action passes through it unchanged ((v - 0) / 1 between
+    // infinite clips is v, exactly).  (The first version branched per destination: 142 branches in the kernel, as many scalar
+    // instructions as vector ones.)
+    float *p0[2], *p1[2];
+    int stride0[2], off[2];
     float mu[2] = {0.f, 0.f};
-    double sd[2] = {1.0, 1.0}, clip[2] = {0.0, 0.0};
+    double sd[2] = {1.0, 1.0}, clip[2] = {INFINITY, INFINITY}, cobs[2] = {INFINITY, INFINITY};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int el = e0 + s;
         const bool ok = unit != 3 && !(tail && s == 0);
-        dst[s] = -1;
+        p0[s] = p1[s] = nullptr;
+        stride0[s] = ldx;
         off[s] = 0;
         if (ok && unit == 0) {
             const int col = el < od ? el : el - od;
-            dst[s] = el < od ? 0 : 1;
+            p0[s] = el < od ? A.x : A.xn;
             off[s] = col;
-            mu[s] = A.onz->mean[col]; sd[s] = A.onz->std[col]; clip[s] = A.clip_o;
+            mu[s] = A.onz->mean[col]; sd[s] = A.onz->std[col]; clip[s] = A.clip_o; cobs[s] = A.clip_obs;
         } else if (ok && unit == 1) {
-            dst[s] = 0;                 // ... and x_next: g_next := g (ddpg_agent.py:231)
+            p0[s] = A.x;
+            p1[s] = A.xn;               // g_next := g (ddpg_agent.py:231)
             off[s] = od + el;
-            mu[s] = A.gnz->mean[el]; sd[s] = A.gnz->std[el]; clip[s] = A.clip_g;
+            mu[s] = A.gnz->mean[el]; sd[s] = A.gnz->std[el]; clip[s] = A.clip_g; cobs[s] = A.clip_obs;
         } else if (ok) {
-            dst[s] = 2;
+            p0[s] = A.a;
+            stride0[s] = ad;
             off[s] = el;
         }
     }
@@ -250,17 +258,11 @@ __global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) 
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const double val = s ? v[k].y : v[k].x;
-                if (!live || dst[s] < 0) continue;
-                if (dst[s] == 2) {
-                    if (A.a) A.a[m * ad + off[s]] = (float)val;
-                    continue;
-                }
-                double c = fmin(fmax(val, -A.clip_obs), A.clip_obs);                    // _preproc_og
+                double c = fmin(fmax(val, -cobs[s]), cobs[s]);                           // _preproc_og
                 c = __ddiv_rn(__dsub_rn(c, (double)mu[s]), sd[s]);                       // normalizer.normalize
                 const float x = (float)fmin(fmax(c, -clip[s]), clip[s]);
-                if (dst[s] == 0) { if (A.x) A.x[m * ldx + off[s]] = x; }
-                else if (A.xn) A.xn[m * ldx + off[s]] = x;
-                if (unit == 1 && A.xn) A.xn[m * ldx + off[s]] = x;
+                if (live && p0[s]) p0[s][m * stride0[s] + off[s]] = x;
+                if (live && p1[s]) p1[s][m * ldx + off[s]] = x;
             }
             // reward (her.py:38): (ag_next - g')^2 per component in lanes l < gd, lane 0 of the half adds them left to right
             const double gx = __shfl(v[k].x, g_lane), gy = __shfl(v[k].y, g_lane);
@@ -341,22 +343,37 @@ __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P)
     const int load = l < 15 ? 0 : (l == 15 || l == 31) ? 1 : (l == 16 || l == 17) ? 2 : 3;
     const int gj = l == 31 ? 1 : 0;                        // which half of g'
     // what this lane COMPUTES, two slots: lanes 0-14 columns 4 l + s, lanes 16-30 columns 4 (l - 16) + 2 + s (handed down by lane
-    // l - 16), lanes 15 / 31 the goal components 2 gj + s.  dst 0: x, 1: x_next, 2: actions, 3: goal column of both, -1: nothing
-    int dst[2], off[2];
+    // l - 16), lanes 15 / 31 the goal components 2 gj + s.  Per slot: a primary output row (x, x_next or actions; nullptr: nowhere),
+    // x_next as well for a goal component, and the constants of one branch-free clip / normalise expression (an action passes
+    // through it unchanged: (v - 0) / 1 between infinite clips), as in k_gather_fused2
+    float *p0[2], *p1[2];
+    int stride0[2], off[2];
+    bool goal[2] = {false, false};
     float mu[2] = {0.f, 0.f};
-    double sd[2] = {1.0, 1.0}, clip[2] = {0.0, 0.0};
+    double sd[2] = {1.0, 1.0}, clip[2] = {INFINITY, INFINITY}, cobs[2] = {INFINITY, INFINITY};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        dst[s] = -1;
+        p0[s] = p1[s] = nullptr;
+        stride0[s] = ldx;
         off[s] = 0;
         if (load == 1) {
             const int c = 2 * gj + s;
-            if (c < gd) { dst[s] = 3; off[s] = od + c; mu[s] = A.gnz->mean[c]; sd[s] = A.gnz->std[c]; clip[s] = A.clip_g; }
+            if (c < gd) {
+                goal[s] = true;
+                p0[s] = A.x; p1[s] = A.xn;                               // g_next := g (ddpg_agent.py:231)
+                off[s] = od + c; mu[s] = A.gnz->mean[c]; sd[s] = A.gnz->std[c]; clip[s] = A.clip_g; cobs[s] = A.clip_obs;
+            }
         } else if (l != 15 && l != 31) {
             const int col = 4 * (l & 15) + 2 * (l >> 4) + s;          // column of the 64-float pair
             const int oc = col < rw ? col : col - rw;                 // ... inside its row
-            if (oc < od) { dst[s] = col < rw ? 0 : 1; off[s] = oc; mu[s] = A.onz->mean[oc]; sd[s] = A.onz->std[oc]; clip[s] = A.clip_o; }
-            else if (col < rw && oc < od + ad) { dst[s] = 2; off[s] = oc - od; }
+            if (oc < od) {
+                p0[s] = col < rw ? A.x : A.xn;
+                off[s] = oc; mu[s] = A.onz->mean[oc]; sd[s] = A.onz->std[oc]; clip[s] = A.clip_o; cobs[s] = A.clip_obs;
+            } else if (col < rw && oc < od + ad) {
+                p0[s] = A.a;
+                stride0[s] = ad;
+                off[s] = oc - od;
+            }
         }
     }
     const int rc = l < gd ? l : gd - 1;                   // reward: lanes l < gd of each half hold component l
@@ -395,18 +412,13 @@ __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P)
             const float lo = l < 16 ? v[k].f[0] : z, hi = l < 16 ? v[k].f[1] : w;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                if (!live || dst[s] < 0) continue;
                 const float raw = s ? hi : lo;
-                if (dst[s] == 2) {
-                    if (A.a) A.a[m * ad + off[s]] = raw;
-                    continue;
-                }
-                double x = dst[s] == 3 ? v[k].d[s] : (double)raw;
-                x = fmin(fmax(x, -A.clip_obs), A.clip_obs);                            // _preproc_og
+                double x = goal[s] ? v[k].d[s] : (double)raw;
+                x = fmin(fmax(x, -cobs[s]), cobs[s]);                                  // _preproc_og
                 x = __ddiv_rn(__dsub_rn(x, (double)mu[s]), sd[s]);                      // normalizer.normalize
                 const float o = (float)fmin(fmax(x, -clip[s]), clip[s]);
-                if (dst[s] != 1 && A.x) A.x[m * ldx + off[s]] = o;
-                if (dst[s] != 0 && A.xn) A.xn[m * ldx + off[s]] = o;                    // (goal columns: both, g_next := g, ddpg_agent.py:231)
+                if (live && p0[s]) p0[s][m * stride0[s] + off[s]] = o;
+                if (live && p1[s]) p1[s][m * ldx + off[s]] = o;
             }
             // reward (her.py:38) on the float64 goals: the same left-to-right sum as every other gather
             const double ax = __shfl(v[k].d[0], a_lane), ay = __shfl(v[k].d[1], a_lane);
