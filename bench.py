@@ -1018,6 +1018,20 @@ def sample_kernel_fused_fields(a, r):
                        "those of float32-rounded observations (tests/test_gpu_her.py::test_sample_device_f32_rows_throughput_mode)"}
     except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the run its line
         f32 = {"error": str(e)}
+    # ... and the opt-in fast draw (hp_buffer_sample_dev_fast: Philox4x32-10 keyed by (seed, call, transition) inside the gather kernel;
+    # SURVEY 8b rng_mode): the WHOLE sample -- index draw included -- as one launch, beside the MT19937 path's draw + gather
+    fast = None
+    try:
+        fu = C.c_double()
+        _l.check(r.ctx.lib.hp_buffer_sample_dev_fast_us(buf.h, r.agent.o_norm.h, r.agent.g_norm.h, 1 << 18, float(r.agent.her_module.future_p),
+                                                        float(r.agent.her_module.sq_threshold), 200.0, 20, 0, C.byref(fu)))
+        fast = {"kernel": "k_gather_fused2<.., fast> (hp_buffer_sample_dev_fast)", "batch": 1 << 18, "whole_sample_us": round(fu.value, 3),
+                "mt19937_path_whole_sample_us": round(big["avg_launch_us"] + big["index_draw_kernel_us"], 3),
+                "transitions_per_s": round((1 << 18) / (fu.value * 1e-6), 1),
+                "note": "not the reference's random stream (opt-in); indices bit-equal to the numpy twin, everything behind them unchanged "
+                        "(tests/test_gpu_her.py::test_sample_device_fast_draw_matches_its_oracle_twin)"}
+    except Exception as e:      # noqa: BLE001
+        fast = {"error": str(e)}
     # PMC traffic of the kernel (separate rocprofv3 --pmc passes, tools/gpu_round6.sh): the committed summary of the 2^18 launch
     traffic, tsrc = None, None
     for rnd in ("r06",):
@@ -1037,6 +1051,7 @@ def sample_kernel_fused_fields(a, r):
         "avg_launch_us": big["avg_launch_us"], "batch": 1 << 18, "traffic": traffic, "traffic_source": tsrc,
         "at_bench_batch": fused[a.batch],
         "throughput_mode_f32_rows": f32,
+        "fast_draw": fast,
         "note": "achieved = SURVEY 8d's algorithmic 528 B / transition (float32 storage) x 2^18 transitions / the kernel's average "
                 "launch time; this build keeps float64 rows (bit-identical rewards and inputs), so the bytes it really moves are "
                 "812 B / transition (the *_this_build figures).  Random 432-byte row pairs out of this run's shard "

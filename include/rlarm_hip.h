@@ -39,8 +39,8 @@ extern "C" {
  * rlarm_hip_debug.h (no stability promise), hp_agent_fused_status is gone (round 3), hp_agent_train_cycle_pinned,
  * hp_peer_set_gate, hp_ctx_pci_bus_id, hp_agent_status were added.  3 (round 5): hp_buffer_sample_dev (device-output fused
  * sampler) was added.  4 (round 6): hp_ctx_get_stream and hp_ctx_borrow_stream / hp_ctx_return_stream were added (a host that hands
- * device outputs to a framework has them written on the framework's stream for that call instead of rebinding the context), and the sampler's throughput mode
- * (hp_buffer_enable_f32_rows, hp_buffer_sample_dev_f32).  hp_abi_version() returns the
+ * device outputs to a framework has them written on the framework's stream for that call instead of rebinding the context), and the sampler's throughput modes
+ * (hp_buffer_enable_f32_rows, hp_buffer_sample_dev_f32, hp_buffer_sample_dev_fast).  hp_abi_version() returns the
  * library's value; a host must refuse a library whose version differs from the header it was built against. */
 #define HP_ABI_VERSION 4
 
@@ -179,6 +179,14 @@ int hp_buffer_sample_dev(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *
 int hp_buffer_enable_f32_rows(hp_buffer *buf);
 int hp_buffer_sample_dev_f32(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
                              double sq_threshold, double clip_obs, const hp_sample_dev_out *dev_out);
+/* Fast draw (SURVEY 8b's `rng_mode` = Philox; opt-in, NOT the reference's random stream): the same device-output minibatch with the
+ * index draw inside the gather kernel -- no hp_rng, no sequential draw launch.  Transition m of call `call` takes
+ * (r0..r3) = Philox4x32-10(counter (m, call), key `seed`) [Random123] and draws her.py:24-33's four values from them:
+ * e = floor(r0 N / 2^32), t = floor(r1 T / 2^32), her = r2 2^-32 < future_p, future_t = t + 1 + floor(r3 (T - t) / 2^32).
+ * Deterministic in (seed, call): the caller owns the counter (a rank passes seed + rank and call = 0, 1, 2, ...).  f32_rows != 0
+ * reads the throughput rows.  Gather, relabel, reward, clip and normalisation are those of hp_buffer_sample_dev, bit for bit. */
+int hp_buffer_sample_dev_fast(hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p, double sq_threshold,
+                              double clip_obs, uint64_t seed, uint64_t call, int32_t f32_rows, const hp_sample_dev_out *dev_out);
 
 /* ---- GoalEnv reward / success as batched device ops --------------------------------------------
  * compute_reward (bmirobot_env_push_F.py:84-90 -> goal_distance :20-23; byte-identical in

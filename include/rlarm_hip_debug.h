@@ -34,6 +34,10 @@ int hp_buffer_sample_device_us(hp_buffer *buf, hp_rng *rng, int64_t batch, doubl
 int hp_buffer_sample_dev_us(hp_buffer *buf, hp_rng *rng, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p,
                             double sq_threshold, double clip_obs, int32_t reps, int32_t f32_rows, double *draw_us, double *gather_us);
 
+/* diagnostic: device microseconds per hp_buffer_sample_dev_fast launch (index draw inside the gather kernel) */
+int hp_buffer_sample_dev_fast_us(hp_buffer *buf, hp_norm *o_norm, hp_norm *g_norm, int64_t batch, double future_p, double sq_threshold,
+                                 double clip_obs, int32_t reps, int32_t f32_rows, double *us);
+
 /* test hook: load torch.optim.Adam state (exp_avg, exp_avg_sq in the flat order of utils.py:18-27; either may be NULL) and the
  * number of optimizer steps already taken (shared by both optimizers, ddpg_agent.py:272,277 step together) */
 int hp_agent_set_adam(hp_agent *ag, int32_t net, const float *m_host, const float *v_host, int64_t n, int64_t step);

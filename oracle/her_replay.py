@@ -81,11 +81,46 @@ def draw_her_indices(rng: np.random.RandomState, n_episodes: int, T: int, batch:
     return episode_idxs, t_samples, her_mask, future_t_all
 
 
-def sample_her_transitions(episode_batch, batch, future_p, rng, reward_fn=compute_reward):
-    """her.py:13-41 on a dict holding obs/ag/g/actions/obs_next/ag_next."""
+# ---- fast draw (the build's opt-in rng_mode of SURVEY 8b; NOT the reference's stream): counter-based indices ----------------------
+PHILOX_M0, PHILOX_M1, PHILOX_W0, PHILOX_W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 of Random123 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC11), vectorised
+    over numpy arrays of uint64 holding 32-bit values.  Pinned by the package's known-answer vectors (tests/test_oracle_rng.py):
+    counter 0, key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8; all ones -> 408f276d 41c83b0e a20bc7c6 6d5451fd; digits of pi ->
+    d16cfe09 94fdcceb 5001e420 24126ea1."""
+    u, mask = np.uint64, np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3))
+    k0, k1 = u(k0), u(k1)
+    for _ in range(10):
+        p0, p1 = u(PHILOX_M0) * c0, u(PHILOX_M1) * c2
+        c0, c1, c2, c3 = (p1 >> u(32)) ^ c1 ^ k0, p1 & mask, (p0 >> u(32)) ^ c3 ^ k1, p0 & mask
+        k0, k1 = (k0 + u(PHILOX_W0)) & mask, (k1 + u(PHILOX_W1)) & mask
+    return c0, c1, c2, c3
+
+
+def draw_her_indices_fast(n_episodes: int, T: int, batch: int, future_p: float, seed: int, call: int):
+    """The four draws of her.py:24-33 for transition m of call `call` from Philox4x32-10(counter (m, call), key seed):
+    e = floor(r0 N / 2^32), t = floor(r1 T / 2^32), her = r2 2^-32 < future_p, future_t = t + 1 + floor(r3 (T - t) / 2^32)
+    (csrc/buffer.hip: fs_fast_rec is the device twin)."""
+    m = np.arange(batch, dtype=np.uint64)
+    mask = np.uint64(0xFFFFFFFF)
+    r0, r1, r2, r3 = philox4x32_10(m & mask, m >> np.uint64(32), np.uint64(call & 0xFFFFFFFF), np.uint64((call >> 32) & 0xFFFFFFFF),
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    e = ((r0 * np.uint64(n_episodes)) >> np.uint64(32)).astype(np.int64)
+    t = ((r1 * np.uint64(T)) >> np.uint64(32)).astype(np.int64)
+    her = (r2.astype(np.float64) * 2.0 ** -32) < future_p
+    future_t = t + 1 + ((r3 * (np.uint64(T) - t.astype(np.uint64))) >> np.uint64(32)).astype(np.int64)
+    return e, t, her, future_t
+
+
+def sample_her_transitions(episode_batch, batch, future_p, rng, reward_fn=compute_reward, indices=None):
+    """her.py:13-41 on a dict holding obs/ag/g/actions/obs_next/ag_next.  indices: (e, t, her_mask, future_t) drawn elsewhere
+    (the fast draw) instead of from `rng`."""
     T = episode_batch["actions"].shape[1]
     n_episodes = episode_batch["actions"].shape[0]
-    e, t, her_mask, future_t = draw_her_indices(rng, n_episodes, T, batch, future_p)
+    e, t, her_mask, future_t = indices if indices is not None else draw_her_indices(rng, n_episodes, T, batch, future_p)
     out = {k: v[e, t].copy() for k, v in episode_batch.items()}          # her.py:26
     sel = np.where(her_mask)
     out["g"][sel] = episode_batch["ag"][e[sel], future_t[sel]]           # her.py:35-36
@@ -148,3 +183,8 @@ class EpisodeStore:
     def sample(self, batch, future_p, rng, reward_fn=compute_reward):
         """replay_buffer.py:46-55."""
         return sample_her_transitions(with_next_views(self.buffers, self.current_size), batch, future_p, rng, reward_fn)
+
+    def sample_fast(self, batch, future_p, seed, call, reward_fn=compute_reward):
+        """The same gather / relabel / reward on the fast draw's indices (draw_her_indices_fast)."""
+        idx = draw_her_indices_fast(self.current_size, self.T, batch, future_p, seed, call)
+        return sample_her_transitions(with_next_views(self.buffers, self.current_size), batch, future_p, None, reward_fn, indices=idx)

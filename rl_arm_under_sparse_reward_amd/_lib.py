@@ -49,7 +49,7 @@ ABI_VERSION = 4     # HP_ABI_VERSION of include/rlarm_hip.h this table binds
 
 # entry points declared in include/rlarm_hip_debug.h: diagnostics and test hooks, outside the stable surface
 DEBUG_SYMBOLS = {"hp_ctx_launch_floor", "hp_ctx_event_pair_us", "hp_ctx_clock_mhz", "hp_ctx_calibrate", "hp_buffer_sample_device_us",
-                 "hp_buffer_sample_dev_us",
+                 "hp_buffer_sample_dev_us", "hp_buffer_sample_dev_fast_us",
                  "hp_agent_set_adam", "hp_agent_debug_chain", "hp_agent_debug_timeline", "hp_agent_update_kernels"}
 
 # name -> (restype, argtypes); every symbol declared in include/rlarm_hip.h and include/rlarm_hip_debug.h
@@ -96,6 +96,10 @@ PROTOTYPES = {
     "hp_buffer_enable_f32_rows": (C.c_int, [C.c_void_p]),
     "hp_buffer_sample_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                            C.c_double, C.POINTER(SampleDevOut)]),
+    "hp_buffer_sample_dev_fast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                            C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(SampleDevOut)]),
+    "hp_buffer_sample_dev_fast_us": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                               C.c_int32, C.c_int32, f64p]),
     "hp_buffer_destroy": (None, [C.c_void_p]),
     "hp_compute_reward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p]),

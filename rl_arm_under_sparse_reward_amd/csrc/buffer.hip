@@ -80,7 +80,61 @@ struct FusedSampleArgs {
     float *x, *xn, *a, *r;
     long long *o_e, *o_t, *o_fut;
     unsigned char *o_her;
+    // fast draw (hp_buffer_sample_dev_fast; SURVEY 8b rng_mode = Philox): no plan, the index record of transition m of call
+    // `fast_call` is Philox4x32-10((m, call); seed) -- fs_fast_rec below
+    unsigned long long fast_seed, fast_call;
+    int fast_n_eps;
+    double fast_future_p;
 };
+
+// ---- fast draw: counter-based indices instead of the reference's sequential MT19937 stream (opt-in, NOT the reference's draws) ------
+// her.py:24-33 draws e = randint(N), t = randint(T), u1, u2 from ONE global stream, which makes the index draw of a large batch a
+// sequential kernel (2.0 ms per 2^18 transitions against 59 us for their gather).  Fast mode keys every transition by its own counter:
+//   (r0, r1, r2, r3) = Philox4x32-10(counter = (m lo, m hi, call lo, call hi), key = (seed lo, seed hi))      [Random123, Salmon et al. SC11]
+//   e = floor(r0 N / 2^32), t = floor(r1 T / 2^32), her = r2 2^-32 < future_p, future_t = t + 1 + floor(r3 (T - t) / 2^32)
+// -- her.py's four draws with multiply-shift bounded integers (bias <= N / 2^32) -- so the draw costs a few dozen integer
+// instructions inside the gather kernel.  Deterministic in (seed, call, m); pinned by Random123's known-answer vectors and an
+// numpy twin in the test infrastructure (draw_her_indices_fast).
+__device__ __forceinline__ void fs_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                                 unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1;
+        c3 = (unsigned)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ PlanRec fs_fast_rec(const FusedSampleArgs &A, long long m) {
+    unsigned r[4];
+    fs_philox4x32_10((unsigned)m, (unsigned)((unsigned long long)m >> 32), (unsigned)A.fast_call, (unsigned)(A.fast_call >> 32),
+                     (unsigned)A.fast_seed, (unsigned)(A.fast_seed >> 32), r);
+    PlanRec rec;
+    rec.e = (int)(((unsigned long long)r[0] * (unsigned)A.fast_n_eps) >> 32);
+    rec.t = (int)(((unsigned long long)r[1] * (unsigned)A.T) >> 32);
+    rec.her = ((double)r[2] * 0x1p-32 < A.fast_future_p) ? 1 : 0;
+    rec.fut = rec.t + 1 + (int)(((unsigned long long)r[3] * (unsigned)(A.T - rec.t)) >> 32);
+    return rec;
+}
+// the records of the 2 x FLIGHT transitions of one pass: lane j draws transition base + j, every lane picks up its half's
+template <int FLIGHT>
+__device__ __forceinline__ void fs_fast_recs(const FusedSampleArgs &A, long long base, int lane, int h, PlanRec (&rec)[FLIGHT]) {
+    const long long mj = base + (lane & (2 * FLIGHT - 1));
+    const PlanRec mine = fs_fast_rec(A, mj < A.batch ? mj : A.batch - 1);
+#pragma unroll
+    for (int k = 0; k < FLIGHT; ++k) {
+        const int src = 2 * k + h;
+        rec[k].e = __shfl(mine.e, src);
+        rec[k].t = __shfl(mine.t, src);
+        rec[k].fut = __shfl(mine.fut, src);
+        rec[k].her = __shfl(mine.her, src);
+    }
+}
 
 // FLIGHT transitions per wavefront and pass: 1 for small batches (one minibatch = two dependent memory latencies, as many
 // wavefronts as transitions), 4 from 16 Ki transitions on (more bytes in flight per wavefront, grid-stride).  Every load of a
@@ -182,7 +236,7 @@ __global__ __launch_bounds__(256) void k_gather_fused(const FusedSampleArgs A) {
 #define FS2_FLIGHT 4
 #endif
 typedef double fs_d2 __attribute__((ext_vector_type(2), aligned(8)));
-template <int FLIGHT>
+template <int FLIGHT, bool FAST = false>
 __global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) {
     const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -234,10 +288,14 @@ __global__ __launch_bounds__(256) void k_gather_fused2(const FusedSampleArgs A) 
     const int g_lane = (h << 5) + od + (rc_tail ? ug - 1 : (rc >> 1)), g_slot = rc_tail ? 1 : (rc & 1);
     for (long long base = wave * (2 * FLIGHT); base < A.batch; base += n_waves * (2 * FLIGHT)) {
         PlanRec rec[FLIGHT];
+        if constexpr (FAST) {
+            fs_fast_recs<FLIGHT>(A, base, lane, h, rec);
+        } else {
 #pragma unroll
-        for (int k = 0; k < FLIGHT; ++k) {
-            const long long m = base + 2 * k + h;
-            rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+            for (int k = 0; k < FLIGHT; ++k) {
+                const long long m = base + 2 * k + h;
+                rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+            }
         }
         fs_d2 v[FLIGHT];
         double ra[FLIGHT];
@@ -331,7 +389,7 @@ struct PackedSampleArgs {
     int row_w, goal_w;
     FusedSampleArgs f;
 };
-template <int FLIGHT>
+template <int FLIGHT, bool FAST = false>
 __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P) {
     const FusedSampleArgs &A = P.f;
     const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
@@ -385,10 +443,14 @@ __global__ __launch_bounds__(256) void k_gather_packed(const PackedSampleArgs P)
     union Ld { f4_t f; d2_t d; };
     for (long long base = wave * (2 * FLIGHT); base < A.batch; base += n_waves * (2 * FLIGHT)) {
         PlanRec rec[FLIGHT];
+        if constexpr (FAST) {
+            fs_fast_recs<FLIGHT>(A, base, lane, h, rec);
+        } else {
 #pragma unroll
-        for (int k = 0; k < FLIGHT; ++k) {
-            const long long m = base + 2 * k + h;
-            rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+            for (int k = 0; k < FLIGHT; ++k) {
+                const long long m = base + 2 * k + h;
+                rec[k] = A.plan[m < A.batch ? m : A.batch - 1];
+            }
         }
         Ld v[FLIGHT];
 #pragma unroll
@@ -823,9 +885,15 @@ int hp_buffer_sample(hp_buffer *b, hp_rng *rng, int64_t batch, double future_p, 
 
 // replay_buffer.sample + the learner's preprocessing (ddpg_agent.py:227-243) with device outputs: index draw, then the fused
 // gather.  Asynchronous on the context's stream; the outputs are caller-owned device memory (e.g. torch tensors).
+struct FastDraw {   // hp_buffer_sample_dev_fast: counter-based index draw inside the gather kernel (fs_fast_rec)
+    uint64_t seed, call;
+    double future_p;
+};
 static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_norm *on, hp_norm *gn, int64_t batch,
-                                      double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+                                      double sq_threshold, double clip_obs, const hp_sample_dev_out *o, const FastDraw *fast = nullptr) {
     FusedSampleArgs A;
+    A.fast_seed = fast ? fast->seed : 0ull; A.fast_call = fast ? fast->call : 0ull;
+    A.fast_n_eps = (int)b->current_size; A.fast_future_p = fast ? fast->future_p : 0.0;
     A.obs = b->d_obs; A.ag = b->d_ag; A.g = b->d_g; A.act = b->d_act;
     A.plan = d_plan;
     A.onz = on->d; A.gnz = gn->d;
@@ -845,14 +913,19 @@ static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_no
         HP_KLOG("k_gather_fused2");
         if (batch >= 16384) {
             const int64_t waves = (batch + 2 * FS2_FLIGHT - 1) / (2 * FS2_FLIGHT), wgs = (waves + 3) / 4;
-            hipLaunchKernelGGL(k_gather_fused2<FS2_FLIGHT>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+            const dim3 grid((unsigned)(wgs < cap ? wgs : cap));
+            if (fast) hipLaunchKernelGGL((k_gather_fused2<FS2_FLIGHT, true>), grid, dim3(256), 0, b->ctx->stream, A);
+            else hipLaunchKernelGGL((k_gather_fused2<FS2_FLIGHT, false>), grid, dim3(256), 0, b->ctx->stream, A);
         } else {
             const int64_t waves = (batch + 1) / 2, wgs = (waves + 3) / 4;
-            hipLaunchKernelGGL(k_gather_fused2<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, A);
+            const dim3 grid((unsigned)(wgs < cap ? wgs : cap));
+            if (fast) hipLaunchKernelGGL((k_gather_fused2<1, true>), grid, dim3(256), 0, b->ctx->stream, A);
+            else hipLaunchKernelGGL((k_gather_fused2<1, false>), grid, dim3(256), 0, b->ctx->stream, A);
         }
         HP_CHECK_HIP(hipGetLastError());
         return HP_OK;
     }
+    HP_REQUIRE(!fast, HP_ERR_INVALID, "hp_buffer_sample_dev_fast: needs obs_dim + ceil(goal_dim / 2) + ceil(act_dim / 2) <= 32 and goal_dim, act_dim >= 2");
     // (us per 262144 transitions of a 5000-episode shard: 4 in flight, grid capped at 8 / 32 workgroups per CU 126.8 / 121.0; 8 in
     // flight 133.6; 2 in flight, cap 16: 130.5; 1 in flight, cap 64: 124.0 -- ~2.1 G transitions/s whatever the shape of the launch)
     const int flight = batch >= 16384 ? 4 : 1;
@@ -865,10 +938,12 @@ static int buffer_launch_gather_fused(hp_buffer *b, const PlanRec *d_plan, hp_no
 }
 
 static int buffer_launch_gather_packed(hp_buffer *b, const PlanRec *d_plan, hp_norm *on, hp_norm *gn, int64_t batch,
-                                       double sq_threshold, double clip_obs, const hp_sample_dev_out *o) {
+                                       double sq_threshold, double clip_obs, const hp_sample_dev_out *o, const FastDraw *fast = nullptr) {
     PackedSampleArgs P;
     P.p_row = b->p_row; P.p_goal = b->p_goal; P.row_w = b->row_w; P.goal_w = b->goal_w;
     FusedSampleArgs &A = P.f;
+    A.fast_seed = fast ? fast->seed : 0ull; A.fast_call = fast ? fast->call : 0ull;
+    A.fast_n_eps = (int)b->current_size; A.fast_future_p = fast ? fast->future_p : 0.0;
     A.obs = b->d_obs; A.ag = b->d_ag; A.g = b->d_g; A.act = b->d_act;
     A.plan = d_plan;
     A.onz = on->d; A.gnz = gn->d;
@@ -885,10 +960,14 @@ static int buffer_launch_gather_packed(hp_buffer *b, const PlanRec *d_plan, hp_n
     HP_KLOG("k_gather_packed");
     if (batch >= 16384) {
         const int64_t waves = (batch + 2 * FS2_FLIGHT - 1) / (2 * FS2_FLIGHT), wgs = (waves + 3) / 4;
-        hipLaunchKernelGGL(k_gather_packed<FS2_FLIGHT>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, P);
+        const dim3 grid((unsigned)(wgs < cap ? wgs : cap));
+        if (fast) hipLaunchKernelGGL((k_gather_packed<FS2_FLIGHT, true>), grid, dim3(256), 0, b->ctx->stream, P);
+        else hipLaunchKernelGGL((k_gather_packed<FS2_FLIGHT, false>), grid, dim3(256), 0, b->ctx->stream, P);
     } else {
         const int64_t waves = (batch + 1) / 2, wgs = (waves + 3) / 4;
-        hipLaunchKernelGGL(k_gather_packed<1>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), 0, b->ctx->stream, P);
+        const dim3 grid((unsigned)(wgs < cap ? wgs : cap));
+        if (fast) hipLaunchKernelGGL((k_gather_packed<1, true>), grid, dim3(256), 0, b->ctx->stream, P);
+        else hipLaunchKernelGGL((k_gather_packed<1, false>), grid, dim3(256), 0, b->ctx->stream, P);
     }
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
@@ -955,6 +1034,56 @@ extern "C" int hp_buffer_sample_dev_f32(hp_buffer *b, hp_rng *rng, hp_norm *on, 
     PlanRec *d_plan = b->plan.as<PlanRec>();
     HP_TRY(rng_launch_plan(rng, b->d_meta, 0, b->T, batch, 1, future_p, d_plan));
     return buffer_launch_gather_packed(b, d_plan, on, gn, batch, sq_threshold, clip_obs, o);
+}
+
+// Fast draw (SURVEY 8b rng_mode = Philox; opt-in, NOT the reference's random stream): hp_buffer_sample_dev / _f32 with the index
+// draw inside the gather kernel, keyed by (seed, call, transition) -- no hp_rng, no sequential draw kernel, one launch.  The caller
+// owns the counter: the same (seed, call) gives the same minibatch; a training loop passes seed + rank and call = 0, 1, 2, ...
+extern "C" int hp_buffer_sample_dev_fast(hp_buffer *b, hp_norm *on, hp_norm *gn, int64_t batch, double future_p, double sq_threshold,
+                                         double clip_obs, uint64_t seed, uint64_t call, int32_t f32_rows, const hp_sample_dev_out *o) {
+    HP_REQUIRE(b && on && gn && o, HP_ERR_INVALID, "hp_buffer_sample_dev_fast: null argument");
+    HP_REQUIRE(on->ctx == b->ctx && gn->ctx == b->ctx, HP_ERR_INVALID, "hp_buffer_sample_dev_fast: handles of different contexts");
+    HP_REQUIRE(on->size == b->obs_dim && gn->size == b->goal_dim, HP_ERR_INVALID,
+               "hp_buffer_sample_dev_fast: normalizer sizes (%d, %d) do not match the buffer's observation / goal widths (%d, %d)", on->size,
+               gn->size, b->obs_dim, b->goal_dim);
+    HP_REQUIRE(batch > 0 && clip_obs > 0, HP_ERR_INVALID, "hp_buffer_sample_dev_fast: batch and clip_obs must be positive");
+    HP_SERIALISE(b);
+    HP_REQUIRE(!f32_rows || b->p_row, HP_ERR_STATE, "hp_buffer_sample_dev_fast: hp_buffer_enable_f32_rows first");
+    HP_REQUIRE(b->current_size > 0, HP_ERR_EMPTY, "high <= 0");
+    const FastDraw fd{seed, call, future_p};
+    return f32_rows ? buffer_launch_gather_packed(b, nullptr, on, gn, batch, sq_threshold, clip_obs, o, &fd)
+                    : buffer_launch_gather_fused(b, nullptr, on, gn, batch, sq_threshold, clip_obs, o, &fd);
+}
+
+// diagnostic: device microseconds per hp_buffer_sample_dev_fast launch (outputs into library scratch), `reps` back to back
+extern "C" int hp_buffer_sample_dev_fast_us(hp_buffer *b, hp_norm *on, hp_norm *gn, int64_t batch, double future_p, double sq_threshold,
+                                            double clip_obs, int32_t reps, int32_t f32_rows, double *us) {
+    HP_REQUIRE(b && on && gn && us && batch > 0 && reps > 0, HP_ERR_INVALID, "hp_buffer_sample_dev_fast_us: bad argument");
+    HP_SERIALISE(b);
+    hipStream_t s = b->ctx->stream;
+    const size_t ldx = (size_t)(b->obs_dim + b->goal_dim);
+    if ((size_t)batch * (2 * ldx + b->act_dim + 1) * 4 > b->out.bytes) HP_CHECK_HIP(hipStreamSynchronize(s));
+    HP_TRY(b->out.ensure((size_t)batch * (2 * ldx + b->act_dim + 1) * 4));
+    hp_sample_dev_out o;
+    memset(&o, 0, sizeof(o));
+    o.x = b->out.as<float>();
+    o.x_next = o.x + batch * ldx;
+    o.actions = o.x_next + batch * ldx;
+    o.r = o.actions + batch * b->act_dim;
+    struct Events {
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < 2; ++i) HP_CHECK_HIP(hipEventCreate(&ev.e[i]));
+    HP_TRY(hp_buffer_sample_dev_fast(b, on, gn, batch, future_p, sq_threshold, clip_obs, 1, 0, f32_rows, &o));   // warm
+    HP_CHECK_HIP(hipEventRecord(ev.e[0], s));
+    for (int i = 0; i < reps; ++i) HP_TRY(hp_buffer_sample_dev_fast(b, on, gn, batch, future_p, sq_threshold, clip_obs, 1, 1 + i, f32_rows, &o));
+    HP_CHECK_HIP(hipEventRecord(ev.e[1], s));
+    HP_CHECK_HIP(hipEventSynchronize(ev.e[1]));
+    float ms = 0.f;
+    HP_CHECK_HIP(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+    *us = 1e3 * ms / reps;
+    return HP_OK;
 }
 
 // diagnostic twin of hp_buffer_sample_device_us for the fused kernel (outputs into library scratch); f32_rows != 0: the

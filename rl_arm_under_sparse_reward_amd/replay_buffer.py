@@ -116,7 +116,7 @@ class DeviceEpisodeBuffer:
         _lib.check(self.lib.hp_buffer_enable_f32_rows(self.h))
         self.f32_rows = True
 
-    def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False, f32_rows=False):
+    def sample_device(self, rng, o_norm, g_norm, batch, future_p, sq_threshold, clip_obs, with_indices=False, f32_rows=False, fast=None):
         """hp_buffer_sample_dev: the minibatch as the learner consumes it (ddpg_agent.py:227-243) in torch CUDA tensors
         allocated here: x, x_next [B, obs+goal], actions [B, act], r [B, 1], float32.  The kernels run on the CONTEXT's stream,
         ordered with torch's current stream by events on both sides (_lib.Context.torch_bridge): the context is not rebound, so
@@ -141,7 +141,11 @@ class DeviceEpisodeBuffer:
                 setattr(o, k, t.data_ptr())
         fn = self.lib.hp_buffer_sample_dev_f32 if f32_rows else self.lib.hp_buffer_sample_dev
         with self.ctx.torch_bridge():
-            _lib.check(fn(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold), float(clip_obs), C.byref(o)))
+            if fast is not None:     # (seed, call): counter-based index draw inside the gather kernel, no hp_rng (hp_buffer_sample_dev_fast)
+                _lib.check(self.lib.hp_buffer_sample_dev_fast(self.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold),
+                                                              float(clip_obs), int(fast[0]), int(fast[1]), 1 if f32_rows else 0, C.byref(o)))
+            else:
+                _lib.check(fn(self.h, rng.h, o_norm.h, g_norm.h, B, float(future_p), float(sq_threshold), float(clip_obs), C.byref(o)))
         return (out, idx) if with_indices else out
 
     def __del__(self):
@@ -218,15 +222,30 @@ class replay_buffer:
         `sample_device(..., f32_rows=True)` then reads it.  Everything else keeps reading the reference's float64 arrays."""
         self._dev.enable_f32_rows()
 
-    def sample_device(self, batch_size, o_norm, g_norm, clip_obs=200, f32_rows=False):
+    def enable_fast_draw(self, seed):
+        """Opt into the counter-based index draw (SURVEY 8b `rng_mode` = Philox; hp_buffer_sample_dev_fast) for
+        `sample_device(..., fast_draw=True)`: every call takes the next counter value under this seed (a rank passes seed + rank).
+        NOT the reference's random stream: her.py:24-33's four draws come from Philox4x32-10 keyed by (seed, call, transition),
+        so a minibatch is one kernel launch whatever its size (the MT19937 draw of 2^18 transitions is a 2 ms sequential kernel)."""
+        self._fast_seed, self._fast_calls = int(seed), 0
+
+    def sample_device(self, batch_size, o_norm, g_norm, clip_obs=200, f32_rows=False, fast_draw=False):
         """`sample(batch_size)` followed by the learner's preprocessing (ddpg_agent.py:227-243: _preproc_og, both
         normalizers, concatenate, float32 tensors) in one gather kernel with device outputs: a dict of torch CUDA tensors
         `x` (inputs_norm_tensor), `x_next` (inputs_next_norm_tensor), `actions` (actions_tensor), `r` (r_tensor, [B, 1]).
         Same draws from the same stream and bit-identical float32 values as sample() + normalize() on the host; nothing
         crosses PCIe.  o_norm / g_norm: this package's normalizer objects; clip_obs: arguments.py:87.
         f32_rows=True (after enable_f32_rows()): the throughput mode -- indices, relabelled goals, rewards, goal columns and
-        actions still bit-identical, observation columns those of float32-rounded observations, ~half the bytes."""
+        actions still bit-identical, observation columns those of float32-rounded observations, ~half the bytes.
+        fast_draw=True (after enable_fast_draw(seed)): the indices come from the counter-based draw inside the gather kernel
+        instead of the reference's MT19937 stream (which is then not consumed); everything downstream of the indices unchanged."""
         if self._sampler is None:
             raise TypeError("replay_buffer was built without a sample_func")
+        fast = None
+        if fast_draw:
+            if getattr(self, "_fast_seed", None) is None:
+                raise RuntimeError("sample_device(fast_draw=True): enable_fast_draw(seed) first")
+            fast = (self._fast_seed, self._fast_calls)
+            self._fast_calls += 1
         return self._dev.sample_device(self.rng, o_norm, g_norm, batch_size, self._sampler.future_p,
-                                       self._sampler.sq_threshold, clip_obs, f32_rows=f32_rows)
+                                       self._sampler.sq_threshold, clip_obs, f32_rows=f32_rows, fast=fast)

@@ -496,6 +496,43 @@ def test_f32_rows_follow_the_cycle_graph_and_keep_losses_within_the_bar():
         assert abs(la[name] - lb[name]) <= 1e-5 * max(abs(la[name]), 1e-6), (name, la[name], lb[name])
 
 
+@pytest.mark.parametrize("n,B,k,f32_rows", [(37, 1001, 4, False), (5000, 256, 4, False), (5000, 70000, 8, False), (5000, 20001, 4, True)])
+def test_sample_device_fast_draw_matches_its_oracle_twin(n, B, k, f32_rows):
+    """SURVEY 8b `rng_mode` = Philox as an opt-in (hp_buffer_sample_dev_fast): the index draw inside the gather kernel, Philox4x32-10
+    keyed by (seed, call, transition) -- pinned on the CPU by Random123's known-answer vectors (tests/test_oracle_rng.py) -- must
+    give exactly the indices of the numpy twin, and from them the same float32 minibatch as every other path; the MT19937 stream
+    is left untouched; the same (seed, call) gives the same minibatch, the next call another."""
+    eps = make_episodes(n, seed=1, mode="walk")
+    fp = future_probability("future", k)
+    st = EpisodeStore(100, 27, 3, 4, n * 100)
+    rs = np.random.RandomState(125)
+    st.store_episode(eps, rs)
+    on, gn, o_dev, g_dev = _primed_normalizers(eps)
+    dev = fresh_rng(125)
+    buf = DeviceEpisodeBuffer(n, 100, 27, 3, 4)
+    buf.store(dev, eps)
+    if f32_rows:
+        buf.enable_f32_rows()
+    state = dev.get_state()
+    seed = 125 + (7 << 32)                       # both key words in use
+    first = None
+    for call in (0, 1, (1 << 33) + 5):
+        ref, ridx = st.sample_fast(B, fp, seed, call)
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, fp, squared_threshold(0.05), 200, with_indices=True, f32_rows=f32_rows,
+                                     fast=(seed, call))
+        for key in ("e", "t", "future_t"):
+            assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), (key, call)
+        assert np.array_equal(idx["her"].cpu().numpy().astype(bool), ridx["her"])
+        _assert_minibatch_equal(got, _f32_rounded(ref) if f32_rows else ref, on, gn, 200)
+        if first is None:
+            first = got["x"].cpu().numpy().copy()
+        else:
+            assert not np.array_equal(first, got["x"].cpu().numpy())
+    again = buf.sample_device(dev, o_dev, g_dev, B, fp, squared_threshold(0.05), 200, f32_rows=f32_rows, fast=(seed, 0))
+    assert np.array_equal(bits(again["x"].cpu().numpy()), bits(first))
+    assert state_equal(dev, state[1], state[2])           # the reference's stream was not consumed
+
+
 def test_sample_device_dense_reward_partial_outputs_and_errors():
     """Dense reward (compute_reward :89-90 narrowed to float32 as ddpg_agent.py:243 does), NULL outputs, and the reference's
     error on an empty buffer."""

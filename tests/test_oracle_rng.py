@@ -73,3 +73,21 @@ def test_rng_kat_golden():
         assert np.all((fut >= t + 1) & (fut <= 100))
         key, pos = m.get_state()
         assert np.array_equal(key, g[tag + "_key"]) and pos == int(g[tag + "_pos"]), tag
+
+
+def test_philox4x32_10_known_answers():
+    """The fast draw's generator (opt-in rng_mode of SURVEY 8b) against Random123's published known-answer vectors
+    (kat_vectors: philox4x32 10), and the draw built on it: in range, reproducible, call-dependent."""
+    from oracle.her_replay import draw_her_indices_fast, philox4x32_10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = philox4x32_10(*[np.array([c], dtype=np.uint64) for c in ctr], *key)
+        assert tuple(int(x[0]) for x in got) == want
+    e, t, her, fut = draw_her_indices_fast(5000, 100, 4096, 0.8, seed=125, call=7)
+    assert e.min() >= 0 and e.max() < 5000 and t.min() >= 0 and t.max() < 100
+    assert np.all(fut > t) and np.all(fut <= 100) and 0.75 < her.mean() < 0.85
+    again = draw_her_indices_fast(5000, 100, 4096, 0.8, seed=125, call=7)
+    other = draw_her_indices_fast(5000, 100, 4096, 0.8, seed=125, call=8)
+    assert all(np.array_equal(a, b) for a, b in zip((e, t, her, fut), again)) and not np.array_equal(e, other[0])
