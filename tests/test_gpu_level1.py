@@ -220,3 +220,55 @@ def test_sample_device_leaves_the_fused_learner_on_its_graphs():
     for a, b in zip(plain[:3], mixed[:3]):
         assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
     assert len(mixed[5]) == 4 and all(np.isfinite(v) for v in mixed[5])
+
+
+def test_borrow_and_return_stream_contract():
+    """hp_ctx_borrow_stream / hp_ctx_return_stream (ABI 4): one borrow at a time, a return needs a borrow, borrowing the stream the
+    context is on already is a no-op, and after the return the context is on the stream it was on before -- with the work it
+    enqueues next ordered behind what ran on the borrowed stream (a store behind a sample behind a store, read back)."""
+    import ctypes as C
+    from rl_arm_under_sparse_reward_amd import _lib
+    from gpu_common import DeviceEpisodeBuffer
+
+    c = ctx()
+    lib = c.lib
+    mine = C.c_void_p()
+    _lib.check(lib.hp_ctx_get_stream(c.h, C.byref(mine)))
+    assert (mine.value or 0) > 2                                    # the context's own stream
+    assert lib.hp_ctx_return_stream(c.h) != 0                       # nothing borrowed
+    side = torch.cuda.Stream()
+    _lib.check(lib.hp_ctx_borrow_stream(c.h, C.c_void_p(side.cuda_stream)))
+    now = C.c_void_p()
+    _lib.check(lib.hp_ctx_get_stream(c.h, C.byref(now)))
+    assert now.value == side.cuda_stream
+    assert lib.hp_ctx_borrow_stream(c.h, C.c_void_p(side.cuda_stream)) != 0      # one at a time
+    _lib.check(lib.hp_ctx_return_stream(c.h))
+    _lib.check(lib.hp_ctx_get_stream(c.h, C.byref(now)))
+    assert now.value == mine.value
+    _lib.check(lib.hp_ctx_borrow_stream(c.h, mine))                 # the stream it is on: nothing to order, nothing left foreign
+    _lib.check(lib.hp_ctx_return_stream(c.h))
+    # ordering across a borrow: store (own stream) -> sample on a side stream -> store again (own stream) -> read back
+    rng = fresh_rng(3)
+    buf = DeviceEpisodeBuffer(4, 100, 27, 3, 4)
+    first, second = make_episodes(4, seed=1, mode="walk"), make_episodes(4, seed=2, mode="walk")
+    o_dev, g_dev = normalizer(27, default_clip_range=5, ctx=c), normalizer(3, default_clip_range=5, ctx=c)
+    buf.store(rng, first)
+    with torch.cuda.stream(side):
+        from rl_arm_under_sparse_reward_amd.her import squared_threshold
+        a = buf.sample_device(rng, o_dev, g_dev, 4096, 0.8, squared_threshold(0.05), 200)        # reads `first` on the side stream
+    buf.store(rng, second)                                                       # a full buffer: random slots overwritten, behind the sample
+    side.synchronize()
+    c.synchronize()
+    rs = np.random.RandomState(3)
+    from oracle.her_replay import EpisodeStore
+    st = EpisodeStore(100, 27, 3, 4, 400)
+    st.store_episode(first, rs)
+    ref, _ = st.sample(4096, 0.8, rs)
+    from oracle.running_norm import RunningNorm
+    on, gn = RunningNorm(27, default_clip_range=5), RunningNorm(3, default_clip_range=5)
+    from oracle.ddpg_update import minibatch_tensors
+    x, _, _, _ = minibatch_tensors(ref, on, gn, 200)
+    assert np.array_equal(bits(a["x"].cpu().numpy()), bits(x.numpy()))          # the sample saw `first`, whole
+    st.store_episode(second, rs)
+    assert np.array_equal(buf.read("obs", 0, 4), st.buffers["obs"][:4])        # and the second store landed after it
+    assert state_equal(rng, *rs.get_state()[1:3])

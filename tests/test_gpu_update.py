@@ -795,3 +795,33 @@ def test_a_failing_deferred_update_names_itself_and_stays_owed():
     empty.buffer.store_episode(make_episodes(2, seed=11, mode="walk"))
     empty._update_network(2)
     assert np.isfinite(empty.last_losses(2)).all()
+
+
+@pytest.mark.parametrize("batch,n_updates,want", [
+    (256, 40, ["k_fb_split8<0>", "k_gemm_lds_adam"]),            # the headline: split launch + the actor's tiles
+    (256, 4, ["k_fb_slab8", "k_gemm_lds_adam"]),                 # short sequences keep the two-launch form
+    (512, 40, ["k_fb_slab8", "k_gemm_lds_adam_ride_u"]),         # 256 chains fill the CUs: plan + gather ride in the tile launch
+    (1024, 40, ["k_fb_slab8", "k_gemm_lds_adam_ride"]),
+    (4096, 40, ["k_fb_slab32", "k_dw64_adam"])])
+def test_update_kernels_names_what_the_launch_logic_enqueues(batch, n_updates, want):
+    """hp_agent_update_kernels (round 6): the kernels of a sequence read off the library's own launch logic, run under a stream
+    capture that is thrown away.  Per engine shape: the names of a steady-state update, the sequence's opening and closing
+    launches, and -- the capture being discarded -- no effect on the learner: the same updates afterwards give the same bits
+    as on an agent that was never asked."""
+    def run(ask):
+        torch.manual_seed(0)
+        agent, rng = make_agent(batch=batch, n_eps=32, seed=21)
+        agent.buffer.store_episode(make_episodes(15, seed=9, mode="walk"))
+        agent._update_normalizer()
+        k = agent.update_kernels(n_updates) if ask else None
+        agent._update_network(6)
+        return agent, k, (agent._get_flat(NET_ACTOR), agent._get_flat(NET_CRITIC), agent.last_losses(6), rng.get_state()[1], np.asarray([rng.get_state()[2]]))
+    agent, k, asked = run(True)
+    assert len(k["updates"]) == n_updates
+    assert k["updates"][min(2, n_updates - 1)] == want, k["updates"][:3]
+    assert k["open"] and k["open"][0].startswith("k_draw_plan")
+    assert ("k_fb_split8<0>" in k["prologue"]) == want[0].startswith("k_fb_split8")
+    assert agent.engine()["kernels_per_update"] == agent.update_kernels()["updates"][2]
+    _, _, plain = run(False)
+    for a, b in zip(asked, plain):
+        assert np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
