@@ -61,22 +61,23 @@ def worker(rank, world, port, out_dir, cycles, updates):
 def main():
     import tempfile
     cycles, updates = int(os.environ.get("CYCLES", "300")), int(os.environ.get("UPDATES", "12"))
+    world = int(os.environ.get("WORLD", "2"))     # 3 / 4: every rank reads every peer's tile (3 x 48 and 4 x 48 chains still fit the CUs)
     for attempt in range(4):
         out = tempfile.mkdtemp()
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         try:
-            mp.spawn(worker, args=(2, port, out, cycles, updates), nprocs=2, join=True)
+            mp.spawn(worker, args=(world, port, out, cycles, updates), nprocs=world, join=True)
         except Exception as e:      # the shared-device rehearsal needs both launches co-resident: bounded waits give up loudly otherwise
             print(f"attempt {attempt + 1}: {str(e)[-300:]}")
             continue
-        r = [torch.load(os.path.join(out, f"soak{k}.pt"), weights_only=False) for k in range(2)]
-        same = all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(r[0]["nets"], r[1]["nets"]))
-        print(f"{cycles} cycles x {updates} updates = {cycles * updates} exchange epochs per rank; kernels {r[0]['kernels']}")
+        r = [torch.load(os.path.join(out, f"soak{k}.pt"), weights_only=False) for k in range(world)]
+        same = all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for q in r[1:] for a, b in zip(r[0]["nets"], q["nets"]))
+        print(f"world {world}: {cycles} cycles x {updates} updates = {cycles * updates} exchange epochs per rank; kernels {r[0]['kernels']}")
         print(f"replicas bit-identical (actor, critic, both targets): {same}; peer error words {r[0]['err']}, {r[1]['err']}; "
               f"normalizer means equal: {np.array_equal(r[0]['o_mean'], r[1]['o_mean'])}; losses finite: "
               f"{bool(np.all(np.isfinite(r[0]['losses'])) and np.all(np.isfinite(r[1]['losses'])))}, differ per rank: "
-              f"{not np.array_equal(r[0]['losses'], r[1]['losses'])}; {r[0]['us_per_update']:.1f} us/update (two ranks on ONE device)")
-        sys.exit(0 if same and r[0]["err"] == 0 and r[1]["err"] == 0 else 1)
+              f"{not np.array_equal(r[0]['losses'], r[1]['losses'])}; {r[0]['us_per_update']:.1f} us/update ({world} ranks on ONE device)")
+        sys.exit(0 if same and all(q["err"] == 0 for q in r) else 1)
     sys.exit(2)
 
 
