@@ -95,7 +95,10 @@ class Runner:
         self.feeder = None
         if a.feeder_episodes > 0:
             # host feeder: one batch of episodes per cycle from a second thread; the library's
-            # per-context lock orders its stores with the cycles on the stream
+            # per-context lock orders its stores with the cycles on the stream.  The thread is released right BEHIND a cycle's
+            # launches (its host-side staging overlaps the cycle running on the device) and the next cycle's launches wait for
+            # that CALL to have been made: which cycle samples which episodes must not depend on which thread wins the lock
+            # (it did, in about one run of ten on a loaded box: same replicas on every rank, other losses than the run before)
             import threading
             self.feed_pool = [make_episodes(a.feeder_episodes, seed=20_000 + 31 * rank + i) for i in range(4)]
             self.feed_sem = threading.Semaphore(0)
@@ -145,13 +148,13 @@ class Runner:
         ag = self.agent
         while k > 0:
             if self.in_cycle == 0 and self.feeder is not None:
-                self.feed_sem.release()      # one feeder batch per cycle, concurrent with it
-                self._releases += 1
+                self._feeder_wait()          # the previous cycle's batch has been stored (stream order: behind that cycle)
             if self.in_cycle == 0 and self.env_feeder is not None:
                 ag.policy_snapshot()         # the rollout workers' policy follows the learner one cycle behind
             if self.in_cycle == 0 and k >= N_BATCHES and (self.world == 1 or ag._native_comm is not None
                                                           or ag._peer is not None):
                 ag.train_cycle(self.pool[self.cycle % len(self.pool)], N_BATCHES)   # one hipGraph launch
+                self._feeder_release()
                 self.cycle += 1
                 self.opens += 1
                 self.closes += 1
@@ -166,15 +169,26 @@ class Runner:
             k -= n
             if self.in_cycle == N_BATCHES:
                 ag._soft_update_target_network()
+                self._feeder_release()
                 self.in_cycle = 0
                 self.cycle += 1
                 self.closes += 1
 
+    def _feeder_release(self):
+        if self.feeder is not None:          # one feeder batch per cycle, staged while the device runs the cycle
+            self.feed_sem.release()
+            self._releases += 1
+
+    def _feeder_wait(self):
+        import time
+        while self.fed < self._releases:
+            if not self.feeder.is_alive():
+                raise RuntimeError("bench: the host feeder thread died (its store_episode raised)")
+            time.sleep(0.0001)
+
     def sync(self):
         if self.feeder is not None:          # the feeder's stores belong to the cycles that released them
-            import time
-            while self.fed < self._releases:
-                time.sleep(0.0002)
+            self._feeder_wait()
         self.ctx.synchronize()
         self.torch.cuda.synchronize()
 
