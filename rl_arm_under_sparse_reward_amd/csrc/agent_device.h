@@ -157,15 +157,32 @@ extern __device__ unsigned long long g_gemm_tl[32];
 #define ADAM_STAMP(k) do { } while (0)
 #endif
 #define ADAM_FRAG_LOOKUP (-2)   // of_known: find the fragment offsets from the arena index (frag8_offsets: a walk over the layout + a division)
+// quad8 (gemm_tile's epilogue): the lanes l ^ 8, l ^ 16, l ^ 24 of this lane's 32 hold rows (n & 3) ^ 1, ^ 2, ^ 3 of the same 4-row
+// group at the same 4 reduction indices, and all four call with od_known >= 0 -- the dX copy then goes out as ONE float4 per lane
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S,
-                                            int of_known = ADAM_FRAG_LOOKUP, int od_known = -1);
+                                            int of_known = ADAM_FRAG_LOOKUP, int od_known = -1, bool quad8 = false);
+
+// 4 x 4 transposition across the lanes l, l ^ 8, l ^ 16, l ^ 24 (i = this lane's row of the four = (l >> 3) & 3): lane i ends up with
+// {a_0[i], a_1[i], a_2[i], a_3[i]}.  ds_swizzle in bit-mask mode (xor within 32 lanes): LDS crossbar, no memory, no address register.
+__device__ __forceinline__ float lane_pick4(const float (&a)[4], int idx) {
+    const float lo = (idx & 1) ? a[1] : a[0], hi = (idx & 1) ? a[3] : a[2];
+    return (idx & 2) ? hi : lo;
+}
+__device__ __forceinline__ float4 quad8_transpose4(const float (&a)[4], int i) {
+    float r[4];   // r[x]: element i of the lane whose row is i ^ x
+    r[0] = lane_pick4(a, i);
+    r[1] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(lane_pick4(a, i ^ 1)), 0x201F));   // xor 8
+    r[2] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(lane_pick4(a, i ^ 2)), 0x401F));   // xor 16
+    r[3] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(lane_pick4(a, i ^ 3)), 0x601F));   // xor 24
+    return make_float4(lane_pick4(r, i), lane_pick4(r, i ^ 1), lane_pick4(r, i ^ 2), lane_pick4(r, i ^ 3));   // out[j] = r[i ^ j]
+}
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4]) {
     AdamState4 S;
     adam_fetch4(S, F, idx0);
     adam_apply4(F, idx0, g, S);
 }
 __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const float (&g)[4], const AdamState4 &S, int of_known,
-                                            int od_known) {
+                                            int od_known, bool quad8) {
     const float neg_step_size = S.neg_step_size;
     const float bc2_sqrt = S.bc2_sqrt;
     ADAM_STAMP(0);
@@ -215,7 +232,14 @@ __device__ __forceinline__ void adam_apply4(const AdamFuse &F, int idx0, const f
             else *reinterpret_cast<float4 *>(F.fragF + of) = make_float4(pp[0], pp[1], pp[2], pp[3]);
         }
         if (of >= 0 && F.tgt) *reinterpret_cast<float4 *>(F.fragFT + of) = make_float4(tt[0], tt[1], tt[2], tt[3]);
-        if (od >= 0) {
+        if (quad8) {
+            // rows n .. n + 3 at reduction index k are ONE float4 of the dX copy (frag8_dx_index): this lane (row i of its group) takes
+            // k = k0 + i of the four lanes' 4 x 4 block -- 16 dword stores at 16-byte stride become four 16-byte stores, 64 B in a row
+            const int i = (int)(threadIdx.x >> 3) & 3;
+            const float4 t = quad8_transpose4(pp, i);
+            if (F.wt) wt_store4(F.fragD + od + 3 * i, t);
+            else *reinterpret_cast<float4 *>(F.fragD + od + 3 * i) = t;
+        } else if (od >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (F.wt) wt_store(F.fragD + od + 4 * j, pp[j]);

@@ -23,6 +23,9 @@
 // operands are prefetched before the products (every kernel starts cache-cold).
 #pragma once
 
+#ifndef ADAM_QUAD8
+#define ADAM_QUAD8 1   // -DADAM_QUAD8=0: the dX copies as four dword stores per lane (A/B builds)
+#endif
 #define GL_THREADS 512
 #define GL_WAVES 8
 #define GL_KC 256
@@ -538,7 +541,9 @@ __device__ __forceinline__ void gemm_tile(const GemmGroup &grp, const AdamFuse *
                 of = p.frag_layer <= 3 ? tw0 + frag8_fwd_index(em, en, p.ldc) : -1;
                 od = p.frag_layer >= 2 ? tw0 + frag8_dx_index(em, en, p.M) : -1;
             }
-            adam_apply4(*F, base, v, ast, of, od);
+            // whole 4-row groups with a dX copy (layers 2-4): the four lanes of a group hand their quads round (adam_apply4, quad8)
+            const bool quad8 = ADAM_QUAD8 && od >= 0 && (vm & 3) == 0;
+            adam_apply4(*F, base, v, ast, of, od, quad8);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
