@@ -533,6 +533,71 @@ def test_sample_device_fast_draw_matches_its_oracle_twin(n, B, k, f32_rows):
     assert state_equal(dev, state[1], state[2])           # the reference's stream was not consumed
 
 
+def _device_fuzz_shapes():
+    rs = np.random.RandomState(606)
+    cases = [(1, 1, 1, 27, 3, 4), (1, 2, 33, 1, 1, 1), (2, 1, 4097, 28, 4, 4), (5, 3, 16385, 31, 1, 2)]   # one episode / one timestep / the
+    for _ in range(10):                                                                              # widest shapes of each kernel
+        cases.append((int(rs.randint(1, 30)), int(rs.randint(1, 50)), int(rs.choice([1, 7, 64, 255, 1000, 4099, 20000])),
+                      int(rs.randint(1, 45)), int(rs.randint(1, 7)), int(rs.randint(1, 8))))
+    return cases
+
+
+@pytest.mark.parametrize("n,T,B,od,gd,ad", _device_fuzz_shapes())
+def test_sample_device_fuzz_over_shapes_and_modes(n, T, B, od, gd, ad):
+    """Seeded sweep of hp_buffer_sample_dev / _f32 / _fast over buffer, episode, batch and row shapes (one episode, one timestep, one
+    transition, batches on both sides of the kernels' in-flight switch, rows too wide for the packed kernels): every mode the shape
+    admits against the oracle -- MT19937 draw on float64 rows, on the float32 mirror where a row fits one line, Philox draw."""
+    from oracle.running_norm import RunningNorm
+    from rl_arm_under_sparse_reward_amd.normalizer import normalizer
+    from gpu_common import ctx
+
+    rs0 = np.random.RandomState(1000 * n + 10 * T + od)
+    obs = rs0.uniform(-1, 1, (n, T + 1, od))
+    ag = rs0.uniform(0, 0.2, (n, T + 1, gd))
+    g = np.repeat(rs0.uniform(0, 0.2, (n, 1, gd)), T, axis=1)
+    act = rs0.uniform(-0.5, 0.5, (n, T, ad))
+    eps = [obs, ag, g, act]
+    on, gn = RunningNorm(od, default_clip_range=5), RunningNorm(gd, default_clip_range=5)
+    o_dev, g_dev = normalizer(od, default_clip_range=5, ctx=ctx()), normalizer(gd, default_clip_range=5, ctx=ctx())
+    for a_, b_, v in ((on, o_dev, obs[:, 0] * 2.5 - 0.2), (gn, g_dev, ag[:, -1])):
+        a_.update(v); b_.update(v)
+        a_.recompute_stats(); b_.recompute_stats()
+    st = EpisodeStore(T, od, gd, ad, n * T)
+    rs = np.random.RandomState(9)
+    st.store_episode(eps, rs)
+    dev = fresh_rng(9)
+    buf = DeviceEpisodeBuffer(n, T, od, gd, ad)
+    buf.store(dev, eps)
+    sq, clip = squared_threshold(0.05), 0.9
+    ref, ridx = st.sample(B, 0.8, rs)
+    got, idx = buf.sample_device(dev, o_dev, g_dev, B, 0.8, sq, clip, with_indices=True)
+    _assert_minibatch_equal(got, ref, on, gn, clip)
+    for key in ("e", "t", "future_t"):
+        assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), key
+    mirror = od + ad <= 32 and od <= 28 and gd <= 4
+    if mirror:
+        buf.enable_f32_rows()
+        ref, ridx = st.sample(B, 0.8, rs)
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, 0.8, sq, clip, with_indices=True, f32_rows=True)
+        _assert_minibatch_equal(got, _f32_rounded(ref), on, gn, clip)
+        assert np.array_equal(idx["future_t"].cpu().numpy(), ridx["future_t"])
+    else:
+        with pytest.raises(Exception):
+            buf.enable_f32_rows()
+    assert state_equal(dev, *rs.get_state()[1:3])
+    packed = od + (gd + 1) // 2 + (ad + 1) // 2 <= 32 and gd >= 2 and ad >= 2     # the in-kernel draw lives in the 32-lane kernels only
+    if not packed:
+        with pytest.raises(ValueError, match="hp_buffer_sample_dev_fast: needs obs_dim"):
+            buf.sample_device(dev, o_dev, g_dev, B, 0.8, sq, clip, fast=(31337, 4))
+    for f32_rows in ((False, True) if mirror else (False,)) if packed else ():
+        ref, ridx = st.sample_fast(B, 0.8, 31337, 4)
+        got, idx = buf.sample_device(dev, o_dev, g_dev, B, 0.8, sq, clip, with_indices=True, f32_rows=f32_rows, fast=(31337, 4))
+        for key in ("e", "t", "future_t"):
+            assert np.array_equal(idx[key].cpu().numpy(), ridx[key]), (key, f32_rows)
+        _assert_minibatch_equal(got, _f32_rounded(ref) if f32_rows else ref, on, gn, clip)
+    assert state_equal(dev, *rs.get_state()[1:3])
+
+
 def test_sample_device_dense_reward_partial_outputs_and_errors():
     """Dense reward (compute_reward :89-90 narrowed to float32 as ddpg_agent.py:243 does), NULL outputs, and the reference's
     error on an empty buffer."""
